@@ -1,0 +1,420 @@
+// Field arithmetic for the Stark prime p = 2^251 + 17*2^192 + 1 and the curve order N, built for
+// the gfx950 VALU: nine SIGNED 29-bit limbs per element and 64-bit signed column accumulators.
+//
+// Why this shape (measured on MI355X, tools/ubench/valu_rate.hip): v_mad_i64_i32 issues at
+// ~5.2 cycles per wave64 instruction, essentially the same as v_add_co/v_addc (~4.8).  Carry
+// handling therefore costs as much as multiplying, so the representation is chosen to have NO
+// carries inside a product: 9 limbs x 29 bits give 81 multiply-accumulates into 17 columns whose
+// sums stay below 2^63, additions and subtractions are plain limb-wise adds (lazy, signed), and
+// the Montgomery radix R = 2^261 leaves ~9 bits of value headroom so no conditional subtraction
+// is ever needed between multiplications.  p = 1 + 17*2^18 * 2^(6*29) + 2^19 * 2^(8*29) has only
+// three non-zero limbs and p = 1 (mod 2^29), so a reduction step is q = -c_i mod 2^29 followed by
+// two multiply-adds.
+//
+// Conventions
+//   * "N-form": limbs 0..7 in [0, 2^29), limb 8 small and signed; value in (-4p, 4p).  This is
+//     what fe_mul / fe_sqr / fe_carry return.
+//   * fe_add / fe_sub are limb-wise and do not normalise.  A product needs
+//     sum_j |a_i||b_j| < 2^63; every call site states its bound in units of 2^29 ("B=k").
+//   * All elements that take part in multiplications are in Montgomery form (x * R mod p).
+//
+// The same header compiles for the host (g++) so the arithmetic can be unit-tested without a GPU;
+// the product library only ever runs it on the device (plus one-off table seeds at sp_init).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SP_HD __host__ __device__ __forceinline__
+#define SP_CONST_MEM
+#else
+#define SP_HD inline
+#endif
+
+#if defined(SP_CHECK_BOUNDS) && !defined(__HIPCC__)
+#include <stdio.h>
+#include <stdlib.h>
+#define SP_CHK32(expr64)                                                        \
+  do {                                                                          \
+    long long v__ = (long long)(expr64);                                        \
+    if (v__ > 2147483647LL || v__ < -2147483648LL) {                            \
+      fprintf(stderr, "limb overflow at %s:%d\n", __FILE__, __LINE__);          \
+      abort();                                                                  \
+    }                                                                           \
+  } while (0)
+#define SP_CHK64(expr128)                                                       \
+  do {                                                                          \
+    __int128 v__ = (expr128);                                                   \
+    if (v__ > (__int128)9223372036854775807LL || v__ < -(__int128)9223372036854775807LL) { \
+      fprintf(stderr, "column overflow at %s:%d\n", __FILE__, __LINE__);        \
+      abort();                                                                  \
+    }                                                                           \
+  } while (0)
+#else
+#define SP_CHK32(e) ((void)0)
+#define SP_CHK64(e) ((void)0)
+#endif
+
+namespace sp {
+
+constexpr int NL = 9;
+constexpr int LB = 29;
+constexpr uint32_t LMASK = (1u << LB) - 1u;
+
+struct fe {
+  int32_t l[NL];
+};
+
+// ---- constants (tools/gen_consts.py prints these; tests/test_field_host.py re-derives them) ----
+// p = sum P_LIMB[i] * 2^(29 i)
+constexpr int32_t P6 = 0x440000;  // 17 * 2^18
+constexpr int32_t P8 = 0x80000;   // 2^19
+// R mod p, R^2 mod p with R = 2^261
+constexpr fe FE_ONE_M = {{0x1ffffc01, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x1fffffff, 0x1fffffff,
+                          0x1043ffff, 0x1ffffff7, 0x7ffff}};
+constexpr fe FE_R2 = {{0x100001, 0x1fae6fc0, 0x1fffffff, 0x9987f, 0x0, 0x1ffedf00, 0x43ffff,
+                       0xf004400, 0x752ad}};
+constexpr fe FE_ZERO = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+constexpr fe FE_P = {{1, 0, 0, 0, 0, 0, P6, 0, P8}};
+
+// ---- 256-bit packed <-> limbs ----
+struct u256 {
+  uint32_t w[8];
+};
+
+SP_HD fe fe_unpack(const u256& a) {
+  fe r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int bit = LB * k, wi = bit >> 5, sh = bit & 31;
+    uint64_t two = (uint64_t)a.w[wi] | ((uint64_t)(wi + 1 < 8 ? a.w[wi + 1] : 0u) << 32);
+    r.l[k] = (int32_t)((uint32_t)(two >> sh) & LMASK);
+  }
+  r.l[8] = (int32_t)(a.w[7] >> 8);
+  return r;
+}
+
+// Requires canonical limbs (all in [0,2^29), value < 2^256).
+SP_HD u256 fe_pack(const fe& a) {
+  u256 r;
+#pragma unroll
+  for (int wi = 0; wi < 8; ++wi) {
+    const int bit = 32 * wi, k = bit / LB, sh = bit - k * LB;  // word starts inside limb k
+    uint64_t two = (uint64_t)(uint32_t)a.l[k] >> sh;
+    two |= (uint64_t)(uint32_t)a.l[k + 1] << (LB - sh);
+    if (k + 2 < NL) two |= (uint64_t)(uint32_t)a.l[k + 2] << (2 * LB - sh);
+    r.w[wi] = (uint32_t)two;
+  }
+  return r;
+}
+
+// ---- lazy add / sub / small multiples ----
+SP_HD fe fe_add(const fe& a, const fe& b) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { SP_CHK32((int64_t)a.l[i] + b.l[i]); r.l[i] = a.l[i] + b.l[i]; }
+  return r;
+}
+SP_HD fe fe_sub(const fe& a, const fe& b) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { SP_CHK32((int64_t)a.l[i] - b.l[i]); r.l[i] = a.l[i] - b.l[i]; }
+  return r;
+}
+SP_HD fe fe_neg(const fe& a) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = -a.l[i];
+  return r;
+}
+SP_HD fe fe_dbl(const fe& a) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { SP_CHK32((int64_t)a.l[i] * 2); r.l[i] = a.l[i] * 2; }
+  return r;
+}
+
+// Signed carry pass: limbs 0..7 -> [0,2^29), limb 8 keeps the (signed) rest.  Value unchanged.
+SP_HD fe fe_carry(const fe& a) {
+  fe r;
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    SP_CHK32((int64_t)a.l[i] + c);
+    int32_t v = a.l[i] + c;
+    r.l[i] = (int32_t)((uint32_t)v & LMASK);
+    c = v >> LB;  // arithmetic
+  }
+  r.l[8] = a.l[8] + c;
+  return r;
+}
+
+// ---- column products ----
+struct cols {
+  int64_t c[17];
+};
+
+SP_HD void cols_zero(cols& t) {
+#pragma unroll
+  for (int i = 0; i < 17; ++i) t.c[i] = 0;
+}
+// t += a*b   (81 v_mad_i64_i32)
+SP_HD void cols_mac(cols& t, const fe& a, const fe& b) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      SP_CHK64((__int128)t.c[i + j] + (__int128)a.l[i] * b.l[j]);
+      t.c[i + j] += (int64_t)a.l[i] * (int64_t)b.l[j];
+    }
+}
+// t -= a*b
+SP_HD void cols_msub(cols& t, const fe& a, const fe& b) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      SP_CHK64((__int128)t.c[i + j] - (__int128)a.l[i] * b.l[j]);
+      t.c[i + j] -= (int64_t)a.l[i] * (int64_t)b.l[j];
+    }
+}
+// t += a*a   (45 multiply-accumulates)
+SP_HD void cols_sqr(cols& t, const fe& a) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    SP_CHK64((__int128)t.c[2 * i] + (__int128)a.l[i] * a.l[i]);
+    t.c[2 * i] += (int64_t)a.l[i] * (int64_t)a.l[i];
+    SP_CHK32((int64_t)a.l[i] * 2);
+    const int32_t d = a.l[i] * 2;
+#pragma unroll
+    for (int j = i + 1; j < NL; ++j) {
+      SP_CHK64((__int128)t.c[i + j] + (__int128)d * a.l[j]);
+      t.c[i + j] += (int64_t)d * (int64_t)a.l[j];
+    }
+  }
+}
+
+// Montgomery reduction mod p: returns (T + q p) / 2^261 in N-form, value in (T/R, T/R + p).
+SP_HD fe fe_reduce(cols& t) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const uint32_t q = (0u - (uint32_t)t.c[i]) & LMASK;  // p = 1 mod 2^29  =>  q = -c_i
+    t.c[i + 1] += (t.c[i] + (int64_t)q) >> LB;           // exact: low 29 bits are zero
+    SP_CHK64((__int128)t.c[i + 6] + (__int128)q * P6);
+    t.c[i + 6] += (int64_t)q * (int64_t)P6;
+    SP_CHK64((__int128)t.c[i + 8] + ((__int128)q << 19));
+    t.c[i + 8] += (int64_t)q << 19;  // P8 = 2^19; i + 8 <= 16
+  }
+  fe r;
+  int64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t v = t.c[9 + k] + carry;
+    r.l[k] = (int32_t)((uint32_t)v & LMASK);
+    carry = v >> LB;
+  }
+  SP_CHK32(carry);
+  r.l[8] = (int32_t)carry;
+  return r;
+}
+
+SP_HD fe fe_mul(const fe& a, const fe& b) {
+  cols t;
+  cols_zero(t);
+  cols_mac(t, a, b);
+  return fe_reduce(t);
+}
+SP_HD fe fe_sqr(const fe& a) {
+  cols t;
+  cols_zero(t);
+  cols_sqr(t, a);
+  return fe_reduce(t);
+}
+// a*b - c*d with a single reduction
+SP_HD fe fe_mul_sub_mul(const fe& a, const fe& b, const fe& c, const fe& d) {
+  cols t;
+  cols_zero(t);
+  cols_mac(t, a, b);
+  cols_msub(t, c, d);
+  return fe_reduce(t);
+}
+// a*b + c*d with a single reduction
+SP_HD fe fe_mul_add_mul(const fe& a, const fe& b, const fe& c, const fe& d) {
+  cols t;
+  cols_zero(t);
+  cols_mac(t, a, b);
+  cols_mac(t, c, d);
+  return fe_reduce(t);
+}
+
+// ---- canonical form ----
+// a in N-form with value in (-p, 2p)  ->  limbs of the unique representative in [0, p).
+SP_HD bool fe_geq_p_canon_limbs(const fe& a) {  // a has non-negative normalised limbs
+  // compare with p = (1,0,0,0,0,0,P6,0,P8) from the top limb down
+  if (a.l[8] != P8) return a.l[8] > P8;
+  if (a.l[7] != 0) return true;
+  if (a.l[6] != P6) return a.l[6] > P6;
+  if ((a.l[5] | a.l[4] | a.l[3] | a.l[2] | a.l[1]) != 0) return true;
+  return a.l[0] >= 1;
+}
+SP_HD fe fe_canon(const fe& a_in) {
+  fe a = fe_carry(a_in);
+  // make non-negative: add p while negative (at most once for the documented range; loop twice
+  // for safety), then subtract p while >= p (at most twice).
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (a.l[8] < 0) a = fe_carry(fe_add(a, FE_P));
+  }
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    if (fe_geq_p_canon_limbs(a)) a = fe_carry(fe_sub(a, FE_P));
+  }
+  return a;
+}
+
+// Montgomery <-> plain.  to_mont input: canonical limbs of x (< p); output N-form of x*R.
+SP_HD fe fe_to_mont(const fe& a) { return fe_mul(a, FE_R2); }
+// output canonical limbs of a/R mod p
+SP_HD fe fe_from_mont(const fe& a) {
+  cols t;
+  cols_zero(t);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) t.c[i] = a.l[i];
+  return fe_canon(fe_reduce(t));
+}
+SP_HD bool fe_is_zero(const fe& a) {  // a in Montgomery N-form (|value| < 16p)
+  fe c = fe_from_mont(a);
+  int32_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc |= c.l[i];
+  return acc == 0;
+}
+SP_HD bool fe_eq(const fe& a, const fe& b) { return fe_is_zero(fe_carry(fe_sub(a, b))); }
+
+// ---- exponentiations ----
+SP_HD fe fe_sqr_n(fe a, int n) {
+  for (int i = 0; i < n; ++i) a = fe_sqr(a);
+  return a;
+}
+// a^(2^59 + 16)
+SP_HD fe fe_pow_2p59_plus16(const fe& a) {
+  fe t = fe_sqr_n(a, 55);   // a^(2^55)
+  t = fe_mul(t, a);         // a^(2^55 + 1)
+  return fe_sqr_n(t, 4);    // a^(2^59 + 16)
+}
+// a^(p-2):  p - 2 = (2^59 + 16) * 2^192 + (2^192 - 1)
+SP_HD fe fe_inv(const fe& a) {
+  // a^63
+  fe a2 = fe_sqr(a);
+  fe a3 = fe_mul(a2, a);
+  fe a7 = fe_mul(fe_sqr(a3), a);
+  fe a63 = fe_mul(fe_sqr_n(a7, 3), a7);
+  fe r = fe_pow_2p59_plus16(a);
+  for (int i = 0; i < 32; ++i) {  // 32 windows of six one-bits
+    r = fe_sqr_n(r, 6);
+    r = fe_mul(r, a63);
+  }
+  return r;
+}
+// Legendre symbol test: a^((p-1)/2) == 1, (p-1)/2 = (2^59 + 17) * 2^191.  a must be non-zero.
+SP_HD bool fe_is_qr(const fe& a) {
+  fe t = fe_mul(fe_pow_2p59_plus16(a), a);  // a^(2^59 + 17)
+  t = fe_sqr_n(t, 191);
+  return fe_eq(t, FE_ONE_M);
+}
+
+// =============================================================================================
+// Arithmetic modulo the curve order N (generic Montgomery, same limb shape, R = 2^261).
+// Used only for the handful of scalar operations per signature (w = 1/s, u1 = z w, u2 = r w, ...).
+// =============================================================================================
+constexpr int32_t N_LIMB[NL] = {0xdc64d2f, 0x1335120d, 0x19ec8c87, 0x224db95, 0x1ffffb78,
+                                0x1fffffff, 0x43ffff, 0x0, 0x80000};
+constexpr uint32_t N0INV = 0x8bde631;  // -N^-1 mod 2^29
+constexpr fe FN_ONE_M = {{0x1491912f, 0x1eecdc54, 0x7ba6e20, 0xeb68458, 0x121b33, 0x0, 0x10440000,
+                          0x1ffffff7, 0x7ffff}};
+constexpr fe FN_R2 = {{0xbeb7fac, 0x25b7097, 0x15023c53, 0x9db76e9, 0xee5ec5a, 0x19ef1775,
+                       0xff0ab4, 0x1199bb2f, 0x795f0}};
+constexpr fe FN_N = {{0xdc64d2f, 0x1335120d, 0x19ec8c87, 0x224db95, 0x1ffffb78, 0x1fffffff,
+                      0x43ffff, 0x0, 0x80000}};
+
+SP_HD fe fn_reduce(cols& t) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const uint32_t q = ((uint32_t)t.c[i] * N0INV) & LMASK;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) t.c[i + j] += (int64_t)q * (int64_t)N_LIMB[j];
+    t.c[i + 1] += t.c[i] >> LB;
+  }
+  fe r;
+  int64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t v = t.c[9 + k] + carry;
+    r.l[k] = (int32_t)((uint32_t)v & LMASK);
+    carry = v >> LB;
+  }
+  r.l[8] = (int32_t)carry;
+  return r;
+}
+SP_HD fe fn_mul(const fe& a, const fe& b) {
+  cols t;
+  cols_zero(t);
+  cols_mac(t, a, b);
+  return fn_reduce(t);
+}
+SP_HD fe fn_sqr(const fe& a) {
+  cols t;
+  cols_zero(t);
+  cols_sqr(t, a);
+  return fn_reduce(t);
+}
+// lexicographic a >= m on canonical non-negative limbs
+SP_HD bool limbs_geq(const fe& a, const fe& m) {
+#pragma unroll
+  for (int i = NL - 1; i >= 0; --i) {
+    if (a.l[i] != m.l[i]) return a.l[i] > m.l[i];
+  }
+  return true;
+}
+SP_HD fe fn_canon(const fe& a_in) {
+  fe a = fe_carry(a_in);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (a.l[8] < 0) a = fe_carry(fe_add(a, FN_N));
+  }
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    if (limbs_geq(a, FN_N)) a = fe_carry(fe_sub(a, FN_N));
+  }
+  return a;
+}
+SP_HD fe fn_to_mont(const fe& a) { return fn_mul(a, FN_R2); }
+SP_HD fe fn_from_mont(const fe& a) {
+  cols t;
+  cols_zero(t);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) t.c[i] = a.l[i];
+  return fn_canon(fn_reduce(t));
+}
+SP_HD bool limbs_is_zero(const fe& a) {
+  int32_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc |= a.l[i];
+  return acc == 0;
+}
+// a^(N-2) by square-and-multiply over the bits of N-2 (canonical limbs of N-2 below).
+SP_HD fe fn_inv(const fe& a) {
+  // N - 2 limbs: N_LIMB with limb0 - 2 (0xdc64d2f - 2 = 0xdc64d2d, no borrow)
+  fe r = FN_ONE_M;
+  for (int i = NL - 1; i >= 0; --i) {
+    const uint32_t e = (uint32_t)N_LIMB[i] - (i == 0 ? 2u : 0u);
+    const int top = (i == NL - 1) ? 19 : LB - 1;  // N < 2^252: limb 8 has 20 bits
+    for (int b = top; b >= 0; --b) {
+      r = fn_sqr(r);
+      if ((e >> b) & 1u) r = fn_mul(r, a);
+    }
+  }
+  return r;
+}
+
+}  // namespace sp

@@ -1,0 +1,139 @@
+"""Host-compiled (g++, bound checks on) unit tests of the device arithmetic headers
+stark-perpetual_amd/csrc/{fp29,curve}.hpp against Python integers / the oracle."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import ref_py as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P, N = R.FIELD_PRIME, R.EC_ORDER
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(HERE, "host", "host_shim.so")
+    src = os.path.join(HERE, "host", "host_shim.cpp")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, src])
+    return ctypes.CDLL(so)
+
+
+def W(v):
+    return (ctypes.c_uint32 * 8)(*[(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+
+
+def WN(vals):
+    arr = (ctypes.c_uint32 * (8 * len(vals)))()
+    for k, v in enumerate(vals):
+        for i in range(8):
+            arr[8 * k + i] = (v >> (32 * i)) & 0xFFFFFFFF
+    return arr
+
+
+def I(buf, off=0):
+    return sum(buf[off + i] << (32 * i) for i in range(8))
+
+
+EDGE = [0, 1, 2, P - 1, P - 2, 2**251, 2**192, 2**29 - 1, 2**232, (P - 1) // 2]
+
+
+def test_constants():
+    Rm = 2**261
+    limbs = lambda v: [(v >> (29 * i)) & (2**29 - 1) for i in range(9)]
+    import re
+    hdr = open(os.path.join(HERE, "..", "stark-perpetual_amd", "csrc", "fp29.hpp")).read()
+
+    def grab(name):
+        m = re.search(name + r" = \{\{([^}]*)\}\}", hdr)
+        return [int(x, 16) for x in m.group(1).replace("\n", " ").split(",")]
+
+    assert grab("FE_ONE_M") == limbs(Rm % P)
+    assert grab("FE_R2") == limbs(Rm * Rm % P)
+    assert grab("FN_ONE_M") == limbs(Rm % N)
+    assert grab("FN_R2") == limbs(Rm * Rm % N)
+    assert grab("FN_N") == limbs(N)
+    assert limbs(P) == [1, 0, 0, 0, 0, 0, 0x440000, 0, 0x80000]
+    assert (-pow(N, -1, 2**29)) % 2**29 == 0x8BDE631
+
+
+def test_pack_roundtrip(shim):
+    rng = random.Random(1)
+    out = (ctypes.c_uint32 * 8)()
+    for v in EDGE + [rng.randrange(2**256) for _ in range(200)]:
+        shim.t_roundtrip(W(v), out)
+        assert I(out) == v
+
+
+def test_fe_mul_sqr_inv(shim):
+    rng = random.Random(2)
+    out = (ctypes.c_uint32 * 8)()
+    vals = EDGE + [rng.randrange(P) for _ in range(300)]
+    for a in vals:
+        b = rng.choice(vals)
+        shim.t_fe_mul(W(a), W(b), out)
+        assert I(out) == a * b % P
+        shim.t_fe_sqr(W(a), out)
+        assert I(out) == a * a % P
+    for a in vals[:40]:
+        if a == 0:
+            continue
+        shim.t_fe_inv(W(a), out)
+        assert I(out) == pow(a, -1, P)
+        assert shim.t_fe_is_qr(W(a)) == (1 if pow(a, (P - 1) // 2, P) == 1 else 0)
+
+
+def test_fe_lazy_expr(shim):
+    rng = random.Random(3)
+    out = (ctypes.c_uint32 * 8)()
+    vals = EDGE + [rng.randrange(P) for _ in range(50)]
+    for _ in range(500):
+        a, b, c, d, e, f = (rng.choice(vals) for _ in range(6))
+        shim.t_fe_expr(W(a), W(b), W(c), W(d), W(e), W(f), out)
+        assert I(out) == ((a - b) * (c + d) - e * f) % P
+
+
+def test_fn(shim):
+    rng = random.Random(4)
+    out = (ctypes.c_uint32 * 8)()
+    vals = [0, 1, 2, N - 1, N - 2, 2**251] + [rng.randrange(N) for _ in range(200)]
+    for a in vals:
+        b = rng.choice(vals)
+        shim.t_fn_mul(W(a), W(b), out)
+        assert I(out) == a * b % N
+    for a in vals[1:30]:
+        shim.t_fn_inv(W(a), out)
+        assert I(out) == pow(a, -1, N)
+
+
+def rand_point(rng):
+    return R.ec_mult(rng.randrange(1, N), tuple(R.EC_GEN))
+
+
+def test_xyzz_chain_and_add(shim):
+    rng = random.Random(5)
+    x = (ctypes.c_uint32 * 8)()
+    y = (ctypes.c_uint32 * 8)()
+    for n in (2, 3, 5, 17):
+        pts = [rand_point(rng) for _ in range(n)]
+        exp = pts[0]
+        for q in pts[1:]:
+            exp = R.ec_add(exp, q)
+        shim.t_xyzz_chain(WN([p[0] for p in pts]), WN([p[1] for p in pts]), n, x, y)
+        assert (I(x), I(y)) == exp
+    pts = [rand_point(rng) for _ in range(4)]
+    exp = R.ec_add(R.ec_add(pts[0], pts[1]), R.ec_add(pts[2], pts[3]))
+    shim.t_xyzz_add(WN([p[0] for p in pts]), WN([p[1] for p in pts]), x, y)
+    assert (I(x), I(y)) == exp
+
+
+def test_jacobian_ladder(shim):
+    rng = random.Random(6)
+    x = (ctypes.c_uint32 * 8)()
+    y = (ctypes.c_uint32 * 8)()
+    for k in [1, 2, 3, 5, N - 1, 2**251 - 1] + [rng.randrange(1, N) for _ in range(6)]:
+        q = rand_point(rng)
+        shim.t_jac_mul(W(q[0]), W(q[1]), W(k), x, y)
+        assert (I(x), I(y)) == R.ec_mult(k, q)
