@@ -1,0 +1,115 @@
+/*
+ * libstarkperp - C ABI of the MI355X hot path for the StarkEx-Perpetual crypto builtins.
+ *
+ * The reference (starkware-libs/stark-perpetual) has no FFI: its hot path is the Python module
+ * src/starkware/crypto/signature/signature.py.  Each entry point below names the reference
+ * function (file:line, relative to /root/reference/src) whose arithmetic it replaces; the Python
+ * host package (stark-perpetual_amd/starkperp) binds them with ctypes and re-exposes the
+ * reference's module API unchanged.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - A field element / scalar ("felt") is 32 bytes: four little-endian uint64 limbs, plain
+ *     (non-Montgomery) integer value.  Arrays are contiguous, n * 32 bytes, caller-owned.
+ *   - Functions ending in _dev take DEVICE pointers (HBM resident, 32-byte aligned) and a
+ *     hipStream_t passed as void* (NULL = the null stream); they enqueue work and return without
+ *     synchronising.  The others take HOST pointers and are synchronous.
+ *   - Return value: 0 on success, negative on library/runtime error (sp_last_error() has the
+ *     text).  Data-dependent outcomes are reported per item in a uint8_t status array.
+ *   - There is no CPU fallback: without a visible gfx950 device sp_init fails and every compute
+ *     entry point returns SP_ERR_NOT_INITIALISED.
+ */
+#ifndef STARKPERP_H
+#define STARKPERP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_ERR_NOT_INITIALISED (-1)
+#define SP_ERR_HIP (-2)
+#define SP_ERR_BAD_ARGUMENT (-3)
+#define SP_ERR_TABLE_BUILD (-4)
+
+/* per-item status of sp_pedersen_* (signature.py:300-318) */
+#define SP_HASH_OK 0
+#define SP_HASH_OUT_OF_RANGE 1 /* an input was not in [0, p): signature.py:307 assertion */
+#define SP_HASH_UNHASHABLE 2   /* exceptional point collision: signature.py:313 ("Unhashable input.") */
+
+/* per-item result of sp_ecdsa_verify_* (signature.py:217-260) */
+#define SP_VERIFY_FALSE 0
+#define SP_VERIFY_TRUE 1
+#define SP_VERIFY_ASSERT_S 2     /* signature.py:219  assert 1 <= s < EC_ORDER */
+#define SP_VERIFY_ASSERT_R 3     /* signature.py:225  assert 1 <= r < 2**251 */
+#define SP_VERIFY_ASSERT_W 4     /* signature.py:226  assert 1 <= w < 2**251 */
+#define SP_VERIFY_ASSERT_MSG 5   /* signature.py:227  assert 0 <= msg_hash < 2**251 */
+#define SP_VERIFY_ASSERT_CURVE 6 /* signature.py:241  assert is_point_on_curve */
+
+/* per-item status of sp_ecdsa_sign_* (signature.py:137-173) */
+#define SP_SIGN_OK 0
+#define SP_SIGN_RETRY 1          /* the k was rejected (signature.py:158-170): draw the next k */
+#define SP_SIGN_BAD_INPUT 2      /* msg_hash >= 2**251 (signature.py:141) or key/k out of range */
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* Selects the HIP device and builds the window tables of the Pedersen constant points
+ * (signature.py:43 CONSTANT_POINTS; table structure nothing_up_my_sleeve_gen.py:88-90) and of
+ * EC_GEN (signature.py:56) in HBM.  window_bits = 0 picks the default (16).  Idempotent. */
+int sp_init(int device, int window_bits);
+void sp_shutdown(void);
+const char* sp_last_error(void);
+int sp_is_initialised(void);
+/* window width in use and bytes of HBM held by the tables */
+int sp_window_bits(void);
+size_t sp_table_bytes(void);
+int sp_synchronize(void* stream);
+
+/* ---- Pedersen hash: pedersen_hash(x, y) signature.py:296-318 -------------------------------- */
+int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n);
+int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status,
+                          size_t n, void* stream);
+/* left fold h = H(h, e_i) starting from h = e_0: the hash-chain shape of
+ * perpetual_messages.py:279-286 and position/hash.cairo:22-43.  n_elems >= 1. */
+int sp_pedersen_chain(const uint64_t* elems, size_t n_elems, uint64_t* out, uint8_t* status);
+/* width independent chains of equal depth, element j of chain i at elems[(j*width + i)*4]:
+ * out[i] = H(...H(H(e0,e1),e2)...,e_{depth-1}) */
+int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, uint64_t* out,
+                           uint8_t* status, void* stream);
+
+/* ---- Merkle trees with node = pedersen_hash(left, right) ------------------------------------- */
+/* (merkle_multi_update call sites services/perpetual/cairo/state/state.cairo:155-173)           */
+/* Full rebuild over 2^height leaves.  levels_out (optional, may be NULL) receives every level
+ * bottom-up, leaves first: (2^(height+1) - 1) felts.  status is a single byte (OR of item status). */
+int sp_merkle_root(const uint64_t* leaves, unsigned height, uint64_t* root, uint64_t* levels_out,
+                   uint8_t* status);
+/* Device version: `levels` is a device buffer of (2^(height+1) - 1) felts whose first 2^height
+ * entries hold the leaves; the upper levels are written behind them, the root last. */
+int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void* stream);
+/* Sparse multi-update: root of the tree of the given height (<= 64) that holds new_leaves[i] at
+ * keys[i] (strictly increasing) and `empty_leaf` everywhere else - the induced-subtree walk of
+ * starkware/python/merkle_tree.py:4-26. */
+int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leaves, size_t n, unsigned height,
+                          const uint64_t* empty_leaf, uint64_t* root, uint8_t* status);
+
+/* ---- Stark-curve ECDSA ------------------------------------------------------------------------ */
+/* verify(msg_hash, r, s, public_key) signature.py:217-260.  qy == NULL: public keys are x-only
+ * (both y candidates are tried, signature.py:229-238). */
+int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* s,
+                          const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n);
+int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64_t* s,
+                              const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n,
+                              void* stream);
+/* One signing attempt per item with caller-supplied nonce k (host RFC 6979, signature.py:117-134):
+ * the body of the loop at signature.py:146-173. */
+int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r,
+                        uint64_t* s, uint8_t* status, size_t n);
+/* private_key_to_ec_point_on_stark_curve signature.py:104-106: (qx, qy) = d * EC_GEN.
+ * status: 0 ok, 2 when d is not in (0, EC_ORDER). */
+int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* status, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARKPERP_H */

@@ -1,0 +1,123 @@
+// Library-wide state of libstarkperp: the selected device, the HBM-resident window tables and
+// growable scratch.  One context per process (one process per GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <string>
+
+#include "../../include/starkperp.h"
+#include "curve.hpp"
+
+namespace sp {
+
+// 64-byte table entry: affine point, Montgomery form, canonical 256-bit packing.
+struct alignas(64) aff_packed {
+  u256 x, y;
+};
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  // Grow-only; contents are not preserved.
+  hipError_t reserve(size_t need) {
+    if (need <= bytes) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    size_t want = need + need / 4;
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e == hipSuccess) bytes = want;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+struct Context {
+  bool ready = false;
+  int device = -1;
+  int wbits = 16;        // window width
+  int nwin = 16;         // windows per 252-bit scalar = ceil(252 / wbits)
+  aff_packed* ped = nullptr;   // [2][nwin][1 << wbits]  Pedersen: element, window, value
+  aff_packed* gen = nullptr;   // [nwin][1 << wbits]     fixed-base EC_GEN
+  size_t table_bytes = 0;
+  DeviceBuffer scratch;        // X / ZZ / prefix products for batched inversion
+  DeviceBuffer io;             // staging for host-pointer entry points
+  DeviceBuffer io2;
+  std::mutex mu;
+};
+
+Context& ctx();
+void set_error(const std::string& s);
+int hip_fail(hipError_t e, const char* what);
+
+#define SP_HIP(call)                                   \
+  do {                                                 \
+    hipError_t e__ = (call);                           \
+    if (e__ != hipSuccess) return hip_fail(e__, #call); \
+  } while (0)
+
+#define SP_REQUIRE_READY()                                                        \
+  do {                                                                            \
+    if (!ctx().ready) {                                                           \
+      set_error("libstarkperp is not initialised (sp_init failed or not called; " \
+                "there is no CPU fallback)");                                     \
+      return SP_ERR_NOT_INITIALISED;                                              \
+    }                                                                             \
+  } while (0)
+
+// ---- device helpers shared by the kernels ----
+__device__ __forceinline__ u256 ld_u256(const uint64_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  u256 r;
+  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+  r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void st_u256(uint64_t* p, const u256& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+  q[1] = make_uint4(v.w[4], v.w[5], v.w[6], v.w[7]);
+}
+__device__ __forceinline__ aff ld_aff(const aff_packed* e) {
+  const uint4* q = reinterpret_cast<const uint4*>(e);
+  uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  u256 x, y;
+  x.w[0] = a.x; x.w[1] = a.y; x.w[2] = a.z; x.w[3] = a.w;
+  x.w[4] = b.x; x.w[5] = b.y; x.w[6] = b.z; x.w[7] = b.w;
+  y.w[0] = c.x; y.w[1] = c.y; y.w[2] = c.z; y.w[3] = c.w;
+  y.w[4] = d.x; y.w[5] = d.y; y.w[6] = d.z; y.w[7] = d.w;
+  aff r;
+  r.x = fe_unpack(x);
+  r.y = fe_unpack(y);
+  return r;
+}
+// plain integer a < 2^256 compared with p / N / 2^251 on packed words
+__host__ __device__ __forceinline__ bool u256_lt(const u256& a, const u256& b) {
+  for (int i = 7; i >= 0; --i) {
+    if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
+  }
+  return false;
+}
+__host__ __device__ __forceinline__ bool u256_is_zero(const u256& a) {
+  uint32_t o = 0;
+  for (int i = 0; i < 8; ++i) o |= a.w[i];
+  return o == 0;
+}
+constexpr u256 U256_P = {{1u, 0u, 0u, 0u, 0u, 0u, 0x11u, 0x08000000u}};
+constexpr u256 U256_N = {{0xadc64d2fu, 0x1e66a241u, 0xcae7b232u, 0xb781126du, 0xffffffffu, 0xffffffffu,
+                          0x10u, 0x08000000u}};
+constexpr u256 U256_2P251 = {{0u, 0u, 0u, 0u, 0u, 0u, 0u, 0x08000000u}};
+
+// w-bit window number `win` of a 256-bit little-endian integer
+__device__ __forceinline__ uint32_t window_of(const u256& a, int win, int wbits) {
+  const int bit = win * wbits, wi = bit >> 5, sh = bit & 31;
+  uint64_t two = (uint64_t)a.w[wi] | ((uint64_t)(wi + 1 < 8 ? a.w[wi + 1] : 0u) << 32);
+  return (uint32_t)(two >> sh) & ((1u << wbits) - 1u);
+}
+
+}  // namespace sp
