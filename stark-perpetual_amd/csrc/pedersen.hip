@@ -1,0 +1,315 @@
+// Batched Pedersen hash and the Merkle / hash-chain drivers built on it.
+//
+// Reference semantics: pedersen_hash(x, y) = x-coordinate of
+//     SHIFT + sum_j x_j C[2+j] + sum_j y_j C[254+j]            (signature.py:300-318)
+// computed there with ~252 affine additions (one modular inversion each).  Here one thread sums
+// the 2*nwin window-table entries selected by the bits of (x, y) in XYZZ coordinates (8M + 2S per
+// entry, no inversion), and a second kernel turns X/ZZ into the canonical affine x with one
+// shared inversion per K hashes (Montgomery's trick, K up to 32).
+//
+// HBM layout
+//   tables  aff_packed[2][nwin][2^w] : 64-byte entries, one random 64-byte gather per window
+//   inputs  x[n], y[n]               : 32-byte felts, element strides given in felts
+//   scratch int32[9][n] x 3          : X, ZZ and prefix products, limb-major so that a wave's
+//                                      64 lanes touch 64 consecutive dwords
+// Algorithmic bytes per hash: 96 (two felts in, one out).  The kernel is VALU bound
+// (~3.3e3 v_mad_i64_i32 per window addition), not HBM bound - see DESIGN.md.
+#include "context.hpp"
+
+namespace sp {
+
+struct raw_aff {
+  uint4 a, b, c, d;
+};
+__device__ __forceinline__ raw_aff ld_raw(const aff_packed* e) {
+  const uint4* q = reinterpret_cast<const uint4*>(e);
+  raw_aff r;
+  r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3];
+  return r;
+}
+__device__ __forceinline__ aff unpack_raw(const raw_aff& t) {
+  u256 x, y;
+  x.w[0] = t.a.x; x.w[1] = t.a.y; x.w[2] = t.a.z; x.w[3] = t.a.w;
+  x.w[4] = t.b.x; x.w[5] = t.b.y; x.w[6] = t.b.z; x.w[7] = t.b.w;
+  y.w[0] = t.c.x; y.w[1] = t.c.y; y.w[2] = t.c.z; y.w[3] = t.c.w;
+  y.w[4] = t.d.x; y.w[5] = t.d.y; y.w[6] = t.d.z; y.w[7] = t.d.w;
+  aff r;
+  r.x = fe_unpack(x);
+  r.y = fe_unpack(y);
+  return r;
+}
+
+// Pops the low `wbits` of s and shifts s right.
+__device__ __forceinline__ uint32_t pop_window(u256& s, int wbits) {
+  const uint32_t v = s.w[0] & ((1u << wbits) - 1u);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s.w[i] = (s.w[i] >> wbits) | (s.w[i + 1] << (32 - wbits));
+  s.w[7] >>= wbits;
+  return v;
+}
+
+__device__ __forceinline__ void store_limbs(int32_t* base, size_t n, size_t e, const fe& v) {
+#pragma unroll
+  for (int k = 0; k < NL; ++k) base[(size_t)k * n + e] = v.l[k];
+}
+__device__ __forceinline__ fe load_limbs(const int32_t* base, size_t n, size_t e) {
+  fe v;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) v.l[k] = base[(size_t)k * n + e];
+  return v;
+}
+
+// Kernel A: one hash per thread -> projective (X, ZZ) in scratch.
+__global__ void __launch_bounds__(256)
+ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
+                      size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits, int nwin,
+                      int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, uint8_t* __restrict__ status,
+                      unsigned* __restrict__ flag) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  u256 sx = ld_u256(x + 4 * e * xstride);
+  u256 sy = ld_u256(y + 4 * e * ystride);
+  uint8_t st = SP_HASH_OK;
+  if (!u256_lt(sx, U256_P) || !u256_lt(sy, U256_P)) {  // signature.py:307
+    st = SP_HASH_OUT_OF_RANGE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sx.w[i] = 0; sy.w[i] = 0; }
+  }
+  const size_t per = (size_t)1 << wbits;
+  // first entry initialises the accumulator, the next one is prefetched while it is unpacked
+  const aff_packed* tab = ped;
+  uint32_t v = pop_window(sx, wbits);
+  xyzz acc = xyzz_from_aff(unpack_raw(ld_raw(tab + v)));
+  tab += per;
+  const int total = 2 * nwin;
+  v = pop_window(nwin > 1 ? sx : sy, wbits);
+  raw_aff nxt = ld_raw(tab + v);
+  for (int i = 1; i < total; ++i) {
+    const aff q = unpack_raw(nxt);
+    if (i + 1 < total) {
+      tab += per;
+      v = (i + 1 < nwin) ? pop_window(sx, wbits) : pop_window(sy, wbits);
+      nxt = ld_raw(tab + v);
+    }
+    acc = xyzz_madd(acc, q);
+  }
+  store_limbs(sX, n, e, acc.X);
+  store_limbs(sZZ, n, e, acc.ZZ);
+  if (st != SP_HASH_OK) {
+    if (status) status[e] = st;
+    if (flag) atomicOr(flag, (unsigned)st);
+  } else if (status) {
+    status[e] = SP_HASH_OK;
+  }
+}
+
+// Kernel B: thread t owns elements t, t+T, t+2T, ...; one inversion per thread.
+__global__ void __launch_bounds__(256)
+ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int32_t* __restrict__ sPre,
+                  size_t n, size_t T, uint64_t* __restrict__ out, size_t ostride,
+                  uint8_t* __restrict__ status, unsigned* __restrict__ flag) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  fe run = FE_ONE_M;
+  for (size_t e = t; e < n; e += T) {
+    fe z = load_limbs(sZZ, n, e);
+    if (fe_is_zero(z)) {  // exceptional addition happened (signature.py:313 territory)
+      z = FE_ONE_M;
+      store_limbs(sZZ, n, e, z);
+      if (status) status[e] = SP_HASH_UNHASHABLE;
+      if (flag) atomicOr(flag, (unsigned)SP_HASH_UNHASHABLE);
+    }
+    store_limbs(sPre, n, e, run);
+    run = fe_mul(run, z);
+  }
+  fe inv = fe_inv(run);
+  const size_t cnt = (n - t + T - 1) / T;  // number of elements owned
+  for (size_t j = cnt; j-- > 0;) {
+    const size_t e = t + j * T;
+    const fe z = load_limbs(sZZ, n, e);
+    const fe pre = load_limbs(sPre, n, e);
+    const fe zinv = fe_mul(inv, pre);
+    inv = fe_mul(inv, z);
+    const fe xa = fe_mul(load_limbs(sX, n, e), zinv);  // Montgomery form of X/ZZ
+    st_u256(out + 4 * e * ostride, fe_pack(fe_from_mont(xa)));
+  }
+}
+
+// ---- host-side drivers -------------------------------------------------------------------------
+struct Scratch {
+  int32_t *X, *ZZ, *Pre;
+  unsigned* flag;
+};
+static int get_scratch(size_t n, Scratch& s) {
+  Context& c = ctx();
+  const size_t plane = ((9 * n * sizeof(int32_t)) + 255) & ~(size_t)255;
+  SP_HIP(c.scratch.reserve(3 * plane + 256));
+  char* b = (char*)c.scratch.ptr;
+  s.X = (int32_t*)b;
+  s.ZZ = (int32_t*)(b + plane);
+  s.Pre = (int32_t*)(b + 2 * plane);
+  s.flag = (unsigned*)(b + 3 * plane);
+  return SP_OK;
+}
+
+static size_t finish_threads(size_t n) {
+  // K hashes share one inversion (~250 M): K = 32 costs ~8 M per hash of overhead.
+  size_t K = n / 65536;
+  if (K < 1) K = 1;
+  if (K > 32) K = 32;
+  return (n + K - 1) / K;
+}
+
+// Enqueue n hashes; x/y/out strides in felts.  `flag` (device, may be null) ORs item status.
+int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
+                     size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
+                     const Scratch& s) {
+  if (n == 0) return SP_OK;
+  Context& c = ctx();
+  const unsigned blocksA = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped,
+                     c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+  const size_t T = finish_threads(n);
+  const unsigned tpb = T >= 256 ? 256 : 64;
+  const unsigned blocksB = (unsigned)((T + tpb - 1) / tpb);
+  hipLaunchKernelGGL(ped_finish_kernel, dim3(blocksB), dim3(tpb), 0, st, s.X, s.ZZ, s.Pre, n, T, out,
+                     os, status, flag);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+}  // namespace sp
+
+using namespace sp;
+
+extern "C" {
+
+int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status,
+                          size_t n, void* stream) {
+  SP_REQUIRE_READY();
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  Scratch s;
+  int rc = get_scratch(n, s);
+  if (rc != SP_OK) return rc;
+  return enqueue_pedersen(x, 1, y, 1, out, 1, status, nullptr, n, (hipStream_t)stream, s);
+}
+
+int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n) {
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  const size_t fb = n * 32;
+  SP_HIP(c.io.reserve(3 * fb + n + 64));
+  uint64_t* dx = (uint64_t*)c.io.ptr;
+  uint64_t* dy = (uint64_t*)((char*)c.io.ptr + fb);
+  uint64_t* dout = (uint64_t*)((char*)c.io.ptr + 2 * fb);
+  uint8_t* dst = (uint8_t*)c.io.ptr + 3 * fb;
+  SP_HIP(hipMemcpy(dx, x, fb, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(dy, y, fb, hipMemcpyHostToDevice));
+  Scratch s;
+  int rc = get_scratch(n, s);
+  if (rc != SP_OK) return rc;
+  rc = enqueue_pedersen(dx, 1, dy, 1, dout, 1, dst, nullptr, n, 0, s);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipDeviceSynchronize());
+  SP_HIP(hipMemcpy(out, dout, fb, hipMemcpyDeviceToHost));
+  if (status) SP_HIP(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
+  return SP_OK;
+}
+
+int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, uint64_t* out,
+                           uint8_t* status, void* stream) {
+  SP_REQUIRE_READY();
+  if (depth < 1) { set_error("chain depth must be >= 1"); return SP_ERR_BAD_ARGUMENT; }
+  if (width == 0) return SP_OK;
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  hipStream_t st = (hipStream_t)stream;
+  Scratch s;
+  int rc = get_scratch(width, s);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
+  if (depth == 1) {
+    SP_HIP(hipMemcpyAsync(out, elems, width * 32, hipMemcpyDeviceToDevice, st));
+  }
+  // h lives in `out` and is updated in place: thread e reads x[e] and writes out[e] only after
+  // kernel A of the same launch pair consumed it (A and B are separate kernels on one stream).
+  const uint64_t* h = elems;
+  for (size_t j = 1; j < depth; ++j) {
+    rc = enqueue_pedersen(h, 1, elems + 4 * j * width, 1, out, 1, nullptr, s.flag, width, st, s);
+    if (rc != SP_OK) return rc;
+    h = out;
+  }
+  if (status) SP_HIP(hipMemcpyAsync(status, s.flag, 1, hipMemcpyDeviceToHost, st));
+  return SP_OK;
+}
+
+int sp_pedersen_chain(const uint64_t* elems, size_t n_elems, uint64_t* out, uint8_t* status) {
+  SP_REQUIRE_READY();
+  if (n_elems < 1) { set_error("chain needs at least one element"); return SP_ERR_BAD_ARGUMENT; }
+  Context& c = ctx();
+  uint64_t *d_el, *d_out;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    SP_HIP(c.io.reserve(n_elems * 32 + 64));
+    d_el = (uint64_t*)c.io.ptr;
+    d_out = (uint64_t*)((char*)c.io.ptr + n_elems * 32);
+    SP_HIP(hipMemcpy(d_el, elems, n_elems * 32, hipMemcpyHostToDevice));
+  }
+  uint8_t st8 = 0;
+  int rc = sp_pedersen_chains_dev(d_el, 1, n_elems, d_out, &st8, 0);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipDeviceSynchronize());
+  SP_HIP(hipMemcpy(out, d_out, 32, hipMemcpyDeviceToHost));
+  if (status) *status = st8;
+  return SP_OK;
+}
+
+int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void* stream) {
+  SP_REQUIRE_READY();
+  if (height > 40) { set_error("height too large for a full rebuild"); return SP_ERR_BAD_ARGUMENT; }
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n0 = (size_t)1 << height;
+  Scratch s;
+  int rc = get_scratch(n0 / 2 + 1, s);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
+  uint64_t* cur = levels;
+  for (size_t n = n0; n > 1; n >>= 1) {
+    uint64_t* nxt = cur + 4 * n;
+    rc = enqueue_pedersen(cur, 2, cur + 4, 2, nxt, 1, nullptr, s.flag, n / 2, st, s);
+    if (rc != SP_OK) return rc;
+    cur = nxt;
+  }
+  if (status) SP_HIP(hipMemcpyAsync(status, s.flag, 1, hipMemcpyDeviceToHost, st));
+  return SP_OK;
+}
+
+int sp_merkle_root(const uint64_t* leaves, unsigned height, uint64_t* root, uint64_t* levels_out,
+                   uint8_t* status) {
+  SP_REQUIRE_READY();
+  if (height > 30) { set_error("height too large"); return SP_ERR_BAD_ARGUMENT; }
+  Context& c = ctx();
+  const size_t n0 = (size_t)1 << height;
+  const size_t total = 2 * n0 - 1;
+  uint64_t* d;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    SP_HIP(c.io.reserve(total * 32));
+    d = (uint64_t*)c.io.ptr;
+    SP_HIP(hipMemcpy(d, leaves, n0 * 32, hipMemcpyHostToDevice));
+  }
+  uint8_t st8 = 0;
+  int rc = sp_merkle_build_dev(d, height, &st8, 0);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipDeviceSynchronize());
+  SP_HIP(hipMemcpy(root, d + 4 * (total - 1), 32, hipMemcpyDeviceToHost));
+  if (levels_out) SP_HIP(hipMemcpy(levels_out, d, total * 32, hipMemcpyDeviceToHost));
+  if (status) *status = st8;
+  return SP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+"""ctypes binding of libstarkperp.so (include/starkperp.h).  No fallbacks: if the library is
+missing, or no MI355X is visible, every compute entry point raises."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libstarkperp.so")
+
+U64P = ctypes.POINTER(ctypes.c_uint64)
+U8P = ctypes.POINTER(ctypes.c_uint8)
+
+
+class StarkPerpError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+_SIGNATURES = {
+    "sp_init": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "sp_shutdown": (None, []),
+    "sp_last_error": (ctypes.c_char_p, []),
+    "sp_is_initialised": (ctypes.c_int, []),
+    "sp_window_bits": (ctypes.c_int, []),
+    "sp_table_bytes": (ctypes.c_size_t, []),
+    "sp_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "sp_pedersen_batch": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t]),
+    "sp_pedersen_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "sp_pedersen_chain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_pedersen_chains_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_merkle_root": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p]),
+    "sp_merkle_build_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_merkle_sparse_root": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                             ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p]),
+    "sp_ecdsa_verify_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
+    "sp_ecdsa_verify_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "sp_ecdsa_sign_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
+    "sp_public_key_batch": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """dlopen the library and attach prototypes (does not touch the GPU)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise StarkPerpError(
+                    "libstarkperp.so not built (%s); run `python __graft_entry__.py` or "
+                    "`make -C stark-perpetual_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(lib, name, None)
+                if fn is None:
+                    continue  # symbol tests report what is missing
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+        return _lib
+
+
+def last_error():
+    return load().sp_last_error().decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise StarkPerpError("%s failed (rc=%d): %s" % (what, rc, last_error()))
+
+
+def ensure_init(device=None, window_bits=None):
+    lib = load()
+    if not lib.sp_is_initialised():
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", os.environ.get("STARKPERP_DEVICE", "0")))
+        if window_bits is None:
+            window_bits = int(os.environ.get("STARKPERP_WINDOW_BITS", "0"))
+        check(lib.sp_init(device, window_bits), "sp_init")
+    return lib
+
+
+# ---- felt marshalling -------------------------------------------------------------------------
+MASK64 = (1 << 64) - 1
+
+
+def pack_felts(values):
+    """ints (0 <= v < 2^256) -> ctypes uint64 array of 4 LE limbs each."""
+    n = len(values)
+    buf = (ctypes.c_uint64 * (4 * n))()
+    raw = b"".join(int(v).to_bytes(32, "little") for v in values)
+    ctypes.memmove(buf, raw, 32 * n)
+    return buf
+
+
+def unpack_felts(buf, n):
+    raw = ctypes.string_at(buf, 32 * n)
+    return [int.from_bytes(raw[32 * i : 32 * i + 32], "little") for i in range(n)]
+
+
+def new_felts(n):
+    return (ctypes.c_uint64 * (4 * n))()
+
+
+def new_bytes(n):
+    return (ctypes.c_uint8 * max(n, 1))()
