@@ -70,6 +70,9 @@ int sp_synchronize(void* stream);
 int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n);
 int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status,
                           size_t n, void* stream);
+/* pedersen_hash_as_point(x, y) signature.py:300-318: the full affine point (testing helper). */
+int sp_pedersen_point_batch(const uint64_t* x, const uint64_t* y, uint64_t* out_x, uint64_t* out_y,
+                            uint8_t* status, size_t n);
 /* left fold h = H(h, e_i) starting from h = e_0: the hash-chain shape of
  * perpetual_messages.py:279-286 and position/hash.cairo:22-43.  n_elems >= 1. */
 int sp_pedersen_chain(const uint64_t* elems, size_t n_elems, uint64_t* out, uint8_t* status);

@@ -135,6 +135,36 @@ ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int
   }
 }
 
+// Full affine point (x, y) per item - pedersen_hash_as_point (signature.py:300-318), a testing
+// helper in the reference; one thread does its own inversion.
+__global__ void __launch_bounds__(128)
+ped_point_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t n,
+                 const aff_packed* __restrict__ ped, int wbits, int nwin, uint64_t* __restrict__ ox,
+                 uint64_t* __restrict__ oy, uint8_t* __restrict__ status) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  u256 sx = ld_u256(x + 4 * e);
+  u256 sy = ld_u256(y + 4 * e);
+  if (!u256_lt(sx, U256_P) || !u256_lt(sy, U256_P)) {
+    status[e] = SP_HASH_OUT_OF_RANGE;
+    return;
+  }
+  const size_t per = (size_t)1 << wbits;
+  xyzz acc = xyzz_from_aff(ld_aff(ped + pop_window(sx, wbits)));
+  for (int i = 1; i < 2 * nwin; ++i) {
+    const uint32_t v = (i < nwin) ? pop_window(sx, wbits) : pop_window(sy, wbits);
+    acc = xyzz_madd(acc, ld_aff(ped + (size_t)i * per + v));
+  }
+  if (fe_is_zero(acc.ZZ)) {
+    status[e] = SP_HASH_UNHASHABLE;
+    return;
+  }
+  const fe izzz = fe_inv(acc.ZZZ);
+  st_u256(ox + 4 * e, fe_pack(fe_from_mont(fe_mul(acc.X, fe_sqr(fe_mul(acc.ZZ, izzz))))));
+  st_u256(oy + 4 * e, fe_pack(fe_from_mont(fe_mul(acc.Y, izzz))));
+  status[e] = SP_HASH_OK;
+}
+
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
   int32_t *X, *ZZ, *Pre;
@@ -215,6 +245,31 @@ int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8
   SP_HIP(hipDeviceSynchronize());
   SP_HIP(hipMemcpy(out, dout, fb, hipMemcpyDeviceToHost));
   if (status) SP_HIP(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
+  return SP_OK;
+}
+
+int sp_pedersen_point_batch(const uint64_t* x, const uint64_t* y, uint64_t* ox, uint64_t* oy,
+                            uint8_t* status, size_t n) {
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  const size_t fb = n * 32;
+  SP_HIP(c.io.reserve(4 * fb + n + 64));
+  char* b = (char*)c.io.ptr;
+  uint64_t *dx = (uint64_t*)b, *dy = (uint64_t*)(b + fb), *dox = (uint64_t*)(b + 2 * fb),
+           *doy = (uint64_t*)(b + 3 * fb);
+  uint8_t* dst = (uint8_t*)(b + 4 * fb);
+  SP_HIP(hipMemcpy(dx, x, fb, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(dy, y, fb, hipMemcpyHostToDevice));
+  SP_HIP(hipMemset(dox, 0, 2 * fb));
+  hipLaunchKernelGGL(ped_point_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, dx, dy, n,
+                     c.ped, c.wbits, c.nwin, dox, doy, dst);
+  SP_HIP(hipGetLastError());
+  SP_HIP(hipDeviceSynchronize());
+  SP_HIP(hipMemcpy(ox, dox, fb, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpy(oy, doy, fb, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
   return SP_OK;
 }
 

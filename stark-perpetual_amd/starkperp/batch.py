@@ -53,6 +53,38 @@ def pedersen_chain(elements):
     return unpack_felts(out, 1)[0]
 
 
+def pedersen_chains_many(chains):
+    """Equal-depth chains: [H(...H(H(c[0], c[1]), c[2])..., c[-1]) for c in chains], evaluated
+    level by level across the whole batch (depth - 1 batched launches)."""
+    width = len(chains)
+    if width == 0:
+        return []
+    depth = len(chains[0])
+    assert depth >= 2 and all(len(c) == depth for c in chains)
+    acc = pedersen_hash_many([c[0] for c in chains], [c[1] for c in chains])
+    for j in range(2, depth):
+        acc = pedersen_hash_many(acc, [c[j] for c in chains])
+    return acc
+
+
+def pedersen_points_many(xs, ys):
+    """[pedersen_hash_as_point(x, y) ...] (signature.py:300-318) - the full affine point."""
+    n = len(xs)
+    assert len(ys) == n
+    if n == 0:
+        return []
+    for v in list(xs) + list(ys):
+        assert 0 <= v < FIELD_PRIME
+    lib = _lib.ensure_init()
+    ox, oy, st = new_felts(n), new_felts(n), new_bytes(n)
+    _lib.check(lib.sp_pedersen_point_batch(pack_felts(xs), pack_felts(ys), ox, oy, st, n),
+               "sp_pedersen_point_batch")
+    for code in bytes(st)[:n]:
+        if code:
+            _raise_hash_status(code)
+    return list(zip(unpack_felts(ox, n), unpack_felts(oy, n)))
+
+
 def merkle_levels(leaves):
     """All levels (bottom-up) of the Pedersen Merkle tree over 2^h leaves."""
     n = len(leaves)
@@ -87,3 +119,114 @@ def merkle_root(leaves):
     if st[0]:
         _raise_hash_status(2 if st[0] & 2 else 1)
     return unpack_felts(root, 1)[0]
+
+
+# ---- ECDSA ------------------------------------------------------------------------------------
+VERIFY_FALSE, VERIFY_TRUE = 0, 1
+VERIFY_ASSERT_S, VERIFY_ASSERT_R, VERIFY_ASSERT_W, VERIFY_ASSERT_MSG, VERIFY_ASSERT_CURVE = 2, 3, 4, 5, 6
+SIGN_OK, SIGN_RETRY, SIGN_BAD_INPUT = 0, 1, 2
+_TWO251 = 2**251
+
+
+def verify_codes(msg_hashes, rs, ss, public_keys):
+    """Raw per-item result codes of sp_ecdsa_verify_batch (include/starkperp.h SP_VERIFY_*).
+    public_keys: all ints (x-only, signature.py:229-238) or all (x, y) pairs."""
+    n = len(msg_hashes)
+    assert len(rs) == len(ss) == len(public_keys) == n
+    if n == 0:
+        return []
+    xonly = isinstance(public_keys[0], int)
+    if xonly:
+        qx, qy = [int(q) % FIELD_PRIME for q in public_keys], None
+    else:
+        qx = [int(q[0]) % FIELD_PRIME for q in public_keys]
+        qy = pack_felts([int(q[1]) % FIELD_PRIME for q in public_keys])
+    # Values that do not fit the 256-bit ABI fail the same pre-asserts as in signature.py:219-227;
+    # they are clamped to an out-of-range representative so the kernel reports the right code.
+    clamp = lambda v, bad: v if 0 <= v < 2**256 else bad
+    z = [clamp(int(v), 2**256 - 1) for v in msg_hashes]
+    r = [clamp(int(v), 0) for v in rs]
+    s = [clamp(int(v), 0) for v in ss]
+    lib = _lib.ensure_init()
+    res = new_bytes(n)
+    _lib.check(lib.sp_ecdsa_verify_batch(pack_felts(z), pack_felts(r), pack_felts(s), pack_felts(qx),
+                                         qy, res, n), "sp_ecdsa_verify_batch")
+    return list(bytes(res)[:n])
+
+
+def raise_for_verify_code(code, msg_hash, r, s):
+    """Re-creates the reference's assertion (text included) for a pre-assert code."""
+    if code == VERIFY_ASSERT_S:
+        raise AssertionError("s = %s" % s)
+    if code == VERIFY_ASSERT_R:
+        raise AssertionError("r = %s" % r)
+    if code == VERIFY_ASSERT_W:
+        raise AssertionError("w = %s" % pow(s, -1, EC_ORDER))
+    if code == VERIFY_ASSERT_MSG:
+        raise AssertionError("msg_hash = %s" % msg_hash)
+    if code == VERIFY_ASSERT_CURVE:
+        raise AssertionError()
+
+
+def verify_many(msg_hashes, rs, ss, public_keys):
+    """[verify(z, r, s, q) ...] (signature.py:217-260); raises AssertionError for the first item
+    whose inputs violate a pre-assert, like the scalar function would."""
+    codes = verify_codes(msg_hashes, rs, ss, public_keys)
+    for i, code in enumerate(codes):
+        if code > VERIFY_TRUE:
+            raise_for_verify_code(code, msg_hashes[i], rs[i], ss[i])
+    return [c == VERIFY_TRUE for c in codes]
+
+
+def public_keys_many(priv_keys):
+    """[private_key_to_ec_point_on_stark_curve(d) ...] (signature.py:104-106)."""
+    n = len(priv_keys)
+    if n == 0:
+        return []
+    for d in priv_keys:
+        assert 0 < d < EC_ORDER
+    lib = _lib.ensure_init()
+    qx, qy, st = new_felts(n), new_felts(n), new_bytes(n)
+    _lib.check(lib.sp_public_key_batch(pack_felts(priv_keys), qx, qy, st, n), "sp_public_key_batch")
+    assert not any(bytes(st)[:n])
+    return list(zip(unpack_felts(qx, n), unpack_felts(qy, n)))
+
+
+def sign_attempt_many(msg_hashes, priv_keys, ks):
+    """One pass of the loop body of sign() (signature.py:146-173) per item with explicit nonces.
+    Returns (rs, ss, status)."""
+    n = len(msg_hashes)
+    lib = _lib.ensure_init()
+    r, s, st = new_felts(n), new_felts(n), new_bytes(n)
+    _lib.check(lib.sp_ecdsa_sign_batch(pack_felts(msg_hashes), pack_felts(priv_keys), pack_felts(ks),
+                                       r, s, st, n), "sp_ecdsa_sign_batch")
+    return unpack_felts(r, n), unpack_felts(s, n), list(bytes(st)[:n])
+
+
+def sign_many(msg_hashes, priv_keys, seeds=None):
+    """[sign(z, d, seed) ...] (signature.py:137-173): RFC 6979 nonces on the host, k*G and the
+    mod-N finish on the GPU, rejected nonces retried with the next seed like the reference."""
+    from .signature import generate_k_rfc6979  # late import (signature imports batch)
+
+    n = len(msg_hashes)
+    assert len(priv_keys) == n
+    seeds = [None] * n if seeds is None else list(seeds)
+    for z in msg_hashes:
+        assert 0 <= z < _TWO251, "Message not signable."
+    out = [None] * n
+    todo = list(range(n))
+    while todo:
+        ks = [generate_k_rfc6979(msg_hashes[i], priv_keys[i], seeds[i]) for i in todo]
+        for i in todo:
+            seeds[i] = 1 if seeds[i] is None else seeds[i] + 1
+        rs, ss, st = sign_attempt_many([msg_hashes[i] for i in todo], [priv_keys[i] for i in todo], ks)
+        again = []
+        for j, i in enumerate(todo):
+            if st[j] == SIGN_OK:
+                out[i] = (rs[j], ss[j])
+            elif st[j] == SIGN_RETRY:
+                again.append(i)
+            else:
+                raise AssertionError("sign: input out of range")
+        todo = again
+    return out

@@ -1,0 +1,181 @@
+"""Signed-message builders with the names, argument order and bounds of the reference's
+services/perpetual/public/perpetual_messages.py (Cairo twins:
+services/exchange/cairo/signature_message_hashes.cairo:56-170).  The scalar functions take the same
+`hash_function=` injection seam; `*_many` variants hash whole order batches on the GPU as
+depth-d, width-n chains (sp_pedersen_chains_dev shape)."""
+from typing import Callable, Sequence
+
+from . import batch
+from .signature import pedersen_hash
+
+LIMIT_ORDER_WITH_FEES = 3
+TRANSFER = 4
+CONDITIONAL_TRANSFER = 5
+WITHDRAWAL_TO_ADDRESS = 7
+
+
+def _limit_order_words(asset_id_synthetic, asset_id_collateral, is_buying_synthetic, asset_id_fee,
+                       amount_synthetic, amount_collateral, max_amount_fee, nonce, position_id,
+                       expiration_timestamp):
+    if is_buying_synthetic:
+        sell, buy, n_sell, n_buy = asset_id_collateral, asset_id_synthetic, amount_collateral, amount_synthetic
+    else:
+        sell, buy, n_sell, n_buy = asset_id_synthetic, asset_id_collateral, amount_synthetic, amount_collateral
+    word0 = ((n_sell * 2**64 + n_buy) * 2**64 + max_amount_fee) * 2**32 + nonce
+    word1 = LIMIT_ORDER_WITH_FEES
+    for _ in range(3):
+        word1 = word1 * 2**64 + position_id
+    word1 = (word1 * 2**32 + expiration_timestamp) * 2**17
+    return [sell, buy, asset_id_fee, word0, word1]
+
+
+def _transfer_words(kind, sender_position_id, receiver_position_id, src_fee_position_id, nonce,
+                    amount, max_amount_fee, expiration_timestamp):
+    word0 = ((sender_position_id * 2**64 + receiver_position_id) * 2**64 + src_fee_position_id) * 2**32 + nonce
+    word1 = (((kind * 2**64 + amount) * 2**64 + max_amount_fee) * 2**32 + expiration_timestamp) * 2**81
+    return word0, word1
+
+
+def _fold(hash_function, words):
+    acc = hash_function(words[0], words[1])
+    for w in words[2:]:
+        acc = hash_function(acc, w)
+    return acc
+
+
+def get_limit_order_msg_without_bounds(asset_id_synthetic, asset_id_collateral, is_buying_synthetic,
+                                       asset_id_fee, amount_synthetic, amount_collateral,
+                                       max_amount_fee, nonce, position_id, expiration_timestamp,
+                                       hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """perpetual_messages.py:253-286."""
+    return _fold(hash_function, _limit_order_words(
+        asset_id_synthetic, asset_id_collateral, is_buying_synthetic, asset_id_fee, amount_synthetic,
+        amount_collateral, max_amount_fee, nonce, position_id, expiration_timestamp))
+
+
+def get_limit_order_msg(asset_id_synthetic, asset_id_collateral, is_buying_synthetic, asset_id_fee,
+                        amount_synthetic, amount_collateral, max_amount_fee, nonce, position_id,
+                        expiration_timestamp, hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """perpetual_messages.py:212-250."""
+    assert 0 <= asset_id_synthetic < 2**128
+    assert 0 <= asset_id_collateral < 2**250
+    assert 0 <= asset_id_fee < 2**250
+    assert 0 <= amount_synthetic < 2**64
+    assert 0 <= amount_collateral < 2**64
+    assert 0 <= max_amount_fee < 2**64
+    assert 0 <= nonce < 2**32
+    assert 0 <= position_id < 2**64
+    assert 0 <= expiration_timestamp < 2**32
+    return get_limit_order_msg_without_bounds(
+        asset_id_synthetic, asset_id_collateral, is_buying_synthetic, asset_id_fee, amount_synthetic,
+        amount_collateral, max_amount_fee, nonce, position_id, expiration_timestamp,
+        hash_function=hash_function)
+
+
+def get_transfer_msg_without_bounds(asset_id, asset_id_fee, receiver_public_key, sender_position_id,
+                                    receiver_position_id, src_fee_position_id, nonce, amount,
+                                    max_amount_fee, expiration_timestamp,
+                                    hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """perpetual_messages.py:136-162."""
+    w0, w1 = _transfer_words(TRANSFER, sender_position_id, receiver_position_id, src_fee_position_id,
+                             nonce, amount, max_amount_fee, expiration_timestamp)
+    return _fold(hash_function, [asset_id, asset_id_fee, receiver_public_key, w0, w1])
+
+
+def get_transfer_msg(asset_id, asset_id_fee, receiver_public_key, sender_position_id,
+                     receiver_position_id, src_fee_position_id, nonce, amount, max_amount_fee,
+                     expiration_timestamp, hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """perpetual_messages.py:97-133."""
+    assert 0 <= amount < 2**64
+    assert 0 <= asset_id < 2**250
+    assert 0 <= asset_id_fee < 2**250
+    assert 0 <= expiration_timestamp < 2**32
+    assert 0 <= max_amount_fee < 2**64
+    assert 0 <= nonce < 2**32
+    assert 0 <= receiver_position_id < 2**64
+    assert 0 <= receiver_public_key < 2**251
+    assert 0 <= sender_position_id < 2**64
+    assert 0 <= src_fee_position_id < 2**64
+    return get_transfer_msg_without_bounds(
+        asset_id, asset_id_fee, receiver_public_key, sender_position_id, receiver_position_id,
+        src_fee_position_id, nonce, amount, max_amount_fee, expiration_timestamp,
+        hash_function=hash_function)
+
+
+def get_conditional_transfer_msg_without_bounds(asset_id, asset_id_fee, receiver_public_key, condition,
+                                                sender_position_id, receiver_position_id,
+                                                src_fee_position_id, nonce, amount, max_amount_fee,
+                                                expiration_timestamp,
+                                                hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """perpetual_messages.py:66-94."""
+    w0, w1 = _transfer_words(CONDITIONAL_TRANSFER, sender_position_id, receiver_position_id,
+                             src_fee_position_id, nonce, amount, max_amount_fee, expiration_timestamp)
+    return _fold(hash_function, [asset_id, asset_id_fee, receiver_public_key, condition, w0, w1])
+
+
+def get_conditional_transfer_msg(asset_id, asset_id_fee, receiver_public_key, condition,
+                                 sender_position_id, receiver_position_id, src_fee_position_id, nonce,
+                                 amount, max_amount_fee, expiration_timestamp,
+                                 hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """perpetual_messages.py:24-63."""
+    assert 0 <= amount < 2**64
+    assert 0 <= asset_id < 2**250
+    assert 0 <= asset_id_fee < 2**250
+    assert 0 <= condition < 2**251
+    assert 0 <= expiration_timestamp < 2**32
+    assert 0 <= src_fee_position_id < 2**64
+    assert 0 <= max_amount_fee < 2**64
+    assert 0 <= nonce < 2**32
+    assert 0 <= receiver_position_id < 2**64
+    assert 0 <= receiver_public_key < 2**251
+    assert 0 <= sender_position_id < 2**64
+    return get_conditional_transfer_msg_without_bounds(
+        asset_id, asset_id_fee, receiver_public_key, condition, sender_position_id,
+        receiver_position_id, src_fee_position_id, nonce, amount, max_amount_fee,
+        expiration_timestamp, hash_function=hash_function)
+
+
+def get_withdrawal_to_address_msg_without_bounds(asset_id_collateral, position_id, eth_address, nonce,
+                                                 expiration_timestamp, amount,
+                                                 hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """perpetual_messages.py:192-209."""
+    word = WITHDRAWAL_TO_ADDRESS
+    word = word * 2**64 + position_id
+    word = word * 2**32 + nonce
+    word = word * 2**64 + amount
+    word = word * 2**32 + expiration_timestamp
+    word = word * 2**49
+    return _fold(hash_function, [asset_id_collateral, int(eth_address, 16), word])
+
+
+def get_withdrawal_to_address_msg(asset_id_collateral, position_id, eth_address, nonce,
+                                  expiration_timestamp, amount,
+                                  hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """perpetual_messages.py:165-189."""
+    assert 0 <= asset_id_collateral < 2**250
+    assert 0 <= nonce < 2**32
+    assert 0 <= position_id < 2**64
+    assert 0 <= expiration_timestamp < 2**32
+    assert 0 <= amount < 2**64
+    assert 0 <= int(eth_address, 16) < 2**160
+    return get_withdrawal_to_address_msg_without_bounds(
+        asset_id_collateral, position_id, eth_address, nonce, expiration_timestamp, amount,
+        hash_function=hash_function)
+
+
+def get_price_msg(oracle_name: int, asset_pair: int, timestamp: int, price: int,
+                  hash_function=pedersen_hash):
+    """perpetual_messages.py:311-326."""
+    assert 0 <= oracle_name < 2**40
+    assert 0 <= asset_pair < 2**128
+    assert 0 <= timestamp < 2**32
+    assert 0 <= price < 2**120
+    return hash_function((asset_pair << 40) + oracle_name, (price << 32) + timestamp)
+
+
+# ---- batch additions --------------------------------------------------------------------------
+def limit_order_msgs_many(orders: Sequence[Sequence[int]]):
+    """Message hashes of many limit orders (each a 10-tuple in get_limit_order_msg argument
+    order): four GPU launches of width len(orders) instead of 4 * len(orders) scalar hashes."""
+    words = [_limit_order_words(*o) for o in orders]
+    return batch.pedersen_chains_many(words)
