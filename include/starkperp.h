@@ -66,6 +66,12 @@ int sp_window_bits(void);
 size_t sp_table_bytes(void);
 int sp_synchronize(void* stream);
 
+/* Measurement aid: between sp_profile_begin and sp_profile_end every launch of the dominant kernel
+ * (ped_accumulate_kernel) is bracketed by HIP events on the stream it is launched on; _end returns
+ * the summed kernel time, the number of launches and the number of hashes they processed. */
+int sp_profile_begin(size_t max_launches);
+int sp_profile_end(double* total_ms, uint64_t* launches, uint64_t* units);
+
 /* ---- Pedersen hash: pedersen_hash(x, y) signature.py:296-318 -------------------------------- */
 int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n);
 int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status,

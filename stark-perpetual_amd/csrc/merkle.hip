@@ -1,0 +1,126 @@
+// Sparse Merkle multi-update: root of a height-h (h <= 64) Pedersen tree that holds the given
+// leaves at the given keys and `empty_leaf` everywhere else.
+//
+// Reference shape: cairo-lang's merkle_multi_update as called from
+// services/perpetual/cairo/state/state.cairo:155-173 (positions tree, orders tree, height 64);
+// the hint-side helper starkware/python/merkle_tree.py:4-26 builds the subtree induced by the
+// modified leaves level by level (parents = set(index // 2)).  Same walk here: the host does the
+// integer bookkeeping of which two children feed each induced node (the merkle_tree.py part),
+// the GPU does every hash: per level one gather kernel + the batched Pedersen kernels.
+#include <map>
+#include <vector>
+
+#include "context.hpp"
+
+namespace sp {
+
+struct Scratch {
+  int32_t *X, *ZZ, *Pre;
+  unsigned* flag;
+};
+int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
+                     size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
+                     const Scratch& s);
+int get_scratch_public(size_t n, Scratch& s);
+
+// x[t], y[t] <- children of induced node t (source index < 0: empty-subtree root of this level)
+__global__ void __launch_bounds__(256)
+gather_children_kernel(const uint64_t* __restrict__ prev, const int2* __restrict__ src, size_t m,
+                       const uint64_t* __restrict__ empty_root, uint64_t* __restrict__ x,
+                       uint64_t* __restrict__ y) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  const int2 s = src[t];
+  const u256 e = ld_u256(empty_root);
+  st_u256(x + 4 * t, s.x >= 0 ? ld_u256(prev + 4 * (size_t)s.x) : e);
+  st_u256(y + 4 * t, s.y >= 0 ? ld_u256(prev + 4 * (size_t)s.y) : e);
+}
+
+static DeviceBuffer g_sparse_buf;
+
+}  // namespace sp
+
+using namespace sp;
+
+extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leaves, size_t n,
+                                     unsigned height, const uint64_t* empty_leaf, uint64_t* root,
+                                     uint8_t* status) {
+  SP_REQUIRE_READY();
+  if (height > 64) { set_error("height must be <= 64"); return SP_ERR_BAD_ARGUMENT; }
+  for (size_t i = 0; i < n; ++i) {
+    if (i > 0 && keys[i] <= keys[i - 1]) { set_error("keys must be strictly increasing"); return SP_ERR_BAD_ARGUMENT; }
+    if (height < 64 && (keys[i] >> height) != 0) { set_error("key out of range for height"); return SP_ERR_BAD_ARGUMENT; }
+  }
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  // ---- host bookkeeping: induced subtree (merkle_tree.py:18-26) ----
+  std::vector<uint64_t> idx(keys, keys + n);
+  std::vector<int2> src;                 // all levels, concatenated
+  std::vector<size_t> level_off, level_cnt;
+  for (unsigned l = 0; l < height && !idx.empty(); ++l) {
+    std::vector<uint64_t> nxt;
+    nxt.reserve(idx.size());
+    level_off.push_back(src.size());
+    const size_t m = idx.size();
+    for (size_t j = 0; j < m;) {
+      int2 s;
+      if ((idx[j] & 1) == 0) {
+        s.x = (int)j;
+        if (j + 1 < m && idx[j + 1] == idx[j] + 1) { s.y = (int)(j + 1); nxt.push_back(idx[j] >> 1); j += 2; }
+        else { s.y = -1; nxt.push_back(idx[j] >> 1); j += 1; }
+      } else {
+        s.x = -1; s.y = (int)j; nxt.push_back(idx[j] >> 1); j += 1;
+      }
+      src.push_back(s);
+    }
+    level_cnt.push_back(nxt.size());
+    idx.swap(nxt);
+  }
+  // ---- device buffers: empties[height+1], vals ping/pong [n], x[n], y[n], src ----
+  const size_t nn = n ? n : 1;
+  const size_t fb = nn * 32;
+  const size_t emp_bytes = ((size_t)height + 1) * 32;
+  const size_t src_bytes = (src.size() + 1) * sizeof(int2);
+  SP_HIP(g_sparse_buf.reserve(emp_bytes + 4 * fb + src_bytes + 1024));
+  char* b = (char*)g_sparse_buf.ptr;
+  uint64_t* d_emp = (uint64_t*)b;
+  uint64_t* d_a = (uint64_t*)(b + emp_bytes);
+  uint64_t* d_b = (uint64_t*)(b + emp_bytes + fb);
+  uint64_t* d_x = (uint64_t*)(b + emp_bytes + 2 * fb);
+  uint64_t* d_y = (uint64_t*)(b + emp_bytes + 3 * fb);
+  int2* d_src = (int2*)(b + emp_bytes + 4 * fb);
+  Scratch s;
+  int rc = get_scratch_public(nn, s);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), 0));
+  // empty-subtree roots: empties[k+1] = H(empties[k], empties[k])
+  SP_HIP(hipMemcpy(d_emp, empty_leaf, 32, hipMemcpyHostToDevice));
+  for (unsigned k = 0; k < height; ++k) {
+    rc = enqueue_pedersen(d_emp + 4 * k, 1, d_emp + 4 * k, 1, d_emp + 4 * (k + 1), 1, nullptr, s.flag, 1, 0, s);
+    if (rc != SP_OK) return rc;
+  }
+  if (n == 0) {
+    SP_HIP(hipDeviceSynchronize());
+    SP_HIP(hipMemcpy(root, d_emp + 4 * height, 32, hipMemcpyDeviceToHost));
+  } else {
+    SP_HIP(hipMemcpy(d_a, leaves, n * 32, hipMemcpyHostToDevice));
+    if (!src.empty()) SP_HIP(hipMemcpy(d_src, src.data(), src.size() * sizeof(int2), hipMemcpyHostToDevice));
+    uint64_t *cur = d_a, *nxt = d_b;
+    for (size_t l = 0; l < level_cnt.size(); ++l) {
+      const size_t m = level_cnt[l];
+      hipLaunchKernelGGL(gather_children_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, cur,
+                         d_src + level_off[l], m, d_emp + 4 * l, d_x, d_y);
+      rc = enqueue_pedersen(d_x, 1, d_y, 1, nxt, 1, nullptr, s.flag, m, 0, s);
+      if (rc != SP_OK) return rc;
+      std::swap(cur, nxt);
+    }
+    SP_HIP(hipDeviceSynchronize());
+    SP_HIP(hipMemcpy(root, cur, 32, hipMemcpyDeviceToHost));
+  }
+  if (status) {
+    unsigned f = 0;
+    SP_HIP(hipMemcpy(&f, s.flag, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *status = (uint8_t)f;
+  }
+  return SP_OK;
+}

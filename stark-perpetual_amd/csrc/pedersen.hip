@@ -14,6 +14,8 @@
 //                                      64 lanes touch 64 consecutive dwords
 // Algorithmic bytes per hash: 96 (two felts in, one out).  The kernel is VALU bound
 // (~3.3e3 v_mad_i64_i32 per window addition), not HBM bound - see DESIGN.md.
+#include <vector>
+
 #include "context.hpp"
 
 namespace sp {
@@ -165,12 +167,23 @@ ped_point_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y,
   status[e] = SP_HASH_OK;
 }
 
+// ---- optional per-launch timing of the dominant kernel (bench.py roofline leg) -----------------
+struct KernelProfile {
+  bool enabled = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  std::vector<size_t> units;
+  size_t used = 0;
+};
+static KernelProfile g_prof;
+
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
   int32_t *X, *ZZ, *Pre;
   unsigned* flag;
 };
-static int get_scratch(size_t n, Scratch& s) {
+int get_scratch_public(size_t n, Scratch& s);
+static int get_scratch(size_t n, Scratch& s) { return get_scratch_public(n, s); }
+int get_scratch_public(size_t n, Scratch& s) {
   Context& c = ctx();
   const size_t plane = ((9 * n * sizeof(int32_t)) + 255) & ~(size_t)255;
   SP_HIP(c.scratch.reserve(3 * plane + 256));
@@ -197,8 +210,15 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
   if (n == 0) return SP_OK;
   Context& c = ctx();
   const unsigned blocksA = (unsigned)((n + 255) / 256);
+  const bool prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size();
+  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped,
                      c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+  if (prof) {
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+    g_prof.units.push_back(n);
+    g_prof.used += 2;
+  }
   const size_t T = finish_threads(n);
   const unsigned tpb = T >= 256 ? 256 : 64;
   const unsigned blocksB = (unsigned)((T + tpb - 1) / tpb);
@@ -245,6 +265,39 @@ int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8
   SP_HIP(hipDeviceSynchronize());
   SP_HIP(hipMemcpy(out, dout, fb, hipMemcpyDeviceToHost));
   if (status) SP_HIP(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
+  return SP_OK;
+}
+
+int sp_profile_begin(size_t max_launches) {
+  SP_REQUIRE_READY();
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  while (g_prof.ev.size() < 2 * max_launches) {
+    hipEvent_t e;
+    SP_HIP(hipEventCreate(&e));
+    g_prof.ev.push_back(e);
+  }
+  g_prof.used = 0;
+  g_prof.units.clear();
+  g_prof.enabled = true;
+  return SP_OK;
+}
+
+int sp_profile_end(double* total_ms, uint64_t* launches, uint64_t* units) {
+  SP_REQUIRE_READY();
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  g_prof.enabled = false;
+  double ms = 0;
+  uint64_t u = 0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    SP_HIP(hipEventSynchronize(g_prof.ev[i + 1]));
+    float f = 0;
+    SP_HIP(hipEventElapsedTime(&f, g_prof.ev[i], g_prof.ev[i + 1]));
+    ms += f;
+    u += g_prof.units[i / 2];
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = g_prof.used / 2;
+  if (units) *units = u;
   return SP_OK;
 }
 

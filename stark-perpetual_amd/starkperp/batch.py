@@ -121,6 +121,24 @@ def merkle_root(leaves):
     return unpack_felts(root, 1)[0]
 
 
+def merkle_sparse_root(height, modifications, empty_leaf=0):
+    """Root of the height-`height` tree (<= 64) holding {index: leaf} and `empty_leaf` elsewhere:
+    the multi-update walk of starkware/python/merkle_tree.py:4-26 with every hash on the GPU."""
+    items = sorted(dict(modifications).items())
+    n = len(items)
+    for k, v in items:
+        assert 0 <= k < (1 << height) and 0 <= v < FIELD_PRIME
+    assert 0 <= empty_leaf < FIELD_PRIME
+    lib = _lib.ensure_init()
+    keys = (ctypes.c_uint64 * max(n, 1))(*[k for k, _ in items])
+    root, st = new_felts(1), new_bytes(1)
+    _lib.check(lib.sp_merkle_sparse_root(keys, pack_felts([v for _, v in items]), n, height,
+                                         pack_felts([empty_leaf]), root, st), "sp_merkle_sparse_root")
+    if st[0]:
+        _raise_hash_status(2 if st[0] & 2 else 1)
+    return unpack_felts(root, 1)[0]
+
+
 # ---- ECDSA ------------------------------------------------------------------------------------
 VERIFY_FALSE, VERIFY_TRUE = 0, 1
 VERIFY_ASSERT_S, VERIFY_ASSERT_R, VERIFY_ASSERT_W, VERIFY_ASSERT_MSG, VERIFY_ASSERT_CURVE = 2, 3, 4, 5, 6

@@ -1,0 +1,65 @@
+"""One process per GPU.  The hot path shards by construction (independent hashes / signatures /
+subtrees - SURVEY.md section 8(e)); the only exchange step is the combine of per-rank Merkle
+sub-roots: an all_gather of world_size x 32 bytes (RCCL over xGMI when the backend is "nccl",
+gloo in the CPU tests) followed by the log2(world_size) top levels hashed redundantly on every
+rank.  A Pedersen hash is not an ncclRedOp, so the "tree-reduce" is all_gather + local top-of-tree.
+"""
+from typing import Callable, List, Sequence
+
+
+def shard_range(n_units: int, rank: int, world: int):
+    """Contiguous [lo, hi) slice of n_units owned by `rank` (remainder spread over low ranks)."""
+    base, rem = divmod(n_units, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def felt_to_tensor(torch, value: int, device=None):
+    limbs = [(value >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]
+    signed = [l - (1 << 64) if l >= (1 << 63) else l for l in limbs]
+    return torch.tensor(signed, dtype=torch.int64, device=device)
+
+
+def tensor_to_felt(t) -> int:
+    vals = [int(v) & ((1 << 64) - 1) for v in t.tolist()]
+    return sum(v << (64 * i) for i, v in enumerate(vals))
+
+
+def gather_subroots(dist, torch, subroot: int, device=None, group=None) -> List[int]:
+    """all_gather of one felt per rank; returns the sub-roots in rank order."""
+    world = dist.get_world_size(group)
+    mine = felt_to_tensor(torch, subroot, device)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [tensor_to_felt(t) for t in out]
+
+
+def combine_subroots(subroots: Sequence[int],
+                     hash_many: Callable[[Sequence[int], Sequence[int]], List[int]]) -> int:
+    """Top of the tree over world_size (a power of two) sub-roots."""
+    level = list(subroots)
+    assert len(level) >= 1 and len(level) & (len(level) - 1) == 0
+    while len(level) > 1:
+        level = hash_many(level[0::2], level[1::2])
+    return level[0]
+
+
+def sharded_merkle_root(dist, torch, local_leaves: Sequence[int], merkle_root, hash_many,
+                        device=None, group=None) -> int:
+    """Root of the tree whose leaves are the concatenation of every rank's `local_leaves`
+    (equal power-of-two counts): local subtree -> all_gather -> top levels."""
+    sub = merkle_root(local_leaves)
+    return combine_subroots(gather_subroots(dist, torch, sub, device, group), hash_many)
+
+
+def combine_subroots_dev(lib, dist, subroot_row, gathered, top, stream):
+    """Device-resident variant used by bench.py: `subroot_row` is the [4] int64 view of this
+    rank's root in HBM, `gathered` a [world, 4] buffer, `top` a [2*world-1, 4] buffer."""
+    from . import _lib
+    world = gathered.shape[0]
+    dist.all_gather_into_tensor(gathered, subroot_row.reshape(1, 4))
+    top[:world].copy_(gathered)
+    height = world.bit_length() - 1
+    assert 1 << height == world
+    _lib.check(lib.sp_merkle_build_dev(top.data_ptr(), height, None, stream), "sp_merkle_build_dev")
+    return top[-1]

@@ -1,0 +1,74 @@
+"""GPU parity of the callers around the hash kernels: position leaves, sparse multi-update,
+and the 4096-order batch of BASELINE.json configs[2] against the reference-generated golden."""
+import json
+import os
+import random
+
+import pytest
+
+import workloads as wl
+from oracle import ref_py as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+P, N = R.FIELD_PRIME, R.EC_ORDER
+
+
+def load(name):
+    return json.load(open(os.path.join(GOLD, name)))
+
+
+def h(s):
+    return int(s, 16)
+
+
+def test_position_hashes():
+    from starkperp import state
+    g = load("g6_merkle.json")
+    poss = wl.positions(64, seed=3)
+    assert state.position_hashes_many(poss) == [h(v) for v in g["position_hashes_seed3"]]
+    assert state.position_hash((0, 0, [])) == h(g["empty_position_leaf"])
+
+
+def test_sparse_roots():
+    from starkperp import batch
+    g = load("g6_merkle.json")
+    mods = {k: h(v) for k, v in g["sparse_h20_seed77"]["mods"]}
+    assert batch.merkle_sparse_root(20, mods) == h(g["sparse_h20_seed77"]["root"])
+    emp = [h(v) for v in g["empty_roots_leaf0"]]
+    for hgt in (0, 1, 5, 64):
+        assert batch.merkle_sparse_root(hgt, {}) == emp[hgt]
+    # dense case equals the full rebuild; ragged key patterns vs the oracle
+    lv = wl.leaves(32, seed=9)
+    assert batch.merkle_sparse_root(5, dict(enumerate(lv))) == R.merkle_root(lv)
+    rng = random.Random(4)
+    for hgt, cnt in ((3, 3), (7, 9), (10, 1)):
+        mods = {rng.randrange(1 << hgt): rng.randrange(P) for _ in range(cnt)}
+        assert batch.merkle_sparse_root(hgt, mods, 5) == R.merkle_multi_update_sparse(hgt, mods, 5)
+    assert batch.merkle_sparse_root(64, {2**64 - 1: 7, 0: 9}) == R.merkle_multi_update_sparse(
+        64, {2**64 - 1: 7, 0: 9})
+
+
+def test_c3_order_batch():
+    """4096 limit orders: message hashes, key derivation, signing, verification and the height-64
+    orders-tree update, all against the golden produced by the reference."""
+    from starkperp import batch, perpetual_messages as pm, state
+    g = load("g7_c3_batch.json")
+    orders = wl.limit_orders(g["n"], seed=g["orders_seed"])
+    zs = pm.limit_order_msgs_many([wl.order_args(o) for o in orders])
+    assert wl.digest_felts(zs) == g["z_digest"]
+    assert [hex(v) for v in zs[:4]] == g["z_first4"]
+    keys = wl.private_keys(1024, seed=g["keys_seed"])
+    pubs = batch.public_keys_many(keys)
+    assert wl.digest_felts([q[0] for q in pubs]) == g["pub_digest"]
+    zsig = [z % 2**251 for z in zs]
+    sigs = batch.sign_many(zsig, [keys[o["key_index"]] for o in orders])
+    assert wl.digest_felts([r for r, _ in sigs]) == g["r_digest"]
+    assert wl.digest_felts([s for _, s in sigs]) == g["s_digest"]
+    rs = [r for r, _ in sigs]
+    ss = [(s % (N - 1)) + 1 if i % 16 == 5 else s for i, (_, s) in enumerate(sigs)]
+    ok = batch.verify_many(zsig, rs, ss, [pubs[o["key_index"]][0] for o in orders])
+    assert "".join("1" if v else "0" for v in ok) == g["verify_bits"]
+    mods = {state.order_id_of(z): o["amount_synthetic"] for z, o in zip(zs, orders)}
+    assert len(mods) == g["n_distinct_order_ids"]
+    assert state.orders_tree_root(mods, g["orders_tree_height"]) == h(g["orders_tree_root"])
