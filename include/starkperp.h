@@ -118,6 +118,29 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
  * status: 0 ok, 2 when d is not in (0, EC_ORDER). */
 int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* status, size_t n);
 
+/* ---- prover-side transforms over GF(p) (build-defined: the reference has no prover) -------------- */
+/* Field and generator: pedersen_params.json:20-21 (FIELD_PRIME, FIELD_GEN = 3).  All pointers are
+ * device pointers to plain felts unless named *_host.                                            */
+/* Radix-2 NTT of 2^log_n felts, natural order in and out; inverse != 0 divides by n. */
+int sp_ntt_dev(const uint64_t* in, uint64_t* out, unsigned log_n, int inverse, void* stream);
+/* Coset low-degree extension of ncols columns (column c at in + c * 2^log_n felts) from <w_n> to
+ * shift * <w_{n * 2^log_blowup}>, natural order; out holds ncols * 2^(log_n + log_blowup) felts. */
+int sp_lde_dev(const uint64_t* in, uint64_t* out, unsigned ncols, unsigned log_n, unsigned log_blowup,
+               const uint64_t* shift_host, void* stream);
+/* Execution trace of the Pedersen-step AIR: 512 rows per hash, columns s, px, py, lambda
+ * (cols = 4 columns of 512 * n_hashes felts).  Step relation: signature.py:305-317 with the chord
+ * rule of math_utils.py:59-68. */
+int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes, uint64_t* cols,
+                          void* stream);
+/* Composition column sum_k alpha_k C_k(x) / (x^n - 1) on the blowup-4 coset.  trace_lde: 4 columns of
+ * 4 * 2^log_n felts; periodic_lde: 6 tables of 2048 felts; alphas_host: 11 felts. */
+int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
+                    const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream);
+/* One FRI fold of f on shift * <w_M> (M = 2^log_m) to g on shift^2 * <w_{M/2}>:
+ * g(x^2) = (f(x) + f(-x)) / 2 + beta (f(x) - f(-x)) / (2 x). */
+int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uint64_t* beta_host,
+                    const uint64_t* shift_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,196 @@
+"""
+ORACLE (test infrastructure, NOT product code) for the prover-side half of the hot path:
+radix-2 NTT / coset LDE, the build-defined Pedersen-step AIR, FRI folding and Pedersen-Merkle
+commitments over p = 2^251 + 17*2^192 + 1.
+
+PARITY UNPINNED: the reference tree contains no prover (no NTT, AIR or FRI code - SURVEY.md
+section 2, rows A10-A13), so there is nothing to pin these functions against.  What IS tied to the
+reference: the field and its generator (pedersen_params.json:20-21), the step relation of the AIR
+(derived line by line from signature.py:305-317 and math_utils.py:64-67) and every hash inside a
+commitment (oracle.ref_py.pedersen_hash, pinned).  Correctness of the rest is established by
+algebraic self-checks in tests/test_stark_oracle.py (naive DFT, iNTT o NTT = id, fold vs direct
+polynomial evaluation, the composition polynomial of a valid trace has degree < 4n - deg Z_H).
+
+Plain Python big-int arithmetic, written for clarity at small sizes.
+"""
+from . import ref_py as R
+
+P = R.FIELD_PRIME
+GEN = R.FIELD_GEN  # 3 generates GF(p)^*;  p - 1 = 2^192 * (2^59 + 17)
+BLOWUP = 4
+ROWS_PER_HASH = 512  # two 256-row blocks (252 bit steps + 4 padding rows) per hash
+
+
+def root_of_unity(log_n):
+    """Primitive 2^log_n-th root of unity: 3^((p-1)/2^log_n)."""
+    assert 0 <= log_n <= 192
+    return pow(GEN, (P - 1) >> log_n, P)
+
+
+def naive_dft(coeffs, w):
+    n = len(coeffs)
+    return [sum(c * pow(w, i * k, P) for k, c in enumerate(coeffs)) % P for i in range(n)]
+
+
+def ntt(coeffs, w):
+    """Evaluations of sum c_k x^k at x = w^i, i = 0..n-1 (natural order both sides)."""
+    n = len(coeffs)
+    if n == 1:
+        return list(coeffs)
+    even = ntt(coeffs[0::2], w * w % P)
+    odd = ntt(coeffs[1::2], w * w % P)
+    out = [0] * n
+    t = 1
+    for i in range(n // 2):
+        o = t * odd[i] % P
+        out[i] = (even[i] + o) % P
+        out[i + n // 2] = (even[i] - o) % P
+        t = t * w % P
+    return out
+
+
+def intt(evals, w):
+    n = len(evals)
+    inv_n = pow(n, -1, P)
+    return [v * inv_n % P for v in ntt(evals, pow(w, -1, P))]
+
+
+def lde(evals, blowup=BLOWUP, shift=GEN):
+    """Values of the interpolant of `evals` (over <w_n>) on the coset shift * <w_{blowup n}>."""
+    n = len(evals)
+    log_n = n.bit_length() - 1
+    coeffs = intt(evals, root_of_unity(log_n))
+    shifted = [c * pow(shift, k, P) % P for k, c in enumerate(coeffs)] + [0] * (n * (blowup - 1))
+    return ntt(shifted, root_of_unity(log_n + blowup.bit_length() - 1))
+
+
+# ---- the Pedersen-step AIR ----------------------------------------------------------------------
+# Columns s, px, py, lam.  A hash occupies 512 rows: block 0 (rows 0..255) consumes x, block 1
+# (rows 256..511) consumes y.  In row j of a block (j = 0..251) with constant point
+# C = CONSTANT_POINTS[2 + 252*block + j]:   b = s - 2 s_next  in {0,1};  if b: (px,py)_next =
+# (px,py) + C by the chord rule with slope lam;  else unchanged.  Rows 252..255 are padding (s = 0).
+def pedersen_trace(inputs):
+    """inputs: list of (x, y).  Returns columns [s, px, py, lam], each of len 512 * len(inputs)."""
+    s_col, px_col, py_col, lam_col = [], [], [], []
+    for x, y in inputs:
+        acc = tuple(R.SHIFT_POINT)
+        for block, elem in enumerate((x, y)):
+            s = elem
+            for j in range(256):
+                s_col.append(s)
+                px_col.append(acc[0])
+                py_col.append(acc[1])
+                lam = 0
+                if j < 252:
+                    c = R.CONSTANT_POINTS[2 + 252 * block + j]
+                    if s & 1:
+                        lam = R.div_mod(acc[1] - c[1], acc[0] - c[0], P)
+                        acc = R.ec_add(acc, c)
+                    s >>= 1
+                lam_col.append(lam)
+    return [s_col, px_col, py_col, lam_col]
+
+
+def periodic_columns():
+    """Period-512 columns: cx, cy (constant points; padding rows repeat the generator), and the
+    selectors  step (1 except on the last row of each 256-block), mid (row 255), end (row 511),
+    zero252 (rows 252 and 508: s must be 0 there)."""
+    cx, cy, step, mid, end, z252 = [], [], [], [], [], []
+    for r in range(512):
+        block, j = divmod(r, 256)
+        c = R.CONSTANT_POINTS[2 + 252 * block + j] if j < 252 else R.EC_GEN
+        cx.append(c[0])
+        cy.append(c[1])
+        step.append(0 if j == 255 else 1)
+        mid.append(1 if r == 255 else 0)
+        end.append(1 if r == 511 else 0)
+        z252.append(1 if j == 252 else 0)
+    return [cx, cy, step, mid, end, z252]
+
+
+N_CONSTRAINTS = 11
+
+
+def constraint_values(cur, nxt, per):
+    """The eleven constraint polynomials at one point.  cur / nxt = (s, px, py, lam) at x and at
+    w_n x;  per = (cx, cy, step, mid, end, z252) at x."""
+    s, px, py, lam = cur
+    s_n, px_n, py_n, _ = nxt
+    cx, cy, step, mid, end, z252 = per
+    b = (s - 2 * s_n) % P
+    nb = (1 - b) % P
+    sx, sy = R.SHIFT_POINT
+    return [
+        step * b * (b - 1) % P,
+        step * b * (lam * (px - cx) - (py - cy)) % P,
+        step * b * (lam * lam - px - cx - px_n) % P,
+        step * b * (lam * (px - px_n) - py - py_n) % P,
+        step * nb * (px_n - px) % P,
+        step * nb * (py_n - py) % P,
+        mid * (px_n - px) % P,
+        mid * (py_n - py) % P,
+        end * (px_n - sx) % P,
+        end * (py_n - sy) % P,
+        z252 * s % P,
+    ]
+
+
+def composition_on_coset(trace_lde, per_lde, n, alphas, shift=GEN):
+    """Random linear combination of the constraints divided by Z_H(x) = x^n - 1, on the LDE coset.
+    trace_lde: 4 columns of 4n values;  per_lde: 6 tables of 4*512 values (index i mod 2048)."""
+    m = BLOWUP * n
+    w = root_of_unity(m.bit_length() - 1)
+    out = []
+    zinv = [pow((pow(shift, n, P) * pow(w, n * k, P) - 1) % P, -1, P) for k in range(BLOWUP)]
+    for i in range(m):
+        cur = [col[i] for col in trace_lde]
+        nxt = [col[(i + BLOWUP) % m] for col in trace_lde]
+        per = [t[i % (BLOWUP * 512)] for t in per_lde]
+        cv = constraint_values(cur, nxt, per)
+        acc = sum(a * c for a, c in zip(alphas, cv)) % P
+        out.append(acc * zinv[i % BLOWUP] % P)
+    return out
+
+
+def periodic_lde(n, shift=GEN):
+    """Periodic columns evaluated on the LDE coset: q(x^(n/512)) with x = shift * w_{4n}^i takes
+    4*512 distinct values = the blowup-4 LDE of the 512 column values with shift^(n/512)."""
+    return [lde(col, BLOWUP, pow(shift, n // 512, P)) for col in periodic_columns()]
+
+
+# ---- FRI ---------------------------------------------------------------------------------------
+def fri_fold(values, beta, shift):
+    """values = f on shift * <w_M> (natural order).  Returns g on shift^2 * <w_{M/2}> with
+    g(x^2) = (f(x) + f(-x))/2 + beta (f(x) - f(-x)) / (2x)."""
+    m = len(values)
+    w = root_of_unity(m.bit_length() - 1)
+    inv2 = pow(2, -1, P)
+    half = m // 2
+    out = []
+    x = shift
+    for i in range(half):
+        a, b = values[i], values[i + half]
+        out.append(((a + b) * inv2 + beta * (a - b) % P * pow(2 * x, -1, P)) % P)
+        x = x * w % P
+    return out
+
+
+def poly_degree_bound_check(values, shift, max_deg):
+    """True iff the interpolant of `values` on shift*<w_M> has degree <= max_deg."""
+    m = len(values)
+    coeffs = intt(values, root_of_unity(m.bit_length() - 1))
+    return all(c == 0 for c in coeffs[max_deg + 1 :])
+
+
+# ---- commitments ---------------------------------------------------------------------------------
+def commit_rows(columns):
+    """Merkle root over rows: leaf = H(...H(H(c0, c1), c2)..., ck) (a single column commits the
+    felts themselves), node = H(left, right)."""
+    n = len(columns[0])
+    leaves = []
+    for i in range(n):
+        acc = columns[0][i]
+        for col in columns[1:]:
+            acc = R.pedersen_hash(acc, col[i])
+        leaves.append(acc)
+    return R.merkle_root(leaves)

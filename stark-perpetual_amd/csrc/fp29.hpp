@@ -149,6 +149,17 @@ SP_HD fe fe_carry(const fe& a) {
   return r;
 }
 
+// Weak reduction for long add/sub chains (NTT butterflies): subtracts floor(value / 2^251) * p.
+// Input lazy or N-form with |limb 8| < 2^29; output N-form with value in (-p, 2p).
+SP_HD fe fe_weak_reduce(const fe& a) {
+  const int32_t q = a.l[8] >> 19;
+  fe r = a;
+  r.l[0] -= q;
+  r.l[6] -= q * P6;
+  r.l[8] -= q * P8;
+  return fe_carry(r);
+}
+
 // ---- column products ----
 struct cols {
   int64_t c[17];

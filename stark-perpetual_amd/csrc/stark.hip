@@ -1,0 +1,525 @@
+// Prover-side kernels over GF(p), p = 2^251 + 17*2^192 + 1: radix-2 NTT / coset LDE staged
+// through LDS, the Pedersen-step AIR (trace generation + constraint evaluation), FRI folding.
+// The reference tree has no prover, so everything here is build-defined and checked against
+// oracle/stark_ref.py ("parity unpinned"); the field, its generator
+// (pedersen_params.json:20-21) and the AIR's step relation (signature.py:305-317,
+// math_utils.py:64-67) are the reference's.
+//
+// Data layout in HBM: a column is a contiguous array of 32-byte felts (plain integers at the C
+// ABI; Montgomery form between the passes of one transform).  Algorithmic bytes: an NTT pass reads
+// and writes each felt once (64 B per element per pass); 2^22 points take 3 passes
+// (9 + 2 strided stages, then 11 stages on a contiguous 2048-point tile in LDS).
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "context.hpp"
+#include "curve_consts.hpp"
+
+namespace sp {
+
+constexpr int TILE_LOG = 11;
+constexpr int TILE = 1 << TILE_LOG;  // 2048 felts = 72 KiB of LDS as 9 x int32 planes
+
+__device__ __forceinline__ fe lds_get(const int32_t* lds, int e) {
+  fe v;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) v.l[l] = lds[l * TILE + e];
+  return v;
+}
+__device__ __forceinline__ void lds_put(int32_t* lds, int e, const fe& v) {
+#pragma unroll
+  for (int l = 0; l < NL; ++l) lds[l * TILE + e] = v.l[l];
+}
+__device__ __forceinline__ fe ld_fe_packed(const uint64_t* p) { return fe_unpack(ld_u256(p)); }
+
+// One pass = `nst` consecutive radix-2 stages on tiles of 2^log_e felts (2^log_t coupled points x
+// 2^(log_e-log_t) adjacent columns).  Stage with global span h = 2^(t + log_lo):
+//   DIF (forward half of a natural->bit-reversed transform): a' = a + b, b' = (a - b) w
+//   DIT (bit-reversed->natural):                             a' = a + w b, b' = a - w b
+// with w = omega_{2h}^(index mod h) = tw[(index mod h) << (log_tw - 1 - t - log_lo)].
+__global__ void __launch_bounds__(256)
+ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int log_e, int log_t,
+                int log_lo, int nst, int t_first, int dit, const uint64_t* __restrict__ tw, int log_tw,
+                int in_plain, int out_plain, int use_scale, fe scale) {
+  __shared__ int32_t lds[NL * TILE];
+  const int E = 1 << log_e;
+  const int log_c = log_e - log_t;
+  const int C = 1 << log_c;
+  const size_t low_blocks = ((size_t)1 << log_lo) >> log_c;
+  const size_t high = blockIdx.x / low_blocks;
+  const size_t lowb = blockIdx.x % low_blocks;
+  const size_t base = (high << (log_t + log_lo)) | (lowb << log_c);
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const int k = e >> log_c, c = e & (C - 1);
+    const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
+    fe v = ld_fe_packed(in + 4 * idx);
+    if (in_plain) v = fe_to_mont(v);
+    lds_put(lds, e, v);
+  }
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const int t = dit ? (t_first + s) : (t_first - s);
+    const int tmask = (1 << t) - 1;
+    for (int p = threadIdx.x; p < E / 2; p += 256) {
+      const int c = p & (C - 1), kk = p >> log_c;
+      const int k0 = ((kk >> t) << (t + 1)) | (kk & tmask);
+      const int e0 = (k0 << log_c) | c, e1 = e0 + (1 << (t + log_c));
+      const size_t j = ((size_t)(k0 & tmask) << log_lo) | (lowb << log_c) | (size_t)c;
+      const fe w = ld_fe_packed(tw + 4 * (j << (log_tw - 1 - t - log_lo)));
+      const fe a = lds_get(lds, e0), b = lds_get(lds, e1);
+      if (dit) {
+        const fe wb = fe_mul(b, w);
+        lds_put(lds, e0, fe_weak_reduce(fe_add(a, wb)));
+        lds_put(lds, e1, fe_weak_reduce(fe_sub(a, wb)));
+      } else {
+        lds_put(lds, e0, fe_weak_reduce(fe_add(a, b)));
+        lds_put(lds, e1, fe_mul(fe_sub(a, b), w));
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const int k = e >> log_c, c = e & (C - 1);
+    const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
+    fe v = lds_get(lds, e);
+    if (use_scale) v = fe_mul(v, scale);
+    v = out_plain ? fe_from_mont(v) : fe_canon(v);
+    st_u256(out + 4 * idx, fe_pack(v));
+  }
+}
+
+// W[k] = base^k (Montgomery, packed) from the squarings pw[b] = base^(2^b); optional factor.
+__global__ void __launch_bounds__(256)
+powers_kernel(uint64_t* __restrict__ W, size_t count, const fe* __restrict__ pw, int nbits, fe factor) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  fe acc = factor;
+  for (int b = 0; b < nbits; ++b) {
+    if ((k >> b) & 1) acc = fe_mul(acc, pw[b]);
+  }
+  st_u256(W + 4 * k, fe_pack(fe_canon(fe_mul(acc, FE_ONE_M))));
+}
+
+// out[i] = in[bitrev(i)]
+__global__ void __launch_bounds__(256)
+bitrev_copy_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int log_n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> log_n) return;
+  const size_t r = log_n ? (__brevll((unsigned long long)i) >> (64 - log_n)) : 0;
+  st_u256(out + 4 * i, ld_u256(in + 4 * r));
+}
+
+// LDE glue: coefficients in bit-reversed order (Montgomery) -> zero-padded, coset-shifted input of
+// the big DIT transform.  out[(j << log_b) + 0] = coef[j] * G[bitrev_n(j)], other slots 0.
+__global__ void __launch_bounds__(256)
+lde_pad_kernel(const uint64_t* __restrict__ coef, uint64_t* __restrict__ out, int log_n, int log_b,
+               const uint64_t* __restrict__ G) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> (log_n + log_b)) return;
+  u256 v;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v.w[q] = 0;
+  if ((i & (((size_t)1 << log_b) - 1)) == 0) {
+    const size_t j = i >> log_b;
+    const size_t c = log_n ? (__brevll((unsigned long long)j) >> (64 - log_n)) : 0;
+    const fe prod = fe_mul(ld_fe_packed(coef + 4 * j), ld_fe_packed(G + 4 * c));
+    v = fe_pack(fe_canon(fe_mul(prod, FE_ONE_M)));
+  }
+  st_u256(out + 4 * i, v);
+}
+
+// ---- Pedersen-step AIR --------------------------------------------------------------------------
+// Trace generation: one thread per hash writes 512 rows of (s, px, py, lam) - witness generation
+// with the reference's affine chord rule (math_utils.py:59-68), one inversion per set bit.
+__global__ void __launch_bounds__(64)
+pedersen_trace_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t m,
+                      const aff_packed* __restrict__ bits /* 504 per-bit points */, aff_packed shift,
+                      aff_packed pad, uint64_t* __restrict__ cols /* [4][512 m] plain felts */) {
+  const size_t hsh = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (hsh >= m) return;
+  const size_t n = 512 * m;
+  uint64_t* cs = cols;
+  uint64_t* cpx = cols + 4 * n;
+  uint64_t* cpy = cols + 8 * n;
+  uint64_t* cl = cols + 12 * n;
+  aff acc = ld_aff(&shift);
+  u256 zero;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) zero.w[q] = 0;
+  for (int block = 0; block < 2; ++block) {
+    u256 s = ld_u256((block ? y : x) + 4 * hsh);
+    for (int j = 0; j < 256; ++j) {
+      const size_t row = 512 * hsh + 256 * block + j;
+      st_u256(cs + 4 * row, s);
+      st_u256(cpx + 4 * row, fe_pack(fe_from_mont(acc.x)));
+      st_u256(cpy + 4 * row, fe_pack(fe_from_mont(acc.y)));
+      u256 lam_out = zero;
+      if (j < 252) {
+        if (s.w[0] & 1u) {
+          const aff c = ld_aff(bits + 252 * block + j);
+          const fe lam = fe_mul(fe_sub(acc.y, c.y), fe_inv(fe_carry(fe_sub(acc.x, c.x))));
+          const fe x3 = fe_carry(fe_sub(fe_sub(fe_sqr(lam), acc.x), c.x));
+          const fe y3 = fe_carry(fe_sub(fe_mul(lam, fe_sub(acc.x, x3)), acc.y));
+          acc.x = fe_mul(x3, FE_ONE_M);
+          acc.y = fe_mul(y3, FE_ONE_M);
+          lam_out = fe_pack(fe_from_mont(lam));
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) s.w[q] = (s.w[q] >> 1) | (s.w[q + 1] << 31);
+        s.w[7] >>= 1;
+      }
+      st_u256(cl + 4 * row, lam_out);
+    }
+  }
+}
+
+struct AirParams {
+  fe alpha[11];  // Montgomery
+  fe zinv[4];    // 1 / (x^n - 1) for i mod 4, Montgomery
+  fe shift_x, shift_y;
+};
+
+// Composition column on the LDE coset: sum_k alpha_k C_k(x) / Z_H(x).  Reads the four trace columns
+// at i and i + blowup (the next trace row) and six periodic tables at i mod 2048.
+__global__ void __launch_bounds__(256)
+air_eval_kernel(const uint64_t* __restrict__ trace /* [4][M] plain */, const uint64_t* __restrict__ per /* [6][2048] plain */,
+                size_t M, AirParams prm, uint64_t* __restrict__ out /* [M] plain */) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const size_t in = (i + 4) & (M - 1);
+  auto col = [&](int c, size_t r) { return fe_to_mont(ld_fe_packed(trace + 4 * ((size_t)c * M + r))); };
+  auto pcol = [&](int c) { return fe_to_mont(ld_fe_packed(per + 4 * ((size_t)c * 2048 + (i & 2047)))); };
+  const fe s = col(0, i), px = col(1, i), py = col(2, i), lam = col(3, i);
+  const fe s_n = col(0, in), px_n = col(1, in), py_n = col(2, in);
+  const fe cx = pcol(0), cy = pcol(1), step = pcol(2), mid = pcol(3), end = pcol(4), z252 = pcol(5);
+  const fe b = fe_carry(fe_sub(s, fe_dbl(s_n)));
+  const fe nb = fe_carry(fe_sub(FE_ONE_M, b));
+  const fe dxn = fe_carry(fe_sub(px_n, px));
+  const fe dyn = fe_carry(fe_sub(py_n, py));
+  fe c[11];
+  c[0] = fe_mul(b, fe_carry(fe_sub(b, FE_ONE_M)));
+  c[1] = fe_mul(b, fe_carry(fe_sub(fe_mul(lam, fe_sub(px, cx)), fe_sub(py, cy))));
+  c[2] = fe_mul(b, fe_carry(fe_sub(fe_sub(fe_sqr(lam), px), fe_add(cx, px_n))));
+  c[3] = fe_mul(b, fe_carry(fe_sub(fe_mul(lam, fe_sub(px, px_n)), fe_add(py, py_n))));
+  c[4] = fe_mul(nb, dxn);
+  c[5] = fe_mul(nb, dyn);
+  // step selector multiplies the first six
+  fe acc_step = fe_mul(prm.alpha[0], c[0]);
+#pragma unroll
+  for (int k = 1; k < 6; ++k) acc_step = fe_weak_reduce(fe_add(acc_step, fe_mul(prm.alpha[k], c[k])));
+  fe acc = fe_mul(step, acc_step);
+  const fe mids = fe_mul_add_mul(prm.alpha[6], dxn, prm.alpha[7], dyn);
+  acc = fe_weak_reduce(fe_add(acc, fe_mul(mid, mids)));
+  const fe ends = fe_mul_add_mul(prm.alpha[8], fe_carry(fe_sub(px_n, prm.shift_x)), prm.alpha[9],
+                                 fe_carry(fe_sub(py_n, prm.shift_y)));
+  acc = fe_weak_reduce(fe_add(acc, fe_mul(end, ends)));
+  acc = fe_weak_reduce(fe_add(acc, fe_mul(prm.alpha[10], fe_mul(z252, s))));
+  const fe q = fe_mul(acc, prm.zinv[i & 3]);
+  st_u256(out + 4 * i, fe_pack(fe_from_mont(q)));
+}
+
+// FRI fold: g[i] = (f[i] + f[i+M/2]) / 2 + beta (f[i] - f[i+M/2]) / (2 x_i),  x_i = shift w_M^i.
+// tw_inv holds w^{-i} (table for size 2^log_tw); c1 = 1/2, c2 = beta / (2 shift), Montgomery.
+__global__ void __launch_bounds__(256)
+fri_fold_kernel(const uint64_t* __restrict__ f, uint64_t* __restrict__ g, int log_m,
+                const uint64_t* __restrict__ tw_inv, int log_tw, fe c1, fe c2) {
+  const size_t half = (size_t)1 << (log_m - 1);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= half) return;
+  const fe a = fe_to_mont(ld_fe_packed(f + 4 * i));
+  const fe b = fe_to_mont(ld_fe_packed(f + 4 * (i + half)));
+  const fe winv = ld_fe_packed(tw_inv + 4 * (i << (log_tw - log_m)));
+  const fe odd = fe_mul(fe_mul(fe_sub(a, b), winv), c2);
+  const fe even = fe_mul(fe_carry(fe_add(a, b)), c1);
+  st_u256(g + 4 * i, fe_pack(fe_from_mont(fe_carry(fe_add(even, odd)))));
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+struct Tables {
+  std::map<std::pair<int, int>, DeviceBuffer> twiddle;        // (log_n, inverse) -> N/2 powers
+  std::map<std::pair<int, std::vector<uint32_t>>, DeviceBuffer> coset;  // (log_n, shift words) -> shift^c / n
+  DeviceBuffer work;   // ping-pong columns for LDE
+  DeviceBuffer bits;   // 504 per-bit constant points for trace generation
+  bool bits_ready = false;
+};
+static Tables g_tab;
+
+static fe h_pow_u64(fe base_m, uint64_t e) {
+  fe r = FE_ONE_M;
+  for (int i = 63; i >= 0; --i) {
+    r = fe_sqr(r);
+    if ((e >> i) & 1) r = fe_mul(r, base_m);
+  }
+  return r;
+}
+// primitive 2^log_n-th root of unity: 3^((p-1) / 2^log_n), (p-1) = 2^192 (2^59 + 17)
+static fe h_root_of_unity(int log_n) {
+  const fe three = fe_to_mont(fe{{3, 0, 0, 0, 0, 0, 0, 0, 0}});
+  fe c = h_pow_u64(three, ((uint64_t)1 << 59) + 17);
+  for (int i = 0; i < 192 - log_n; ++i) c = fe_sqr(c);
+  return c;
+}
+static fe h_inv(const fe& a) { return fe_inv(a); }
+
+static int build_powers(DeviceBuffer& buf, size_t count, fe base_m, fe factor_m, hipStream_t st) {
+  SP_HIP(buf.reserve(count * 32 + 64));
+  int nbits = 0;
+  while (((size_t)1 << nbits) < count) ++nbits;
+  if (nbits == 0) nbits = 1;
+  std::vector<fe> pw(nbits);
+  fe cur = base_m;
+  for (int b = 0; b < nbits; ++b) { pw[b] = fe_mul(cur, FE_ONE_M); cur = fe_sqr(cur); }
+  fe* d_pw = nullptr;
+  SP_HIP(hipMalloc(&d_pw, nbits * sizeof(fe)));
+  SP_HIP(hipMemcpy(d_pw, pw.data(), nbits * sizeof(fe), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(powers_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                     (uint64_t*)buf.ptr, count, d_pw, nbits, factor_m);
+  SP_HIP(hipGetLastError());
+  SP_HIP(hipStreamSynchronize(st));
+  (void)hipFree(d_pw);
+  return SP_OK;
+}
+
+static int get_twiddles(int log_n, int inverse, const uint64_t** out, hipStream_t st) {
+  auto key = std::make_pair(log_n, inverse);
+  auto it = g_tab.twiddle.find(key);
+  if (it == g_tab.twiddle.end()) {
+    fe w = h_root_of_unity(log_n);
+    if (inverse) w = h_inv(w);
+    DeviceBuffer buf;
+    const size_t count = log_n ? ((size_t)1 << (log_n - 1)) : 1;
+    int rc = build_powers(buf, count, w, FE_ONE_M, st);
+    if (rc != SP_OK) return rc;
+    it = g_tab.twiddle.emplace(key, buf).first;
+  }
+  *out = (const uint64_t*)it->second.ptr;
+  return SP_OK;
+}
+
+// Full transform of one column.  dit = 0: natural -> bit-reversed (DIF), dit = 1: bit-reversed ->
+// natural.  in/out may alias.  Montgomery/plain conversion happens in the first/last pass.
+static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse, int dit, int in_plain,
+                      int out_plain, int use_scale, fe scale, hipStream_t st) {
+  const uint64_t* tw;
+  int rc = get_twiddles(log_n, inverse, &tw, st);
+  if (rc != SP_OK) return rc;
+  if (log_n == 0) {
+    // single point: (optionally) scale and convert
+    hipLaunchKernelGGL(ntt_tile_kernel, dim3(1), dim3(256), 0, st, in, out, 0, 0, 0, 0, 0, dit, tw, 1,
+                       in_plain, out_plain, use_scale, scale);
+    SP_HIP(hipGetLastError());
+    return SP_OK;
+  }
+  // pass plan: local pass covers the low min(11, log_n) stages; the rest in strided passes of <= 9
+  struct Pass { int log_e, log_t, log_lo, nst, t_first; };
+  std::vector<Pass> plan;
+  const int local = log_n < TILE_LOG ? log_n : TILE_LOG;
+  const int rest = log_n - local;
+  const int npass = (rest + 8) / 9;
+  std::vector<Pass> strided;
+  int lo = local;
+  for (int pi = 0; pi < npass; ++pi) {
+    const int cnt = (rest - (lo - local) + (npass - pi) - 1) / (npass - pi);
+    Pass ps;
+    ps.log_e = TILE_LOG;
+    ps.log_t = cnt;
+    ps.log_lo = lo;
+    ps.nst = cnt;
+    ps.t_first = dit ? 0 : cnt - 1;
+    strided.push_back(ps);
+    lo += cnt;
+  }
+  Pass loc{local, local, 0, local, dit ? 0 : local - 1};
+  if (dit) {
+    plan.push_back(loc);
+    for (auto& ps : strided) plan.push_back(ps);
+  } else {
+    for (auto it = strided.rbegin(); it != strided.rend(); ++it) plan.push_back(*it);
+    plan.push_back(loc);
+  }
+  const uint64_t* src = in;
+  for (size_t pi = 0; pi < plan.size(); ++pi) {
+    const Pass& ps = plan[pi];
+    const bool first = pi == 0, last = pi + 1 == plan.size();
+    const unsigned blocks = (unsigned)(((size_t)1 << log_n) >> ps.log_e);
+    hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks), dim3(256), 0, st, src, out, ps.log_e, ps.log_t,
+                       ps.log_lo, ps.nst, ps.t_first, dit, tw, log_n, first ? in_plain : 0,
+                       last ? out_plain : 0, last ? use_scale : 0, scale);
+    src = out;
+  }
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+}  // namespace sp
+
+using namespace sp;
+
+extern "C" {
+
+int sp_ntt_dev(const uint64_t* in, uint64_t* out, unsigned log_n, int inverse, void* stream) {
+  SP_REQUIRE_READY();
+  if (log_n > 26) { set_error("log_n too large"); return SP_ERR_BAD_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)1 << log_n;
+  SP_HIP(g_tab.work.reserve(n * 32));
+  uint64_t* tmp = (uint64_t*)g_tab.work.ptr;
+  // natural -> natural: DIF into tmp (bit-reversed), then permute
+  fe scale = FE_ONE_M;
+  if (inverse) {
+    fe nm = fe_to_mont(fe{{(int32_t)(n & LMASK), (int32_t)(n >> LB), 0, 0, 0, 0, 0, 0, 0}});
+    scale = fe_inv(nm);
+  }
+  int rc = ntt_column(in, tmp, (int)log_n, inverse, 0, 1, 1, inverse, scale, st);
+  if (rc != SP_OK) return rc;
+  hipLaunchKernelGGL(bitrev_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp, out,
+                     (int)log_n);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_lde_dev(const uint64_t* in, uint64_t* out, unsigned ncols, unsigned log_n, unsigned log_blowup,
+               const uint64_t* shift_host, void* stream) {
+  SP_REQUIRE_READY();
+  if (log_n + log_blowup > 26) { set_error("LDE size too large"); return SP_ERR_BAD_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)1 << log_n, m = n << log_blowup;
+  u256 sh;
+  std::memcpy(sh.w, shift_host, 32);
+  std::vector<uint32_t> key_words(sh.w, sh.w + 8);
+  key_words.push_back(log_blowup);
+  auto key = std::make_pair((int)log_n, key_words);
+  auto it = g_tab.coset.find(key);
+  if (it == g_tab.coset.end()) {
+    const fe shift_m = fe_to_mont(fe_unpack(sh));
+    fe nm = fe_to_mont(fe{{(int32_t)(n & LMASK), (int32_t)(n >> LB), 0, 0, 0, 0, 0, 0, 0}});
+    DeviceBuffer buf;
+    int rc = build_powers(buf, n, shift_m, fe_inv(nm), st);
+    if (rc != SP_OK) return rc;
+    it = g_tab.coset.emplace(key, buf).first;
+  }
+  const uint64_t* G = (const uint64_t*)it->second.ptr;
+  SP_HIP(g_tab.work.reserve(n * 32));
+  uint64_t* coef = (uint64_t*)g_tab.work.ptr;
+  for (unsigned c = 0; c < ncols; ++c) {
+    const uint64_t* src = in + 4 * (size_t)c * n;
+    uint64_t* dst = out + 4 * (size_t)c * m;
+    int rc = ntt_column(src, coef, (int)log_n, 1, 0, 1, 0, 0, FE_ONE_M, st);  // -> bit-reversed coefficients
+    if (rc != SP_OK) return rc;
+    hipLaunchKernelGGL(lde_pad_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, coef, dst,
+                       (int)log_n, (int)log_blowup, G);
+    rc = ntt_column(dst, dst, (int)(log_n + log_blowup), 0, 1, 0, 1, 0, FE_ONE_M, st);
+    if (rc != SP_OK) return rc;
+  }
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes, uint64_t* cols,
+                          void* stream) {
+  SP_REQUIRE_READY();
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  hipStream_t st = (hipStream_t)stream;
+  if (!g_tab.bits_ready) {
+    // per-bit points = window value 2^b of the w-bit window tables minus the offsets is awkward;
+    // recompute the doubling chains on the host like sp_init does.
+    std::vector<aff_packed> h(504);
+    auto mk = [](const u256& px, const u256& py) {
+      aff a;
+      a.x = fe_to_mont(fe_unpack(px));
+      a.y = fe_to_mont(fe_unpack(py));
+      return a;
+    };
+    auto dbl = [](const aff& a) {
+      const fe xx = fe_sqr(a.x);
+      const fe num = fe_carry(fe_add(fe_carry(fe_add(fe_dbl(xx), xx)), FE_ONE_M));
+      const fe lam = fe_mul(num, fe_inv(fe_carry(fe_dbl(a.y))));
+      aff r;
+      r.x = fe_mul(fe_carry(fe_sub(fe_sqr(lam), fe_dbl(a.x))), FE_ONE_M);
+      r.y = fe_mul(fe_carry(fe_sub(fe_mul(lam, fe_sub(a.x, r.x)), a.y)), FE_ONE_M);
+      return r;
+    };
+    auto pk = [](const aff& a) {
+      aff_packed o;
+      o.x = fe_pack(fe_canon(fe_mul(a.x, FE_ONE_M)));
+      o.y = fe_pack(fe_canon(fe_mul(a.y, FE_ONE_M)));
+      return o;
+    };
+    const aff bases[4] = {mk(PT_P0_X, PT_P0_Y), mk(PT_P1_X, PT_P1_Y), mk(PT_P2_X, PT_P2_Y), mk(PT_P3_X, PT_P3_Y)};
+    for (int e2 = 0; e2 < 2; ++e2) {
+      aff q = bases[2 * e2];
+      for (int j = 0; j < 248; ++j) { h[252 * e2 + j] = pk(q); q = dbl(q); }
+      q = bases[2 * e2 + 1];
+      for (int j = 0; j < 4; ++j) { h[252 * e2 + 248 + j] = pk(q); q = dbl(q); }
+    }
+    SP_HIP(g_tab.bits.reserve(504 * sizeof(aff_packed)));
+    SP_HIP(hipMemcpy(g_tab.bits.ptr, h.data(), 504 * sizeof(aff_packed), hipMemcpyHostToDevice));
+    g_tab.bits_ready = true;
+  }
+  aff_packed shift, pad;
+  shift.x = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_X))));
+  shift.y = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_Y))));
+  pad = shift;
+  hipLaunchKernelGGL(pedersen_trace_kernel, dim3((unsigned)((n_hashes + 63) / 64)), dim3(64), 0, st, x, y,
+                     n_hashes, (const aff_packed*)g_tab.bits.ptr, shift, pad, cols);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
+                    const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream) {
+  SP_REQUIRE_READY();
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  const size_t n = (size_t)1 << log_n, M = 4 * n;
+  AirParams prm;
+  for (int k = 0; k < 11; ++k) {
+    u256 a;
+    std::memcpy(a.w, alphas_host + 4 * k, 32);
+    prm.alpha[k] = fe_to_mont(fe_unpack(a));
+  }
+  u256 sh;
+  std::memcpy(sh.w, shift_host, 32);
+  const fe shift_m = fe_to_mont(fe_unpack(sh));
+  // x^n on the coset = shift^n * w_4^(i mod 4)
+  fe sn = shift_m;
+  for (unsigned i = 0; i < log_n; ++i) sn = fe_sqr(sn);
+  const fe w4 = h_root_of_unity(2);
+  fe wk = FE_ONE_M;
+  for (int k = 0; k < 4; ++k) {
+    prm.zinv[k] = fe_inv(fe_carry(fe_sub(fe_mul(sn, wk), FE_ONE_M)));
+    wk = fe_mul(wk, w4);
+  }
+  prm.shift_x = fe_to_mont(fe_unpack(PT_SHIFT_X));
+  prm.shift_y = fe_to_mont(fe_unpack(PT_SHIFT_Y));
+  hipLaunchKernelGGL(air_eval_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     trace_lde, periodic_lde, M, prm, out);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uint64_t* beta_host,
+                    const uint64_t* shift_host, void* stream) {
+  SP_REQUIRE_READY();
+  if (log_m < 1 || log_m > 26) { set_error("bad layer size"); return SP_ERR_BAD_ARGUMENT; }
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t* tw;
+  int rc = get_twiddles((int)log_m, 1, &tw, st);
+  if (rc != SP_OK) return rc;
+  u256 b, s;
+  std::memcpy(b.w, beta_host, 32);
+  std::memcpy(s.w, shift_host, 32);
+  const fe two = fe_to_mont(fe{{2, 0, 0, 0, 0, 0, 0, 0, 0}});
+  const fe c1 = fe_inv(two);
+  const fe c2 = fe_mul(fe_to_mont(fe_unpack(b)), fe_inv(fe_mul(two, fe_to_mont(fe_unpack(s)))));
+  const size_t half = (size_t)1 << (log_m - 1);
+  hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, out,
+                     (int)log_m, tw, (int)log_m, c1, c2);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+}  // extern "C"

@@ -40,6 +40,15 @@ _SIGNATURES = {
     "sp_merkle_sparse_root": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                              ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p]),
+    "sp_ntt_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p]),
+    "sp_lde_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint,
+                                  ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_pedersen_trace_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                             ctypes.c_void_p]),
+    "sp_air_eval_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_fri_fold_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p]),
     "sp_ecdsa_verify_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
     "sp_ecdsa_verify_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
     "sp_ecdsa_sign_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),

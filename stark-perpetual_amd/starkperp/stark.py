@@ -1,0 +1,161 @@
+"""Prover-side pipeline on device-resident columns: trace -> coset LDE -> commit -> AIR composition
+-> commit -> FRI folds with per-layer commits.  Build-defined (the reference has no prover); every
+commitment hash is the reference's pedersen_hash.  Columns live in HBM as torch int64 [n, 4]
+tensors (four little-endian 64-bit limbs per felt); torch is only the allocator / stream owner."""
+from . import _lib
+from ._lib import pack_felts
+
+FIELD_PRIME = 2**251 + 17 * 2**192 + 1
+FIELD_GEN = 3
+BLOWUP_LOG = 2
+N_CONSTRAINTS = 11
+SHIFT_POINT = (
+    0x49EE3EBA8C1600700EE1B87EB599F16716B0B1022947733551FDE4050CA6804,
+    0x3CA0CFE4B3BC6DDF346D49D06EA0ED34E621062C0E056C1D0405D266E10268A,
+)
+EC_GEN = (
+    0x1EF15C18599971B7BECED415A40F0C7DEACFD9B0D1819E03D723D8BC943CFCA,
+    0x5668060AA49730B7BE4801DF46EC62DE53ECD11ABE43A32873000C36E8DC1F,
+)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def felts_to_tensor(values, device="cuda"):
+    torch = _torch()
+    import numpy as np
+    raw = b"".join(int(v).to_bytes(32, "little") for v in values)
+    arr = np.frombuffer(raw, dtype="<i8").reshape(len(values), 4).copy()
+    return torch.from_numpy(arr).to(device)
+
+
+def tensor_to_felts(t):
+    raw = t.detach().cpu().contiguous().numpy().astype("<i8").tobytes()
+    return [int.from_bytes(raw[32 * i : 32 * i + 32], "little") for i in range(len(raw) // 32)]
+
+
+def _stream():
+    return _torch().cuda.current_stream().cuda_stream
+
+
+def ntt(col, inverse=False):
+    """Natural-order NTT of a [n, 4] column (n a power of two)."""
+    torch = _torch()
+    lib = _lib.ensure_init()
+    n = col.shape[0]
+    out = torch.empty_like(col)
+    _lib.check(lib.sp_ntt_dev(col.data_ptr(), out.data_ptr(), n.bit_length() - 1, 1 if inverse else 0,
+                              _stream()), "sp_ntt_dev")
+    return out
+
+
+def lde(cols, blowup_log=BLOWUP_LOG, shift=FIELD_GEN):
+    """cols: [ncols, n, 4] -> [ncols, n << blowup_log, 4] on the coset shift * <w>."""
+    torch = _torch()
+    lib = _lib.ensure_init()
+    ncols, n = cols.shape[0], cols.shape[1]
+    out = torch.empty((ncols, n << blowup_log, 4), dtype=torch.int64, device=cols.device)
+    _lib.check(lib.sp_lde_dev(cols.data_ptr(), out.data_ptr(), ncols, n.bit_length() - 1, blowup_log,
+                              pack_felts([shift]), _stream()), "sp_lde_dev")
+    return out
+
+
+def pedersen_trace(xs, ys):
+    """xs, ys: [m, 4] device tensors of hash inputs -> [4, 512 m, 4] trace (s, px, py, lambda)."""
+    torch = _torch()
+    lib = _lib.ensure_init()
+    m = xs.shape[0]
+    cols = torch.empty((4, 512 * m, 4), dtype=torch.int64, device=xs.device)
+    _lib.check(lib.sp_pedersen_trace_dev(xs.data_ptr(), ys.data_ptr(), m, cols.data_ptr(), _stream()),
+               "sp_pedersen_trace_dev")
+    return cols
+
+
+def periodic_columns():
+    """The six period-512 columns of the AIR (constant points and selectors) as Python ints; the
+    per-bit constant points come from starkperp.signature.CONSTANT_POINTS."""
+    from .signature import CONSTANT_POINTS
+    cx, cy, step, mid, end, z252 = [], [], [], [], [], []
+    for r in range(512):
+        block, j = divmod(r, 256)
+        c = CONSTANT_POINTS[2 + 252 * block + j] if j < 252 else EC_GEN
+        cx.append(c[0])
+        cy.append(c[1])
+        step.append(0 if j == 255 else 1)
+        mid.append(1 if r == 255 else 0)
+        end.append(1 if r == 511 else 0)
+        z252.append(1 if j == 252 else 0)
+    return [cx, cy, step, mid, end, z252]
+
+
+def periodic_lde(n, shift=FIELD_GEN, device="cuda"):
+    """[6, 2048, 4]: the periodic columns on the LDE coset (values repeat with period 4 * 512)."""
+    torch = _torch()
+    cols = torch.stack([felts_to_tensor(c, device) for c in periodic_columns()])
+    return lde(cols, BLOWUP_LOG, pow(shift, n // 512, FIELD_PRIME))
+
+
+def air_eval(trace_lde, per_lde, n, alphas, shift=FIELD_GEN):
+    torch = _torch()
+    lib = _lib.ensure_init()
+    assert len(alphas) == N_CONSTRAINTS and trace_lde.shape[1] == 4 * n
+    out = torch.empty((4 * n, 4), dtype=torch.int64, device=trace_lde.device)
+    _lib.check(lib.sp_air_eval_dev(trace_lde.data_ptr(), per_lde.data_ptr(), n.bit_length() - 1,
+                                   pack_felts(alphas), pack_felts([shift]), out.data_ptr(), _stream()),
+               "sp_air_eval_dev")
+    return out
+
+
+def fri_fold(layer, beta, shift):
+    torch = _torch()
+    lib = _lib.ensure_init()
+    m = layer.shape[0]
+    out = torch.empty((m // 2, 4), dtype=torch.int64, device=layer.device)
+    _lib.check(lib.sp_fri_fold_dev(layer.data_ptr(), out.data_ptr(), m.bit_length() - 1,
+                                   pack_felts([beta]), pack_felts([shift]), _stream()),
+               "sp_fri_fold_dev")
+    return out
+
+
+def commit_rows(cols):
+    """Pedersen-Merkle root over rows of `cols` [ncols, n, 4]: leaf = left-fold hash of the row
+    (a single column commits the felts themselves).  Returns (root_int, levels tensor)."""
+    torch = _torch()
+    lib = _lib.ensure_init()
+    ncols, n = cols.shape[0], cols.shape[1]
+    levels = torch.empty((2 * n - 1, 4), dtype=torch.int64, device=cols.device)
+    if ncols == 1:
+        levels[:n] = cols[0]
+    else:
+        _lib.check(lib.sp_pedersen_chains_dev(cols.data_ptr(), n, ncols, levels.data_ptr(), None, _stream()),
+                   "sp_pedersen_chains_dev")
+    _lib.check(lib.sp_merkle_build_dev(levels.data_ptr(), n.bit_length() - 1, None, _stream()),
+               "sp_merkle_build_dev")
+    return levels
+
+
+def root_of(levels):
+    return tensor_to_felts(levels[-1:])[0]
+
+
+def prove_commitments(xs, ys, alphas, betas, final_log=6, shift=FIELD_GEN):
+    """The AIR+FRI commit job of BASELINE.json configs[3]: returns the list of commitment roots
+    [trace, composition, fri_1, ..., fri_k] and the final FRI layer (Python ints)."""
+    n = 512 * xs.shape[0]
+    trace = pedersen_trace(xs, ys)
+    trace_lde = lde(trace)
+    roots = [commit_rows(trace_lde)]
+    per = periodic_lde(n, shift, xs.device)
+    comp = air_eval(trace_lde, per, n, alphas, shift)
+    roots.append(commit_rows(comp.unsqueeze(0)))
+    layer, s, k = comp, shift, 0
+    while layer.shape[0] > (1 << final_log):
+        layer = fri_fold(layer, betas[k], s)
+        s = s * s % FIELD_PRIME
+        k += 1
+        if layer.shape[0] > (1 << final_log):
+            roots.append(commit_rows(layer.unsqueeze(0)))
+    return [root_of(r) for r in roots], tensor_to_felts(layer)

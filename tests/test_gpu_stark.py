@@ -1,0 +1,140 @@
+"""GPU parity of the prover-side kernels (NTT / LDE / AIR / FRI / commit) against
+oracle/stark_ref.py at oracle-sized inputs, plus size-independent properties at 2^20.
+The reference has no prover: "parity unpinned" (see the oracle header)."""
+import random
+
+import pytest
+
+from oracle import ref_py as R
+from oracle import stark_ref as S
+
+pytestmark = pytest.mark.gpu
+P = S.P
+
+
+@pytest.fixture(scope="module")
+def stark():
+    from starkperp import stark as st
+    return st
+
+
+def test_ntt_matches_oracle(stark):
+    rng = random.Random(1)
+    for log_n in (0, 1, 2, 5, 10, 11, 12, 13):
+        n = 1 << log_n
+        c = [rng.randrange(P) for _ in range(n)]
+        w = S.root_of_unity(log_n)
+        t = stark.felts_to_tensor(c)
+        assert stark.tensor_to_felts(stark.ntt(t)) == S.ntt(c, w), log_n
+        assert stark.tensor_to_felts(stark.ntt(stark.ntt(t), inverse=True)) == c
+
+
+def test_ntt_roundtrip_and_linearity_large(stark):
+    import torch
+    rng = random.Random(2)
+    log_n = 21
+    n = 1 << log_n
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, generator=g)
+    a[:, 3] &= (1 << 58) - 1
+    a = a.cuda()
+    fa = stark.ntt(a)
+    assert torch.equal(stark.ntt(fa, inverse=True), a)
+    # spot values against the definition: f(w^i) for a sparse polynomial
+    coeffs = {0: 5, 1: 7, 12345: 11, n - 1: 13}
+    dense = [0] * n
+    for k, v in coeffs.items():
+        dense[k] = v
+    ev = stark.tensor_to_felts(stark.ntt(stark.felts_to_tensor(dense)))
+    w = S.root_of_unity(log_n)
+    for i in (0, 1, 2, 777, n // 2, n - 1):
+        x = pow(w, i, P)
+        assert ev[i] == sum(v * pow(x, k, P) for k, v in coeffs.items()) % P
+
+
+def test_lde_matches_oracle(stark):
+    import torch
+    rng = random.Random(3)
+    for log_n in (4, 9, 11):
+        n = 1 << log_n
+        cols = [[rng.randrange(P) for _ in range(n)] for _ in range(2)]
+        t = torch.stack([stark.felts_to_tensor(c) for c in cols])
+        got = stark.lde(t)
+        for c, g in zip(cols, got):
+            assert stark.tensor_to_felts(g) == S.lde(c), log_n
+
+
+def test_trace_air_fri_match_oracle(stark):
+    import torch
+    rng = random.Random(4)
+    inputs = [(rng.randrange(P), rng.randrange(P)) for _ in range(2)]
+    xs = stark.felts_to_tensor([a for a, _ in inputs])
+    ys = stark.felts_to_tensor([b for _, b in inputs])
+    n = 1024
+    trace = stark.pedersen_trace(xs, ys)
+    exp_cols = S.pedersen_trace(inputs)
+    for g, e in zip(trace, exp_cols):
+        assert stark.tensor_to_felts(g) == e
+    assert exp_cols[1][511] == R.pedersen_hash(*inputs[0])
+    trace_lde = stark.lde(trace)
+    per = stark.periodic_lde(n)
+    exp_per = S.periodic_lde(n)
+    for g, e in zip(per, exp_per):
+        assert stark.tensor_to_felts(g) == e
+    alphas = [rng.randrange(P) for _ in range(S.N_CONSTRAINTS)]
+    comp = stark.air_eval(trace_lde, per, n, alphas)
+    exp_comp = S.composition_on_coset([S.lde(c) for c in exp_cols], exp_per, n, alphas)
+    assert stark.tensor_to_felts(comp) == exp_comp
+    assert S.poly_degree_bound_check(exp_comp, S.GEN, 3 * n - 1)
+    layer, exp_layer, shift = comp, exp_comp, S.GEN
+    while layer.shape[0] > 64:
+        beta = rng.randrange(P)
+        layer = stark.fri_fold(layer, beta, shift)
+        exp_layer = S.fri_fold(exp_layer, beta, shift)
+        shift = shift * shift % P
+        assert stark.tensor_to_felts(layer) == exp_layer
+
+
+def test_commit_rows_matches_oracle(stark):
+    import torch
+    rng = random.Random(6)
+    cols = [[rng.randrange(P) for _ in range(16)] for _ in range(4)]
+    t = torch.stack([stark.felts_to_tensor(c) for c in cols])
+    assert stark.root_of(stark.commit_rows(t)) == S.commit_rows(cols)
+    assert stark.root_of(stark.commit_rows(t[:1])) == S.commit_rows(cols[:1])
+
+
+def test_full_size_pipeline_properties(stark):
+    """2^20-row job: the composition of a valid trace folds down to a low-degree final layer; a
+    corrupted trace does not."""
+    import torch
+    m = 2048
+    g = torch.Generator().manual_seed(9)
+    xs = torch.randint(0, 2**62, (m, 4), dtype=torch.int64, generator=g)
+    ys = torch.randint(0, 2**62, (m, 4), dtype=torch.int64, generator=g)
+    xs[:, 3] &= (1 << 58) - 1
+    ys[:, 3] &= (1 << 58) - 1
+    xs, ys = xs.cuda(), ys.cuda()
+    rng = random.Random(10)
+    alphas = [rng.randrange(P) for _ in range(S.N_CONSTRAINTS)]
+    betas = [rng.randrange(P) for _ in range(16)]
+    roots, final = stark.prove_commitments(xs, ys, alphas, betas)
+    assert len(roots) == 2 + 15 and len(final) == 64
+    shift = S.GEN
+    for _ in range(16):
+        shift = shift * shift % P
+    assert S.poly_degree_bound_check(final, shift, 47)
+    # the trace commits to real hashes: row 511 of px is H(x0, y0)
+    n = 512 * m
+    trace = stark.pedersen_trace(xs, ys)
+    x0, y0 = stark.tensor_to_felts(xs[:1])[0], stark.tensor_to_felts(ys[:1])[0]
+    assert stark.tensor_to_felts(trace[1][511:512])[0] == R.pedersen_hash(x0, y0)
+    # corrupt one cell -> the final layer is no longer low degree
+    trace[2][12345][0] += 1
+    trace_lde = stark.lde(trace)
+    comp = stark.air_eval(trace_lde, stark.periodic_lde(n), n, alphas)
+    layer, s = comp, S.GEN
+    for k in range(16):
+        layer = stark.fri_fold(layer, betas[k], s)
+        s = s * s % P
+    assert not S.poly_degree_bound_check(stark.tensor_to_felts(layer), s, 47)

@@ -1,0 +1,95 @@
+"""Algebraic self-checks of the prover-side oracle (oracle/stark_ref.py).  The reference has no
+prover, so these replace golden vectors for rows A10-A13 ("parity unpinned")."""
+import random
+
+from oracle import ref_py as R
+from oracle import stark_ref as S
+
+P = S.P
+
+
+def test_roots_of_unity():
+    w = S.root_of_unity(20)
+    assert w == 0x0594BEAFCA8A00D9581D81CAEE93DC85C727C9AF7FC4C648E3D47B998574E81F  # SURVEY appx B
+    assert pow(w, 1 << 20, P) == 1 and pow(w, 1 << 19, P) == P - 1
+
+
+def test_ntt_matches_naive_and_inverts():
+    rng = random.Random(1)
+    for log_n in (0, 1, 3, 6):
+        n = 1 << log_n
+        c = [rng.randrange(P) for _ in range(n)]
+        w = S.root_of_unity(log_n)
+        ev = S.ntt(c, w)
+        assert ev == S.naive_dft(c, w)
+        assert S.intt(ev, w) == c
+
+
+def test_lde_agrees_with_polynomial():
+    rng = random.Random(2)
+    n = 16
+    coeffs = [rng.randrange(P) for _ in range(n)]
+    evals = S.ntt(coeffs, S.root_of_unity(4))
+    ext = S.lde(evals)
+    w = S.root_of_unity(6)
+    for i in (0, 1, 17, 63):
+        x = S.GEN * pow(w, i, P) % P
+        assert ext[i] == sum(c * pow(x, k, P) for k, c in enumerate(coeffs)) % P
+
+
+def test_trace_satisfies_constraints_and_composition_is_low_degree():
+    rng = random.Random(3)
+    inputs = [(rng.randrange(P), rng.randrange(P))]
+    cols = S.pedersen_trace(inputs)
+    n = len(cols[0])
+    assert n == 512
+    # last accumulator row carries the hash
+    assert cols[1][511] == R.pedersen_hash(*inputs[0])
+    per = S.periodic_columns()
+    for i in range(n):
+        cur = [c[i] for c in cols]
+        nxt = [c[(i + 1) % n] for c in cols]
+        assert all(v == 0 for v in S.constraint_values(cur, nxt, [t[i] for t in per])), i
+    trace_lde = [S.lde(c) for c in cols]
+    per_lde = S.periodic_lde(n)
+    alphas = [rng.randrange(P) for _ in range(S.N_CONSTRAINTS)]
+    comp = S.composition_on_coset(trace_lde, per_lde, n, alphas)
+    assert S.poly_degree_bound_check(comp, S.GEN, 3 * n - 1)
+    # a corrupted trace does not give a low-degree quotient
+    bad = [list(c) for c in cols]
+    bad[1][100] = (bad[1][100] + 1) % P
+    comp_bad = S.composition_on_coset([S.lde(c) for c in bad], per_lde, n, alphas)
+    assert not S.poly_degree_bound_check(comp_bad, S.GEN, 3 * n - 1)
+    # FRI: folding halves the degree bound; fold equals direct evaluation of the folded polynomial
+    layer, shift, bound = comp, S.GEN, 3 * n
+    while len(layer) > 64:
+        beta = rng.randrange(P)
+        layer = S.fri_fold(layer, beta, shift)
+        shift = shift * shift % P
+        bound //= 2
+        assert S.poly_degree_bound_check(layer, shift, bound - 1)
+    assert len(layer) == 64 and bound == 48
+
+
+def test_fold_matches_even_odd_split():
+    rng = random.Random(4)
+    m = 32
+    coeffs = [rng.randrange(P) for _ in range(m)]
+    shift = 5
+    w = S.root_of_unity(5)
+    vals = [sum(c * pow(shift * pow(w, i, P) % P, k, P) for k, c in enumerate(coeffs)) % P
+            for i in range(m)]
+    beta = rng.randrange(P)
+    folded = S.fri_fold(vals, beta, shift)
+    g = [(coeffs[2 * k] + beta * coeffs[2 * k + 1]) % P for k in range(m // 2)]
+    w2 = w * w % P
+    for i in range(m // 2):
+        y = shift * shift * pow(w2, i, P) % P
+        assert folded[i] == sum(c * pow(y, k, P) for k, c in enumerate(g)) % P
+
+
+def test_commit_rows_small():
+    cols = [[1, 2, 3, 4], [5, 6, 7, 8]]
+    leaves = [R.pedersen_hash(a, b) for a, b in zip(*cols)]
+    assert S.commit_rows(cols) == R.merkle_root(leaves)
+    assert S.commit_rows([[1, 2, 3, 4]]) == R.merkle_root([1, 2, 3, 4])
