@@ -231,6 +231,49 @@ def extras(torch, lib, _lib, dev, stream):
                                                            n, stream), "ped"), 3)
     out["bulk_pedersen_hashes_per_sec"] = n / s
     out["bulk_pedersen_batch"] = n
+    del x, y, o
+
+    # BASELINE.json configs[3]: 2^20-row trace -> LDE -> commit -> AIR -> commit -> FRI (+commits)
+    import random
+    from starkperp import stark
+    m = 2048
+    xs, ys = seeded_felts(torch, m, 11, dev), seeded_felts(torch, m, 12, dev)
+    rng = random.Random(13)
+    P = stark.FIELD_PRIME
+    alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
+    betas = [rng.randrange(P) for _ in range(16)]
+    trace = stark.pedersen_trace(xs, ys)          # witness generation, outside the timed job
+    per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
+    torch.cuda.synchronize()
+
+    def job():
+        t_lde = stark.lde(trace)
+        stark.commit_rows(t_lde)
+        comp = stark.air_eval(t_lde, per, 512 * m, alphas)
+        stark.commit_rows(comp.unsqueeze(0))
+        layer, sh, k = comp, stark.FIELD_GEN, 0
+        while layer.shape[0] > 64:
+            layer = stark.fri_fold(layer, betas[k], sh)
+            sh = sh * sh % P
+            k += 1
+            if layer.shape[0] > 64:
+                stark.commit_rows(layer.unsqueeze(0))
+
+    s = timed(job, 2)
+    out["air_fri_commit_seconds_2p20_rows"] = s
+    out["air_fri_commits_per_sec"] = 1.0 / s
+
+    def phase(fn):
+        return timed(fn, 2)
+
+    t_lde = stark.lde(trace)
+    out["phase_seconds"] = {
+        "lde_4cols_2p20_to_2p22": phase(lambda: stark.lde(trace)),
+        "commit_trace_lde_4cols_2p22_rows": phase(lambda: stark.commit_rows(t_lde)),
+        "air_eval_2p22_points": phase(lambda: stark.air_eval(t_lde, per, 512 * m, alphas)),
+        "fri_fold_first_layer_2p22": phase(
+            lambda: stark.fri_fold(t_lde[0], betas[0], stark.FIELD_GEN)),
+    }
     return out
 
 

@@ -98,13 +98,16 @@ __device__ __forceinline__ aff ld_aff(const aff_packed* e) {
 }
 // plain integer a < 2^256 compared with p / N / 2^251 on packed words
 __host__ __device__ __forceinline__ bool u256_lt(const u256& a, const u256& b) {
-  for (int i = 7; i >= 0; --i) {
-    if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
+  bool lt = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (a.w[i] != b.w[i]) lt = a.w[i] < b.w[i];  // highest differing word decides
   }
-  return false;
+  return lt;
 }
 __host__ __device__ __forceinline__ bool u256_is_zero(const u256& a) {
   uint32_t o = 0;
+#pragma unroll
   for (int i = 0; i < 8; ++i) o |= a.w[i];
   return o == 0;
 }

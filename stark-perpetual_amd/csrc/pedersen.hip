@@ -14,6 +14,7 @@
 //                                      64 lanes touch 64 consecutive dwords
 // Algorithmic bytes per hash: 96 (two felts in, one out).  The kernel is VALU bound
 // (~3.3e3 v_mad_i64_i32 per window addition), not HBM bound - see DESIGN.md.
+#include <cstdlib>
 #include <vector>
 
 #include "context.hpp"
@@ -105,6 +106,79 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
   }
 }
 
+// Kernel A', latency variant for small batches (upper tree levels, short chains): 2^LOG_L lanes
+// share one hash.  Each lane sums its contiguous block of 2*nwin / L table entries (mmadd, then
+// madd), the partial sums are combined with log2(L) butterfly rounds of wave shuffles + general
+// XYZZ additions.  Latency drops from 31 dependent mixed additions (~300 field mul) to ~65 at
+// L = 8, at the price of ~1.7x more total work - used only while the batch cannot fill the chip.
+__device__ __forceinline__ fe shfl_xor_fe(const fe& v, int mask) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = __shfl_xor(v.l[i], mask, 64);
+  return r;
+}
+__device__ __forceinline__ uint32_t window_from_memory(const uint64_t* felt, int win, int wbits) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(felt);
+  const int bit = win * wbits, wi = bit >> 5, sh = bit & 31;
+  uint64_t two = (uint64_t)w[wi];
+  if (wi + 1 < 8) two |= (uint64_t)w[wi + 1] << 32;
+  return (uint32_t)(two >> sh) & ((1u << wbits) - 1u);
+}
+
+template <int LOG_L>
+__global__ void __launch_bounds__(256)
+ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
+                            size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits,
+                            int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
+                            uint8_t* __restrict__ status, unsigned* __restrict__ flag) {
+  constexpr int L = 1 << LOG_L;
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e_raw = gt >> LOG_L;
+  const int sub = (int)(gt & (L - 1));
+  const bool active = e_raw < n;
+  const size_t e = active ? e_raw : n - 1;  // clamp: whole lane groups stay convergent for the shuffles
+  const int total = 2 * nwin;
+  const int cnt = total / L;  // host guarantees divisibility and cnt >= 2
+  const size_t per = (size_t)1 << wbits;
+  const uint64_t* fx = x + 4 * e * xstride;
+  const uint64_t* fy = y + 4 * e * ystride;
+  auto entry = [&](int g) {
+    const uint64_t* f = g < nwin ? fx : fy;
+    const int win = g < nwin ? g : g - nwin;
+    return ped + (size_t)g * per + window_from_memory(f, win, wbits);
+  };
+  const int g0 = sub * cnt;
+  const aff q0 = ld_aff(entry(g0));
+  raw_aff nxt = ld_raw(entry(g0 + 1));
+  xyzz acc;
+  {
+    const aff q1 = unpack_raw(nxt);
+    if (cnt > 2) nxt = ld_raw(entry(g0 + 2));
+    acc = xyzz_mmadd(q0, q1);
+  }
+  for (int j = 2; j < cnt; ++j) {
+    const aff q = unpack_raw(nxt);
+    if (j + 1 < cnt) nxt = ld_raw(entry(g0 + j + 1));
+    acc = xyzz_madd(acc, q);
+  }
+#pragma unroll
+  for (int r = 0; r < LOG_L; ++r) {
+    xyzz o;
+    o.X = shfl_xor_fe(acc.X, 1 << r);
+    o.Y = shfl_xor_fe(acc.Y, 1 << r);
+    o.ZZ = shfl_xor_fe(acc.ZZ, 1 << r);
+    o.ZZZ = shfl_xor_fe(acc.ZZZ, 1 << r);
+    acc = xyzz_add(acc, o);
+  }
+  if (!active || sub != 0) return;
+  uint8_t st = SP_HASH_OK;
+  if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
+  store_limbs(sX, n, e, acc.X);
+  store_limbs(sZZ, n, e, acc.ZZ);
+  if (status) status[e] = st;
+  if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
+}
+
 // Kernel B: thread t owns elements t, t+T, t+2T, ...; one inversion per thread.
 __global__ void __launch_bounds__(256)
 ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int32_t* __restrict__ sPre,
@@ -175,6 +249,7 @@ struct KernelProfile {
   size_t used = 0;
 };
 static KernelProfile g_prof;
+static bool g_split_enabled = getenv("STARKPERP_NO_SPLIT") == nullptr;  // A/B switch
 
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
@@ -212,8 +287,29 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
   const unsigned blocksA = (unsigned)((n + 255) / 256);
   const bool prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size();
   if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
-  hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped,
-                     c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+  // lanes per hash: fill ~2 waves per SIMD (131072 lanes) before falling back to one lane per hash
+  int log_l = 0;
+  if (g_split_enabled) {
+    if (n <= 16384) log_l = 3;
+    else if (n <= 32768) log_l = 2;
+    else if (n <= 65536) log_l = 1;
+    while (log_l > 0 && ((2 * c.nwin) % (1 << log_l) != 0 || (2 * c.nwin) >> log_l < 2)) --log_l;
+  }
+  if (log_l == 0) {
+    hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped,
+                       c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+  } else {
+    const unsigned blocks = (unsigned)(((n << log_l) + 255) / 256);
+    if (log_l == 3)
+      hipLaunchKernelGGL(ped_accumulate_split_kernel<3>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
+                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+    else if (log_l == 2)
+      hipLaunchKernelGGL(ped_accumulate_split_kernel<2>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
+                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+    else
+      hipLaunchKernelGGL(ped_accumulate_split_kernel<1>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
+                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+  }
   if (prof) {
     (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
     g_prof.units.push_back(n);

@@ -85,6 +85,25 @@ def test_fe_mul_sqr_inv(shim):
         assert shim.t_fe_is_qr(W(a)) == (1 if pow(a, (P - 1) // 2, P) == 1 else 0)
 
 
+def test_fe_inv_gcd(shim):
+    rng = random.Random(7)
+    out = (ctypes.c_uint32 * 8)()
+    Rm = 2**261
+    import re
+    hdr = open(os.path.join(HERE, "..", "stark-perpetual_amd", "csrc", "fp29.hpp")).read()
+    m = re.search(r"FE_R3 = \{\{([^}]*)\}\}", hdr)
+    assert [int(x, 16) for x in m.group(1).replace("\n", " ").split(",")] == [
+        (pow(Rm, 3, P) >> (29 * i)) & (2**29 - 1) for i in range(9)]
+    vals = [1, 2, 3, P - 1, P - 2, 2**251, 2**192 + 1, (P + 1) // 2] + [rng.randrange(1, P) for _ in range(400)]
+    for a in vals:
+        shim.t_fe_inv_plain_gcd(W(a), out)
+        assert I(out) == pow(a, -1, P), hex(a)
+        shim.t_fe_inv_gcd(W(a), out)
+        assert I(out) == pow(a, -1, P), hex(a)
+    shim.t_fe_inv_plain_gcd(W(0), out)
+    assert I(out) == 0
+
+
 def test_fe_lazy_expr(shim):
     rng = random.Random(3)
     out = (ctypes.c_uint32 * 8)()
@@ -103,9 +122,14 @@ def test_fn(shim):
         b = rng.choice(vals)
         shim.t_fn_mul(W(a), W(b), out)
         assert I(out) == a * b % N
-    for a in vals[1:30]:
+    for a in vals[1:]:
         shim.t_fn_inv(W(a), out)
         assert I(out) == pow(a, -1, N)
+    for a in vals[1:12]:
+        shim.t_fn_inv_fermat(W(a), out)
+        assert I(out) == pow(a, -1, N)
+        shim.t_fe_inv_fermat(W(a), out)
+        assert I(out) == pow(a, -1, P)
 
 
 def rand_point(rng):
