@@ -143,7 +143,7 @@ static int init_locked(int device, int window_bits) {
     set_error("device index out of range");
     return SP_ERR_BAD_ARGUMENT;
   }
-  if (window_bits == 0) window_bits = 16;
+  if (window_bits == 0) window_bits = 21;  // 12 windows of 21 bits cover the 252-bit scalars exactly
   if (window_bits < 4 || window_bits > 26) {
     set_error("window_bits must be in [4, 26]");
     return SP_ERR_BAD_ARGUMENT;

@@ -85,7 +85,8 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
   xyzz acc = xyzz_from_aff(unpack_raw(ld_raw(tab + v)));
   tab += per;
   const int total = 2 * nwin;
-  v = pop_window(nwin > 1 ? sx : sy, wbits);
+  if (nwin > 1) v = pop_window(sx, wbits);
+  else v = pop_window(sy, wbits);
   raw_aff nxt = ld_raw(tab + v);
   for (int i = 1; i < total; ++i) {
     const aff q = unpack_raw(nxt);
