@@ -24,6 +24,10 @@ import os
 import sys
 import time
 
+# 16 independent trees are kept in flight on 16 HIP streams; the runtime default of 4 hardware
+# queues would serialise them (measured: 4 queues 1.2e8, 16 queues 1.9e8 hashes/s, 32 worse).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "stark-perpetual_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -77,11 +81,29 @@ def cpu_baseline(leaf_ints, budget_s=12.0):
     }, flat
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py: separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE runs of this bench, FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return json.load(open(path))["accumulate_kernels"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=16,
+                    help="HIP streams the K steps are issued on round-robin (independent trees "
+                         "overlap: the upper levels of one rebuild are latency-bound and leave most "
+                         "of the chip idle); 1 = strictly one tree at a time")
+    ap.add_argument("--no-graphs", dest="graphs", action="store_false",
+                    help="issue every launch eagerly instead of replaying one hipGraph per tree")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -109,16 +131,54 @@ def main():
 
     lib = _lib.ensure_init(local_rank)
     n_leaves = 1 << HEIGHT
-    levels = torch.zeros((2 * n_leaves - 1, 4), dtype=torch.int64, device=dev)
-    levels[:n_leaves] = seeded_felts(torch, n_leaves, 1000 + rank, dev)
-    gathered = torch.zeros((max(world, 1), 4), dtype=torch.int64, device=dev)
-    top = torch.zeros((2 * max(world, 1) - 1, 4), dtype=torch.int64, device=dev)
+    n_streams = max(1, args.streams)
+    leaves = seeded_felts(torch, n_leaves, 1000 + rank, dev)
+    slots = []
+    for si in range(n_streams):
+        lv = torch.zeros((2 * n_leaves - 1, 4), dtype=torch.int64, device=dev)
+        lv[:n_leaves] = leaves
+        slots.append({
+            "levels": lv,
+            "gathered": torch.zeros((max(world, 1), 4), dtype=torch.int64, device=dev),
+            "top": torch.zeros((2 * max(world, 1) - 1, 4), dtype=torch.int64, device=dev),
+            "stream": torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream(device=dev),
+        })
+    levels = slots[0]["levels"]
     stream = torch.cuda.current_stream().cuda_stream
+    step_counter = [0]
+
+    def run_slot(sl):
+        h = sl["stream"].cuda_stream
+        _lib.check(lib.sp_merkle_build_dev(sl["levels"].data_ptr(), HEIGHT, None, h), "merkle")
+        if world > 1:
+            combine_subroots_dev(lib, dist, sl["levels"][-1], sl["gathered"], sl["top"], h)
+
+    # The ~35 launches of one rebuild are captured once per slot into a hipGraph and replayed:
+    # with several trees in flight the eager path is host-launch bound (~0.6 ms of API calls per tree).
+    use_graphs = args.graphs and world == 1 and n_streams > 1
+    if use_graphs:
+        for sl in slots:  # size scratch / twiddles before capture (no allocation inside a capture)
+            with torch.cuda.stream(sl["stream"]):
+                run_slot(sl)
+        torch.cuda.synchronize()
+
+    def capture_graphs():
+        for sl in slots:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=sl["stream"]):
+                run_slot(sl)
+            sl["graph"] = g
 
     def step():
-        _lib.check(lib.sp_merkle_build_dev(levels.data_ptr(), HEIGHT, None, stream), "merkle")
-        if world > 1:
-            combine_subroots_dev(lib, dist, levels[-1], gathered, top, stream)
+        nonlocal use_graphs
+        sl = slots[step_counter[0] % n_streams]
+        step_counter[0] += 1
+        if use_graphs:
+            with torch.cuda.stream(sl["stream"]):
+                sl["graph"].replay()
+            return
+        with torch.cuda.stream(sl["stream"]):
+            run_slot(sl)
 
     def fence():
         torch.cuda.synchronize()
@@ -126,16 +186,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    launches_per_step = HEIGHT + 8
+    if use_graphs:
+        capture_graphs()
     for _ in range(args.warmup):
         step()
     fence()
-    launches_per_step = HEIGHT + 8
-    _lib.check(lib.sp_profile_begin(args.steps * launches_per_step), "profile_begin")
+    if not use_graphs:
+        _lib.check(lib.sp_profile_begin(args.steps * launches_per_step), "profile_begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if use_graphs:
+        # HIP events captured into a graph cannot be read back (hipEventElapsedTime: invalid
+        # resource handle), so the dominant kernel is timed by re-issuing the same K steps eagerly
+        # on the same streams right after the timed region - same kernels, same overlap pattern.
+        use_graphs = False
+        _lib.check(lib.sp_profile_begin(args.steps * launches_per_step), "profile_begin")
+        for _ in range(args.steps):
+            step()
+        fence()
+        use_graphs = True
     k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
     _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)),
                "profile_end")
@@ -169,21 +242,26 @@ def main():
                 "tree_height": HEIGHT,
                 "leaves_per_gpu": n_leaves,
                 "hashes_per_step": hashes_per_step,
+                "streams": n_streams,
+                "hip_graphs": bool(use_graphs),
                 "window_bits": int(lib.sp_window_bits()),
                 "table_mib": lib.sp_table_bytes() / 2**20,
                 "combine": "none" if world == 1 else "all_gather of %d sub-roots (RCCL) + %d top hashes" % (
                     world, world - 1),
             },
             "roofline": {
-                "kernel": "ped_accumulate_kernel",
+                "kernel": "ped_accumulate_kernel / ped_accumulate_split_kernel<L> (the window-table summation)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic_per_launch(),
                 "launches": int(k_launches.value),
                 "avg_launch_us": avg_launch_s * 1e6,
+                "timing": ("HIP events around every launch, eager re-issue of the same K steps after the "
+                           "graph-replayed timed region") if use_graphs else
+                          "HIP events around every launch inside the timed region",
                 "note": "integer-ALU bound kernel (DESIGN.md): ~2.9e3 v_mad_i64_i32 per window add; "
                         "HBM fraction is reported because the contract asks for it",
             },
@@ -191,9 +269,10 @@ def main():
         if world == 1 and not args.no_extras:
             result["extra"] = extras(torch, lib, _lib, dev, stream)
         if world == 1 and not args.no_cpu_baseline:
+            n_sample = 1 << HEIGHT  # up to the whole first level (32768 hashes), bounded by budget_s
             leaf_ints = _lib.unpack_felts(
-                (ctypes.c_uint64 * (4 * 8192)).from_buffer_copy(
-                    levels[:8192].cpu().numpy().astype("<i8").tobytes()), 8192)
+                (ctypes.c_uint64 * (4 * n_sample)).from_buffer_copy(
+                    levels[:n_sample].cpu().numpy().astype("<i8").tobytes()), n_sample)
             base, cpu_out = cpu_baseline(leaf_ints)
             # the sample doubles as one more parity check of the timed tree
             gpu_l1 = _lib.unpack_felts(
@@ -223,6 +302,12 @@ def extras(torch, lib, _lib, dev, stream):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters / 1e3
+
+    lv = torch.zeros((2 * (1 << HEIGHT) - 1, 4), dtype=torch.int64, device=dev)
+    lv[: 1 << HEIGHT] = seeded_felts(torch, 1 << HEIGHT, 5, dev)
+    s1 = timed(lambda: _lib.check(lib.sp_merkle_build_dev(lv.data_ptr(), HEIGHT, None, stream), "merkle"), 10)
+    out["single_tree_rebuild_ms_one_stream"] = s1 * 1e3
+    out["single_tree_hashes_per_sec_one_stream"] = ((1 << HEIGHT) - 1) / s1
 
     n = 1 << 22
     x, y = seeded_felts(torch, n, 7, dev), seeded_felts(torch, n, 8, dev)

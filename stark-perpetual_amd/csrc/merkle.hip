@@ -21,7 +21,7 @@ struct Scratch {
 int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
                      size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
                      const Scratch& s);
-int get_scratch_public(size_t n, Scratch& s);
+int get_scratch_public(size_t n, Scratch& s, hipStream_t st);
 
 // x[t], y[t] <- children of induced node t (source index < 0: empty-subtree root of this level)
 __global__ void __launch_bounds__(256)
@@ -90,7 +90,7 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
   uint64_t* d_y = (uint64_t*)(b + emp_bytes + 3 * fb);
   int2* d_src = (int2*)(b + emp_bytes + 4 * fb);
   Scratch s;
-  int rc = get_scratch_public(nn, s);
+  int rc = get_scratch_public(nn, s, 0);
   if (rc != SP_OK) return rc;
   SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), 0));
   // empty-subtree roots: empties[k+1] = H(empties[k], empties[k])

@@ -15,6 +15,7 @@
 // Algorithmic bytes per hash: 96 (two felts in, one out).  The kernel is VALU bound
 // (~3.3e3 v_mad_i64_i32 per window addition), not HBM bound - see DESIGN.md.
 #include <cstdlib>
+#include <map>
 #include <vector>
 
 #include "context.hpp"
@@ -126,23 +127,14 @@ __device__ __forceinline__ uint32_t window_from_memory(const uint64_t* felt, int
   return (uint32_t)(two >> sh) & ((1u << wbits) - 1u);
 }
 
+// Partial sums of one lane group: returns the full XYZZ sum on every lane of the group.
 template <int LOG_L>
-__global__ void __launch_bounds__(256)
-ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
-                            size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits,
-                            int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
-                            uint8_t* __restrict__ status, unsigned* __restrict__ flag) {
+__device__ __forceinline__ xyzz split_accumulate(const uint64_t* fx, const uint64_t* fy, int sub,
+                                                 const aff_packed* __restrict__ ped, int wbits, int nwin) {
   constexpr int L = 1 << LOG_L;
-  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t e_raw = gt >> LOG_L;
-  const int sub = (int)(gt & (L - 1));
-  const bool active = e_raw < n;
-  const size_t e = active ? e_raw : n - 1;  // clamp: whole lane groups stay convergent for the shuffles
   const int total = 2 * nwin;
   const int cnt = total / L;  // host guarantees divisibility and cnt >= 2
   const size_t per = (size_t)1 << wbits;
-  const uint64_t* fx = x + 4 * e * xstride;
-  const uint64_t* fy = y + 4 * e * ystride;
   auto entry = [&](int g) {
     const uint64_t* f = g < nwin ? fx : fy;
     const int win = g < nwin ? g : g - nwin;
@@ -162,7 +154,9 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
     if (j + 1 < cnt) nxt = ld_raw(entry(g0 + j + 1));
     acc = xyzz_madd(acc, q);
   }
-#pragma unroll
+  // NOT unrolled on purpose: one copy of the 14-multiplication general addition keeps the kernel
+  // inside the instruction cache (a 58 KB straight-line body ran 2x slower than a 25 KB loop).
+#pragma unroll 1
   for (int r = 0; r < LOG_L; ++r) {
     xyzz o;
     o.X = shfl_xor_fe(acc.X, 1 << r);
@@ -171,6 +165,24 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
     o.ZZZ = shfl_xor_fe(acc.ZZZ, 1 << r);
     acc = xyzz_add(acc, o);
   }
+  return acc;
+}
+
+template <int LOG_L>
+__global__ void __launch_bounds__(256)
+ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
+                            size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits,
+                            int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
+                            uint8_t* __restrict__ status, unsigned* __restrict__ flag) {
+  constexpr int L = 1 << LOG_L;
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e_raw = gt >> LOG_L;
+  const int sub = (int)(gt & (L - 1));
+  const bool active = e_raw < n;
+  const size_t e = active ? e_raw : n - 1;  // clamp: whole lane groups stay convergent for the shuffles
+  const uint64_t* fx = x + 4 * e * xstride;
+  const uint64_t* fy = y + 4 * e * ystride;
+  const xyzz acc = split_accumulate<LOG_L>(fx, fy, sub, ped, wbits, nwin);
   if (!active || sub != 0) return;
   uint8_t st = SP_HASH_OK;
   if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
@@ -178,6 +190,66 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
   store_limbs(sZZ, n, e, acc.ZZ);
   if (status) status[e] = st;
   if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
+}
+
+// One lane finishes a hash on its own: x = X / ZZ, canonical, with status.
+__device__ __forceinline__ void finish_single(const xyzz& acc, const uint64_t* fx, const uint64_t* fy,
+                                              uint64_t* out, uint8_t* status, size_t e, unsigned* flag) {
+  uint8_t st = SP_HASH_OK;
+  if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
+  fe zz = acc.ZZ;
+  if (fe_is_zero(zz)) {
+    zz = FE_ONE_M;
+    st = SP_HASH_UNHASHABLE;
+  }
+  st_u256(out, fe_pack(fe_from_mont(fe_mul(acc.X, fe_inv(zz)))));
+  if (status) status[e] = st;
+  if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
+}
+
+// Fused small-batch kernel (n <= 8192): 8 lanes accumulate one hash, lane 0 of the group inverts
+// and writes the canonical x - one launch per tree level instead of two, no scratch round trip.
+__global__ void __launch_bounds__(256)
+ped_hash_small_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
+                      size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits, int nwin,
+                      uint64_t* __restrict__ out, size_t ostride, uint8_t* __restrict__ status,
+                      unsigned* __restrict__ flag) {
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e_raw = gt >> 3;
+  const int sub = (int)(gt & 7);
+  const bool active = e_raw < n;
+  const size_t e = active ? e_raw : n - 1;
+  const uint64_t* fx = x + 4 * e * xstride;
+  const uint64_t* fy = y + 4 * e * ystride;
+  const xyzz acc = split_accumulate<3>(fx, fy, sub, ped, wbits, nwin);
+  if (!active || sub != 0) return;
+  finish_single(acc, fx, fy, out + 4 * e * ostride, status, e, flag);
+}
+
+// Top of a Merkle tree in ONE launch: a single 512-thread workgroup hashes the levels with
+// 64, 32, ..., 1 nodes (8 lanes per node), synchronising with __syncthreads() between levels
+// (a workgroup's global stores are visible to its own waves after the barrier).
+// `level` points at the 2 * n_first children; parents are appended behind each level.
+__global__ void __launch_bounds__(512)
+ped_tree_top_kernel(uint64_t* __restrict__ level, int n_first, const aff_packed* __restrict__ ped,
+                    int wbits, int nwin, unsigned* __restrict__ flag) {
+  uint64_t* cur = level;
+  for (int n = n_first; n >= 1; n >>= 1) {
+    uint64_t* nxt = cur + 4 * (size_t)(2 * n);
+    const int e_raw = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    // whole waves beyond the level's lanes skip the work (8 nodes per wave)
+    if ((threadIdx.x & ~63) < 8 * n) {
+      const bool active = e_raw < n;
+      const int e = active ? e_raw : n - 1;
+      const uint64_t* fx = cur + 4 * (size_t)(2 * e);
+      const uint64_t* fy = fx + 4;
+      const xyzz acc = split_accumulate<3>(fx, fy, sub, ped, wbits, nwin);
+      if (active && sub == 0) finish_single(acc, fx, fy, nxt + 4 * (size_t)e, nullptr, (size_t)e, flag);
+    }
+    __threadfence_block();
+    __syncthreads();
+    cur = nxt;
+  }
 }
 
 // Kernel B: thread t owns elements t, t+T, t+2T, ...; one inversion per thread.
@@ -250,20 +322,29 @@ struct KernelProfile {
   size_t used = 0;
 };
 static KernelProfile g_prof;
-static bool g_split_enabled = getenv("STARKPERP_NO_SPLIT") == nullptr;  // A/B switch
+static bool g_split_enabled = getenv("STARKPERP_NO_SPLIT") == nullptr;  // A/B switches
+// Fused accumulate+invert and the single-launch tree top measured SLOWER than two kernels per level
+// (a lone wave issues v_mad_i64_i32 every ~11 cycles; the separate finish kernel runs its
+// 32-bit divsteps at ~5): kept behind opt-in switches for experiments.
+static bool g_fused_enabled = getenv("STARKPERP_FUSED") != nullptr;
+static bool g_treetop_enabled = getenv("STARKPERP_TREETOP") != nullptr;
 
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
   int32_t *X, *ZZ, *Pre;
   unsigned* flag;
 };
-int get_scratch_public(size_t n, Scratch& s);
-static int get_scratch(size_t n, Scratch& s) { return get_scratch_public(n, s); }
-int get_scratch_public(size_t n, Scratch& s) {
-  Context& c = ctx();
+// Scratch is per stream, so independent calls issued on different HIP streams (e.g. several trees
+// in flight) never share X / ZZ / prefix planes.  Growing a buffer reallocates it: callers that
+// overlap streams should size the first call of each stream for their largest batch.
+static std::map<hipStream_t, DeviceBuffer> g_stream_scratch;
+int get_scratch_public(size_t n, Scratch& s, hipStream_t st);
+static int get_scratch(size_t n, Scratch& s, hipStream_t st) { return get_scratch_public(n, s, st); }
+int get_scratch_public(size_t n, Scratch& s, hipStream_t st) {
+  DeviceBuffer& buf = g_stream_scratch[st];
   const size_t plane = ((9 * n * sizeof(int32_t)) + 255) & ~(size_t)255;
-  SP_HIP(c.scratch.reserve(3 * plane + 256));
-  char* b = (char*)c.scratch.ptr;
+  SP_HIP(buf.reserve(3 * plane + 256));
+  char* b = (char*)buf.ptr;
   s.X = (int32_t*)b;
   s.ZZ = (int32_t*)(b + plane);
   s.Pre = (int32_t*)(b + 2 * plane);
@@ -288,6 +369,20 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
   const unsigned blocksA = (unsigned)((n + 255) / 256);
   const bool prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size();
   if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+  const bool can8 = g_split_enabled && (2 * c.nwin) % 8 == 0 && (2 * c.nwin) / 8 >= 2;
+  if (can8 && n <= 8192 && g_fused_enabled) {
+    // fused accumulate + inversion: one launch, no scratch
+    const unsigned blocks = (unsigned)((8 * n + 255) / 256);
+    hipLaunchKernelGGL(ped_hash_small_kernel, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n, c.ped,
+                       c.wbits, c.nwin, out, os, status, flag);
+    if (prof) {
+      (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+      g_prof.units.push_back(n);
+      g_prof.used += 2;
+    }
+    SP_HIP(hipGetLastError());
+    return SP_OK;
+  }
   // lanes per hash: fill ~2 waves per SIMD (131072 lanes) before falling back to one lane per hash
   int log_l = 0;
   if (g_split_enabled) {
@@ -336,7 +431,7 @@ int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, u
   SP_REQUIRE_READY();
   std::lock_guard<std::mutex> lk(ctx().mu);
   Scratch s;
-  int rc = get_scratch(n, s);
+  int rc = get_scratch(n, s, (hipStream_t)stream);
   if (rc != SP_OK) return rc;
   return enqueue_pedersen(x, 1, y, 1, out, 1, status, nullptr, n, (hipStream_t)stream, s);
 }
@@ -355,7 +450,7 @@ int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8
   SP_HIP(hipMemcpy(dx, x, fb, hipMemcpyHostToDevice));
   SP_HIP(hipMemcpy(dy, y, fb, hipMemcpyHostToDevice));
   Scratch s;
-  int rc = get_scratch(n, s);
+  int rc = get_scratch(n, s, 0);
   if (rc != SP_OK) return rc;
   rc = enqueue_pedersen(dx, 1, dy, 1, dout, 1, dst, nullptr, n, 0, s);
   if (rc != SP_OK) return rc;
@@ -432,7 +527,7 @@ int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, ui
   std::lock_guard<std::mutex> lk(c.mu);
   hipStream_t st = (hipStream_t)stream;
   Scratch s;
-  int rc = get_scratch(width, s);
+  int rc = get_scratch(width, s, st);
   if (rc != SP_OK) return rc;
   SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
   if (depth == 1) {
@@ -479,11 +574,19 @@ int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void
   hipStream_t st = (hipStream_t)stream;
   const size_t n0 = (size_t)1 << height;
   Scratch s;
-  int rc = get_scratch(n0 / 2 + 1, s);
+  int rc = get_scratch(n0 / 2 + 1, s, st);
   if (rc != SP_OK) return rc;
   SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
   uint64_t* cur = levels;
+  const bool can8 = g_split_enabled && g_treetop_enabled && (2 * c.nwin) % 8 == 0 && (2 * c.nwin) / 8 >= 2;
   for (size_t n = n0; n > 1; n >>= 1) {
+    if (can8 && n <= 128) {
+      // the remaining levels (n/2, n/4, ..., 1 parents) in one single-workgroup launch
+      hipLaunchKernelGGL(ped_tree_top_kernel, dim3(1), dim3(512), 0, st, cur, (int)(n / 2), c.ped,
+                         c.wbits, c.nwin, s.flag);
+      SP_HIP(hipGetLastError());
+      break;
+    }
     uint64_t* nxt = cur + 4 * n;
     rc = enqueue_pedersen(cur, 2, cur + 4, 2, nxt, 1, nullptr, s.flag, n / 2, st, s);
     if (rc != SP_OK) return rc;
