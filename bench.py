@@ -156,8 +156,8 @@ def main():
     # The ~35 launches of one rebuild are captured once per slot into a hipGraph and replayed:
     # with several trees in flight the eager path is host-launch bound (~0.6 ms of API calls per tree).
     use_graphs = args.graphs and world == 1 and n_streams > 1
-    if use_graphs:
-        for sl in slots:  # size scratch / twiddles before capture (no allocation inside a capture)
+    if n_streams > 1:
+        for sl in slots:  # size per-stream scratch up front (no allocation inside a capture / the timed region)
             with torch.cuda.stream(sl["stream"]):
                 run_slot(sl)
         torch.cuda.synchronize()

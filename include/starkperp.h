@@ -82,6 +82,9 @@ int sp_pedersen_point_batch(const uint64_t* x, const uint64_t* y, uint64_t* out_
 /* left fold h = H(h, e_i) starting from h = e_0: the hash-chain shape of
  * perpetual_messages.py:279-286 and position/hash.cairo:22-43.  n_elems >= 1. */
 int sp_pedersen_chain(const uint64_t* elems, size_t n_elems, uint64_t* out, uint8_t* status);
+/* right fold h = H(e_i, h) starting from h = e_{n-1}: cairo-lang compute_hash_chain, the consumer
+ * behind starkware/cairo/bootloaders/program_hash_test_utils.py:9. */
+int sp_pedersen_chain_right(const uint64_t* elems, size_t n_elems, uint64_t* out, uint8_t* status);
 /* width independent chains of equal depth, element j of chain i at elems[(j*width + i)*4]:
  * out[i] = H(...H(H(e0,e1),e2)...,e_{depth-1}) */
 int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, uint64_t* out,

@@ -566,6 +566,41 @@ int sp_pedersen_chain(const uint64_t* elems, size_t n_elems, uint64_t* out, uint
   return SP_OK;
 }
 
+// Right fold h = H(e_i, h) from the last element down: the shape of cairo-lang's
+// compute_hash_chain, which the program-hash harness calls
+// (starkware/cairo/bootloaders/program_hash_test_utils.py:9).  Inherently serial: n - 1 launches.
+int sp_pedersen_chain_right(const uint64_t* elems, size_t n_elems, uint64_t* out, uint8_t* status) {
+  SP_REQUIRE_READY();
+  if (n_elems < 1) { set_error("chain needs at least one element"); return SP_ERR_BAD_ARGUMENT; }
+  Context& c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  SP_HIP(c.io.reserve((n_elems + 2) * 32 + 64));
+  uint64_t* d_el = (uint64_t*)c.io.ptr;
+  uint64_t* d_a = d_el + 4 * n_elems;
+  uint64_t* d_b = d_a + 4;
+  SP_HIP(hipMemcpy(d_el, elems, n_elems * 32, hipMemcpyHostToDevice));
+  Scratch s;
+  int rc = get_scratch(1, s, 0);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), 0));
+  const uint64_t* h = d_el + 4 * (n_elems - 1);
+  uint64_t* nxt = d_a;
+  for (size_t i = n_elems - 1; i-- > 0;) {
+    rc = enqueue_pedersen(d_el + 4 * i, 1, h, 1, nxt, 1, nullptr, s.flag, 1, 0, s);
+    if (rc != SP_OK) return rc;
+    h = nxt;
+    nxt = (nxt == d_a) ? d_b : d_a;
+  }
+  SP_HIP(hipDeviceSynchronize());
+  SP_HIP(hipMemcpy(out, h, 32, hipMemcpyDeviceToHost));
+  if (status) {
+    unsigned f = 0;
+    SP_HIP(hipMemcpy(&f, s.flag, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *status = (uint8_t)f;
+  }
+  return SP_OK;
+}
+
 int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void* stream) {
   SP_REQUIRE_READY();
   if (height > 40) { set_error("height too large for a full rebuild"); return SP_ERR_BAD_ARGUMENT; }

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "sp_pedersen_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]),
     "sp_pedersen_point_batch": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_size_t]),
     "sp_pedersen_chain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_pedersen_chain_right": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_pedersen_chains_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_merkle_root": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,

@@ -53,6 +53,20 @@ def pedersen_chain(elements):
     return unpack_felts(out, 1)[0]
 
 
+def pedersen_chain_right(elements):
+    """Right fold H(e0, H(e1, ... H(e_{n-2}, e_{n-1}))) - cairo-lang's compute_hash_chain shape."""
+    n = len(elements)
+    assert n >= 1
+    for v in elements:
+        assert 0 <= v < FIELD_PRIME
+    lib = _lib.ensure_init()
+    out, st = new_felts(1), new_bytes(1)
+    _lib.check(lib.sp_pedersen_chain_right(pack_felts(elements), n, out, st), "sp_pedersen_chain_right")
+    if st[0]:
+        _raise_hash_status(2 if st[0] & 2 else 1)
+    return unpack_felts(out, 1)[0]
+
+
 def pedersen_chains_many(chains):
     """Equal-depth chains: [H(...H(H(c[0], c[1]), c[2])..., c[-1]) for c in chains], evaluated
     level by level across the whole batch (depth - 1 batched launches)."""
