@@ -318,6 +318,45 @@ def extras(torch, lib, _lib, dev, stream):
     out["bulk_pedersen_batch"] = n
     del x, y, o
 
+    # BASELINE.json configs[2]: 4096 limit orders - message hashes, ECDSA verify, orders-tree update
+    import random as _random
+    from starkperp import batch as _batch, perpetual_messages as _pm, state as _state
+    import workloads as wl
+    orders = wl.limit_orders(4096, seed=2)
+    keys = wl.private_keys(1024, seed=12)
+    t0 = time.perf_counter()
+    zs = _pm.limit_order_msgs_many([wl.order_args(o) for o in orders])
+    t_msgs = time.perf_counter() - t0
+    pubs = _batch.public_keys_many(keys)
+    zsig = [z % 2**251 for z in zs]
+    sigs = _batch.sign_many(zsig, [keys[o["key_index"]] for o in orders])
+    t0 = time.perf_counter()
+    ok = _batch.verify_many(zsig, [r for r, _ in sigs], [s_ for _, s_ in sigs],
+                            [pubs[o["key_index"]][0] for o in orders])
+    t_verify = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _state.orders_tree_root({_state.order_id_of(z): o["amount_synthetic"] for z, o in zip(zs, orders)}, 64)
+    t_tree = time.perf_counter() - t0
+    out["c3_4096_orders_host_inclusive_seconds"] = {
+        "message_hashes": t_msgs, "verify_x_only": t_verify, "orders_tree_height64_update": t_tree,
+        "all_verified": bool(all(ok))}
+    out["c3_orders_per_sec_host_inclusive"] = 4096 / (t_msgs + t_verify + t_tree)
+    # device-resident verification rate
+    nv = 1 << 16
+    rng = _random.Random(21)
+    dsk = [rng.randrange(1, _batch.EC_ORDER) for _ in range(nv)]
+    zv = [rng.randrange(2**251) for _ in range(nv)]
+    kv = [rng.randrange(1, _batch.EC_ORDER) for _ in range(nv)]
+    pv = _batch.public_keys_many(dsk)
+    rv, sv, stv = _batch.sign_attempt_many(zv, dsk, kv)
+    from starkperp import stark as _st
+    dz, dr, dsig, dq = (_st.felts_to_tensor(v, dev) for v in (zv, rv, sv, [q[0] for q in pv]))
+    res = torch.zeros(nv, dtype=torch.uint8, device=dev)
+    sv_t = timed(lambda: _lib.check(lib.sp_ecdsa_verify_batch_dev(
+        dz.data_ptr(), dr.data_ptr(), dsig.data_ptr(), dq.data_ptr(), None, res.data_ptr(), nv, stream), "verify"), 3)
+    out["ecdsa_verifies_per_sec_x_only_2p16"] = nv / sv_t
+    out["ecdsa_verify_all_true"] = bool(int((res == 1).sum()) == stv.count(0))
+
     # BASELINE.json configs[3]: 2^20-row trace -> LDE -> commit -> AIR -> commit -> FRI (+commits)
     import random
     from starkperp import stark
