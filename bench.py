@@ -102,6 +102,10 @@ def main():
                     help="HIP streams the K steps are issued on round-robin (independent trees "
                          "overlap: the upper levels of one rebuild are latency-bound and leave most "
                          "of the chip idle); 1 = strictly one tree at a time")
+    ap.add_argument("--workload", choices=["merkle", "airfri"], default="merkle",
+                    help="merkle = BASELINE.json configs[1] (default, the headline line); airfri = one "
+                         "2^20-row AIR+FRI commit job per GPU per step (configs[3]; with N GPUs the "
+                         "N * 2^20-row trace of configs[4] as disjoint row ranges, roots combined over RCCL)")
     ap.add_argument("--no-graphs", dest="graphs", action="store_false",
                     help="issue every launch eagerly instead of replaying one hipGraph per tree")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,6 +134,8 @@ def main():
     from starkperp.distributed import combine_subroots_dev
 
     lib = _lib.ensure_init(local_rank)
+    if args.workload == "airfri":
+        return run_airfri(args, torch, dist, lib, _lib, dev, rank, world)
     n_leaves = 1 << HEIGHT
     n_streams = max(1, args.streams)
     leaves = seeded_felts(torch, n_leaves, 1000 + rank, dev)
@@ -282,6 +288,84 @@ def main():
             base["matches_gpu"] = gpu_l1 == cpu_out
             result["cpu_baseline"] = base
         print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
+    """configs[3]/[4]: every rank proves the commitments of its own 2^20-row segment (disjoint trace
+    row ranges); the 17 commitment roots per rank are exchanged with one all_gather (17 x 32 B per
+    rank) and combined into 17 job-level roots by hashing the log2(N) top levels on every rank."""
+    import random
+    from starkperp import stark
+    m = 2048
+    P = stark.FIELD_PRIME
+    xs, ys = seeded_felts(torch, m, 11 + 100 * rank, dev), seeded_felts(torch, m, 12 + 100 * rank, dev)
+    rng = random.Random(13)
+    alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
+    betas = [rng.randrange(P) for _ in range(16)]
+    trace = stark.pedersen_trace(xs, ys)  # witness generation is input preparation
+    per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    n_roots = 17
+    roots_dev = torch.zeros((n_roots, 4), dtype=torch.int64, device=dev)
+    gathered = torch.zeros((max(world, 1) * n_roots, 4), dtype=torch.int64, device=dev)
+    tops = torch.zeros((n_roots, 2 * max(world, 1) - 1, 4), dtype=torch.int64, device=dev)
+
+    def step():
+        k = 0
+        t_lde = stark.lde(trace)
+        roots_dev[k] = stark.commit_rows(t_lde)[-1]; k += 1
+        comp = stark.air_eval(t_lde, per, 512 * m, alphas)
+        roots_dev[k] = stark.commit_rows(comp.unsqueeze(0))[-1]; k += 1
+        layer, sh, j = comp, stark.FIELD_GEN, 0
+        while layer.shape[0] > 64:
+            layer = stark.fri_fold(layer, betas[j], sh)
+            sh = sh * sh % P
+            j += 1
+            if layer.shape[0] > 64:
+                roots_dev[k] = stark.commit_rows(layer.unsqueeze(0))[-1]; k += 1
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, roots_dev)
+            g = gathered.reshape(world, n_roots, 4)
+            height = world.bit_length() - 1
+            for c in range(n_roots):
+                tops[c, :world] = g[:, c]
+                _lib.check(lib.sp_merkle_build_dev(tops[c].data_ptr(), height, None, stream), "combine")
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        hashes = 4 * (1 << 22) + (1 << 22) + sum((1 << k) for k in range(7, 22))
+        print(json.dumps({
+            "metric": "air_fri_commits_per_sec", "value": world * args.steps / elapsed, "unit": "commits/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32x9 (29-bit limbs) mod p", "data": "synthetic",
+            "config": {"workload": "2^20-row Pedersen-step trace per GPU: LDE x4 -> commit -> AIR -> commit -> "
+                                   "16 FRI folds with 15 layer commits (BASELINE.json configs[3]; N GPUs = "
+                                   "configs[4] as N disjoint row ranges)",
+                       "rows_per_gpu": 512 * m, "pedersen_hashes_per_job": hashes,
+                       "combine": "none" if world == 1 else "all_gather of 17 roots per rank + top hashes"},
+            "roofline": None, "cpu_baseline": None,
+        }))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -207,6 +207,12 @@ SP_HD void cols_sqr(cols& t, const fe& a) {
 
 // Montgomery reduction mod p: returns (T + q p) / 2^261 in N-form, value in (T/R, T/R + p).
 SP_HD fe fe_reduce(cols& t) {
+  // On the device q * 2^19 is issued as ONE v_mad_u64_u32 (q, 2^19 in an SGPR, accumulator) instead
+  // of the shift + 64-bit add the compiler derives from a visible power of two.
+  uint32_t p8 = (uint32_t)P8;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(p8));
+#endif
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const uint32_t q = (0u - (uint32_t)t.c[i]) & LMASK;  // p = 1 mod 2^29  =>  q = -c_i
@@ -214,7 +220,7 @@ SP_HD fe fe_reduce(cols& t) {
     SP_CHK64((__int128)t.c[i + 6] + (__int128)q * P6);
     t.c[i + 6] += (int64_t)q * (int64_t)P6;
     SP_CHK64((__int128)t.c[i + 8] + ((__int128)q << 19));
-    t.c[i + 8] += (int64_t)q << 19;  // P8 = 2^19; i + 8 <= 16
+    t.c[i + 8] += (int64_t)((uint64_t)q * (uint64_t)p8);  // P8 = 2^19; i + 8 <= 16
   }
   fe r;
   int64_t carry = 0;
