@@ -208,7 +208,6 @@ void sp_shutdown(void) {
   if (g_ctx.ped) (void)hipFree(g_ctx.ped);
   if (g_ctx.gen) (void)hipFree(g_ctx.gen);
   g_ctx.ped = g_ctx.gen = nullptr;
-  g_ctx.scratch.release();
   g_ctx.io.release();
   g_ctx.io2.release();
   g_ctx.ready = false;

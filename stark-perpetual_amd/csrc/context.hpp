@@ -44,7 +44,6 @@ struct Context {
   aff_packed* ped = nullptr;   // [2][nwin][1 << wbits]  Pedersen: element, window, value
   aff_packed* gen = nullptr;   // [nwin][1 << wbits]     fixed-base EC_GEN
   size_t table_bytes = 0;
-  DeviceBuffer scratch;        // X / ZZ / prefix products for batched inversion
   DeviceBuffer io;             // staging for host-pointer entry points
   DeviceBuffer io2;
   std::mutex mu;

@@ -25,10 +25,6 @@
 
 namespace sp {
 
-struct raw_aff2 {
-  uint4 a, b, c, d;
-};
-
 // k * EC_GEN from the window table; k < 2^252.  Infinity (only for k == 0 mod N) shows as ZZ == 0.
 __device__ __forceinline__ xyzz gen_mul(u256 k, const aff_packed* __restrict__ gen, int wbits, int nwin) {
   const size_t per = (size_t)1 << wbits;

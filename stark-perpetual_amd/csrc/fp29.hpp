@@ -26,7 +26,6 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SP_HD __host__ __device__ __forceinline__
-#define SP_CONST_MEM
 #else
 #define SP_HD inline
 #endif
