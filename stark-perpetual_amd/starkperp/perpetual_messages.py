@@ -179,3 +179,32 @@ def limit_order_msgs_many(orders: Sequence[Sequence[int]]):
     order): four GPU launches of width len(orders) instead of 4 * len(orders) scalar hashes."""
     words = [_limit_order_words(*o) for o in orders]
     return batch.pedersen_chains_many(words)
+
+
+def transfer_msgs_many(transfers: Sequence[Sequence[int]]):
+    """Many transfers (10-tuples in get_transfer_msg argument order): depth-5 chains."""
+    words = []
+    for (asset_id, asset_id_fee, receiver_public_key, sender, receiver, fee_pos, nonce, amount,
+         max_fee, expiration) in transfers:
+        w0, w1 = _transfer_words(TRANSFER, sender, receiver, fee_pos, nonce, amount, max_fee, expiration)
+        words.append([asset_id, asset_id_fee, receiver_public_key, w0, w1])
+    return batch.pedersen_chains_many(words)
+
+
+def conditional_transfer_msgs_many(transfers: Sequence[Sequence[int]]):
+    """Many conditional transfers (11-tuples in get_conditional_transfer_msg order): depth 6."""
+    words = []
+    for (asset_id, asset_id_fee, receiver_public_key, condition, sender, receiver, fee_pos, nonce,
+         amount, max_fee, expiration) in transfers:
+        w0, w1 = _transfer_words(CONDITIONAL_TRANSFER, sender, receiver, fee_pos, nonce, amount, max_fee,
+                                 expiration)
+        words.append([asset_id, asset_id_fee, receiver_public_key, condition, w0, w1])
+    return batch.pedersen_chains_many(words)
+
+
+def price_msgs_many(prices: Sequence[Sequence[int]]):
+    """Many oracle price messages ((oracle_name, asset_pair, timestamp, price) tuples): the
+    1-hash + 1-verify per oracle signature of oracle/oracle_price.cairo:96-108."""
+    xs = [(asset_pair << 40) + oracle for oracle, asset_pair, _, _ in prices]
+    ys = [(price << 32) + ts for _, _, ts, price in prices]
+    return batch.pedersen_hash_many(xs, ys)

@@ -62,3 +62,88 @@ def order_id_of(message_hash: int) -> int:
 def orders_tree_root(fulfilled: Dict[int, int], height: int = 64) -> int:
     """Root of the orders tree (leaf = fulfilled amount, empty leaf 0) after writing `fulfilled`."""
     return batch.merkle_sparse_root(height, fulfilled, 0)
+
+
+# ---- persistent sparse tree with a preimage ("facts") store -------------------------------------
+class SparseMerkleTree:
+    """Height-h Pedersen Merkle tree over 2^h leaves, stored sparsely as the reference stores it:
+    a map node_hash -> (left, right) (`merkle_facts`, services/perpetual/cairo/main.cairo:39-40,
+    61-64) plus the current root.  `update` is the equivalent of one
+    merkle_multi_update{hash_ptr=pedersen_ptr} call (state/state.cairo:155-173): it walks the
+    subtree induced by the modified leaves (starkware/python/merkle_tree.py:4-26), takes untouched
+    siblings from the store and recomputes the touched nodes level by level - one batched GPU
+    launch pair per level through `hash_many` (default: starkperp.batch.pedersen_hash_many).
+
+    Only bookkeeping (dicts of ints) happens on the host; every hash goes through `hash_many`.
+    """
+
+    def __init__(self, height: int, empty_leaf: int = 0, hash_many=None):
+        self.height = height
+        self.hash_many = hash_many or batch.pedersen_hash_many
+        self.facts: Dict[int, Tuple[int, int]] = {}
+        self.empties = [empty_leaf]
+        for _ in range(height):
+            prev = self.empties[-1]
+            node = self.hash_many([prev], [prev])[0]
+            self.facts[node] = (prev, prev)
+            self.empties.append(node)
+        self.root = self.empties[height]
+
+    def _children(self, node: int, level: int) -> Tuple[int, int]:
+        """Children of `node`, which sits `level` levels above the leaves."""
+        if node == self.empties[level]:
+            e = self.empties[level - 1]
+            return e, e
+        return self.facts[node]
+
+    def get(self, key: int) -> int:
+        node = self.root
+        for level in range(self.height, 0, -1):
+            left, right = self._children(node, level)
+            node = right if (key >> (level - 1)) & 1 else left
+        return node
+
+    def update(self, modifications: Dict[int, int]) -> Tuple[int, int]:
+        """Writes {leaf_index: value}; returns (old_root, new_root)."""
+        old_root = self.root
+        if not modifications:
+            return old_root, old_root
+        for k in modifications:
+            assert 0 <= k < (1 << self.height)
+        # top-down: current hashes of every node on a modified path, per level (level = height
+        # above the leaves), keyed by node index within its level
+        paths: List[Dict[int, int]] = [dict() for _ in range(self.height + 1)]
+        paths[self.height][0] = self.root
+        for level in range(self.height, 0, -1):
+            wanted = sorted(set(k >> (level - 1) for k in modifications))
+            for idx in wanted:
+                parent = paths[level][idx >> 1]
+                left, right = self._children(parent, level)
+                paths[level - 1][idx] = right if idx & 1 else left
+                sib = idx ^ 1
+                if sib not in paths[level - 1]:
+                    paths[level - 1][sib] = left if idx & 1 else right
+        # bottom-up: new values
+        layer = dict(modifications)
+        for level in range(1, self.height + 1):
+            parents = sorted(set(i >> 1 for i in layer))
+            lefts = [layer.get(2 * i, paths[level - 1][2 * i]) for i in parents]
+            rights = [layer.get(2 * i + 1, paths[level - 1][2 * i + 1]) for i in parents]
+            hashes = self.hash_many(lefts, rights)
+            for node, l, r in zip(hashes, lefts, rights):
+                self.facts[node] = (l, r)
+            layer = dict(zip(parents, hashes))
+        self.root = layer[0]
+        return old_root, self.root
+
+
+def hash_position_updates(updates: Sequence[Tuple[int, Position, Position]]):
+    """position/hash.cairo:76-131: (key, prev_position, new_position) -> (key, prev_hash, new_hash);
+    an unchanged position is hashed once."""
+    prev = position_hashes_many([u[1] for u in updates])
+    changed = [i for i, u in enumerate(updates) if u[1] != u[2]]
+    new_h = position_hashes_many([updates[i][2] for i in changed])
+    out = [(u[0], p, p) for u, p in zip(updates, prev)]
+    for i, hnew in zip(changed, new_h):
+        out[i] = (updates[i][0], prev[i], hnew)
+    return out

@@ -169,5 +169,11 @@ def test_messages(sig):
     assert got == [h(v) for v in g["limit_order_z"]]
     assert pm.get_price_msg(0x4D616B6572, 0x42544355534400000000000000000000, 0x5F590C1E,
                             0xAC9F3163AD52B000) == h(g["price"])
+    t = [(5 + i, 6, 7, 8, 9, 10, 11, 12, 13, 14) for i in range(3)]
+    assert spm.transfer_msgs_many(t) == [R.get_transfer_msg(*a) for a in t]
+    c = [(5, 6, 7, 99 + i, 8, 9, 10, 11, 12, 13, 14) for i in range(3)]
+    assert spm.conditional_transfer_msgs_many(c) == [R.get_conditional_transfer_msg(*a) for a in c]
+    pr = [(0x4D616B6572, 0x42544355534400000000000000000000 + i, 0x5F590C1E, 0xAC9F3163AD52B000) for i in range(3)]
+    assert spm.price_msgs_many(pr) == [R.get_price_msg(*a) for a in pr]
     # the hash_function injection seam still works
     assert pm.get_price_msg(1, 2, 3, 4, hash_function=lambda a, b: a + b) == (2 << 40) + 1 + (4 << 32) + 3

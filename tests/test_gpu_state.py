@@ -72,3 +72,26 @@ def test_c3_order_batch():
     mods = {state.order_id_of(z): o["amount_synthetic"] for z, o in zip(zs, orders)}
     assert len(mods) == g["n_distinct_order_ids"]
     assert state.orders_tree_root(mods, g["orders_tree_height"]) == h(g["orders_tree_root"])
+
+
+def test_persistent_tree_and_position_updates():
+    """SparseMerkleTree on the GPU backend: same roots as the oracle-hashed twin, old/new root
+    pairs of successive multi-updates in a height-64 tree; hash_position_updates (hash.cairo:76-131)."""
+    from starkperp import state
+    rng = random.Random(31)
+    gpu = state.SparseMerkleTree(64)
+    ref_state = {}
+    for _ in range(3):
+        mods = {rng.randrange(2**64): rng.randrange(P) for _ in range(8)}
+        old, new = gpu.update(mods)
+        assert old == R.merkle_multi_update_sparse(64, ref_state)
+        ref_state.update(mods)
+        assert new == R.merkle_multi_update_sparse(64, ref_state)
+    some = next(iter(ref_state))
+    assert gpu.get(some) == ref_state[some]
+    poss = wl.positions(8, seed=5)
+    changed = [(p[0], p[1] + 1, p[2]) for p in poss]
+    ups = [(i, poss[i], changed[i] if i % 2 else poss[i]) for i in range(8)]
+    got = state.hash_position_updates(ups)
+    for (k, prev, new), (gk, gp, gn) in zip(ups, got):
+        assert gk == k and gp == R.position_hash(*prev) and gn == R.position_hash(*new)
