@@ -18,6 +18,10 @@
 
 namespace sp {
 
+void release_pedersen_state();  // per-stream scratch, profiling events (pedersen.hip)
+void release_merkle_state();    // sparse-update staging (merkle.hip)
+void release_stark_state();     // twiddle / coset tables, work buffers (stark.hip)
+
 static Context g_ctx;
 static std::string g_err;
 static std::mutex g_err_mu;
@@ -205,6 +209,10 @@ int sp_init(int device, int window_bits) {
 
 void sp_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_ctx.mu);
+  (void)hipDeviceSynchronize();
+  sp::release_pedersen_state();
+  sp::release_merkle_state();
+  sp::release_stark_state();
   if (g_ctx.ped) (void)hipFree(g_ctx.ped);
   if (g_ctx.gen) (void)hipFree(g_ctx.gen);
   g_ctx.ped = g_ctx.gen = nullptr;

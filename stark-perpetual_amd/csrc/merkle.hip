@@ -37,6 +37,7 @@ gather_children_kernel(const uint64_t* __restrict__ prev, const int2* __restrict
 }
 
 static DeviceBuffer g_sparse_buf;
+void release_merkle_state() { g_sparse_buf.release(); }
 
 }  // namespace sp
 

@@ -360,6 +360,16 @@ static size_t finish_threads(size_t n) {
   return (n + K - 1) / K;
 }
 
+void release_pedersen_state() {
+  for (auto& kv : g_stream_scratch) kv.second.release();
+  g_stream_scratch.clear();
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.units.clear();
+  g_prof.used = 0;
+  g_prof.enabled = false;
+}
+
 // Enqueue n hashes; x/y/out strides in felts.  `flag` (device, may be null) ORs item status.
 int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
                      size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,

@@ -244,6 +244,15 @@ struct Tables {
   bool bits_ready = false;
 };
 static Tables g_tab;
+void release_stark_state() {
+  for (auto& kv : g_tab.twiddle) kv.second.release();
+  for (auto& kv : g_tab.coset) kv.second.release();
+  g_tab.twiddle.clear();
+  g_tab.coset.clear();
+  g_tab.work.release();
+  g_tab.bits.release();
+  g_tab.bits_ready = false;
+}
 
 static fe h_pow_u64(fe base_m, uint64_t e) {
   fe r = FE_ONE_M;

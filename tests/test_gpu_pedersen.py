@@ -88,3 +88,23 @@ def test_merkle_c2_full(batch):
     assert levels[-1][0] == h(g["root"])
     assert [hex(l[0]) for l in levels] == g["left_spine"]
     assert [wl.digest_felts(l) for l in levels] == g["level_digests"]
+
+
+def test_shutdown_and_reinit_with_other_window(batch):
+    """sp_shutdown releases every device buffer; a re-init with a different window width gives the
+    same hashes (the tables are an implementation detail)."""
+    from starkperp import _lib
+    lib = _lib.load()
+    g = load("g1_pedersen.json")
+    pairs = wl.pedersen_pairs(64, seed=g["seed"])
+    exp = [h(v) for v in g["all"][:64]]
+    for wbits in (8, 13, 16):
+        lib.sp_shutdown()
+        assert lib.sp_is_initialised() == 0
+        _lib.check(lib.sp_init(0, wbits), "sp_init")
+        assert lib.sp_window_bits() == wbits
+        assert batch.pedersen_hash_many([p[0] for p in pairs], [p[1] for p in pairs]) == exp
+        lv = wl.leaves(256, seed=108)
+        assert batch.merkle_root(lv) == h(load("g6_merkle.json")["roots_seed_100_plus_h"]["8"])
+    lib.sp_shutdown()
+    _lib.ensure_init()
