@@ -89,6 +89,7 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
   if (nwin > 1) v = pop_window(sx, wbits);
   else v = pop_window(sy, wbits);
   raw_aff nxt = ld_raw(tab + v);
+#pragma unroll 2
   for (int i = 1; i < total; ++i) {
     const aff q = unpack_raw(nxt);
     if (i + 1 < total) {
