@@ -403,6 +403,8 @@ SP_HD void gcd_update_fg(fe& f, fe& g, const trans2x2& t) {
   }
   f.l[NL - 1] = (int32_t)cf;
   g.l[NL - 1] = (int32_t)cg;
+  fe_pin(f);
+  fe_pin(g);
 }
 
 // (d, e) <- t (d, e) / 2^29 mod p, keeping d, e in (-2p, p).  p = 1 (mod 2^29).
@@ -439,6 +441,8 @@ SP_HD void gcd_update_de(fe& d, fe& e, const trans2x2& t) {
   }
   d.l[NL - 1] = (int32_t)cd;
   e.l[NL - 1] = (int32_t)ce;
+  fe_pin(d);
+  fe_pin(e);
 }
 
 // Plain integer inverse: x canonical limbs in [0, p)  ->  canonical limbs of x^-1 mod p (0 -> 0).
@@ -597,6 +601,8 @@ SP_HD void gcd_update_de_n(fe& d, fe& e, const trans2x2& t) {
   }
   d.l[NL - 1] = (int32_t)cd;
   e.l[NL - 1] = (int32_t)ce;
+  fe_pin(d);
+  fe_pin(e);
 }
 // Montgomery-form inverse modulo N via divsteps (a: Montgomery N-form, value in (-p, 2p)).
 SP_HD fe fn_inv(const fe& a) {
