@@ -222,14 +222,14 @@ SP_HD void cols_sqr(cols& t, const fe& a) {
 SP_HD fe fe_reduce(cols& t) {
   // On the device q * 2^19 is issued as ONE v_mad_u64_u32 (q, 2^19 in an SGPR, accumulator) instead
   // of the shift + 64-bit add the compiler derives from a visible power of two.
-  uint32_t p8 = (uint32_t)P8;
+  uint32_t p8 = (uint32_t)P8, one = 1u;
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+s"(p8));
+  asm volatile("" : "+s"(p8), "+s"(one));  // keep both as SGPR multiplicands (q * 1 + c_i is one mad)
 #endif
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const uint32_t q = (0u - (uint32_t)t.c[i]) & LMASK;  // p = 1 mod 2^29  =>  q = -c_i
-    t.c[i + 1] += (t.c[i] + (int64_t)q) >> LB;           // exact: low 29 bits are zero
+    t.c[i + 1] += (int64_t)((uint64_t)q * (uint64_t)one + (uint64_t)t.c[i]) >> LB;  // exact: low 29 bits are zero
     SP_CHK64((__int128)t.c[i + 6] + (__int128)q * P6);
     t.c[i + 6] += (int64_t)q * (int64_t)P6;
     SP_CHK64((__int128)t.c[i + 8] + ((__int128)q << 19));
