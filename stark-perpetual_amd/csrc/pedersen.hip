@@ -20,6 +20,10 @@
 
 #include "context.hpp"
 
+#ifndef SP_ACC_WAVES
+#define SP_ACC_WAVES 1
+#endif
+
 namespace sp {
 
 struct raw_aff {
@@ -64,7 +68,7 @@ __device__ __forceinline__ fe load_limbs(const int32_t* base, size_t n, size_t e
 }
 
 // Kernel A: one hash per thread -> projective (X, ZZ) in scratch.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, SP_ACC_WAVES)
 ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
                       size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits, int nwin,
                       int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, uint8_t* __restrict__ status,
@@ -80,23 +84,21 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
     for (int i = 0; i < 8; ++i) { sx.w[i] = 0; sy.w[i] = 0; }
   }
   const size_t per = (size_t)1 << wbits;
-  // first entry initialises the accumulator, the next one is prefetched while it is unpacked
-  const aff_packed* tab = ped;
-  uint32_t v = pop_window(sx, wbits);
-  xyzz acc = xyzz_from_aff(unpack_raw(ld_raw(tab + v)));
-  tab += per;
+  // The first entry initialises the accumulator; entries i+1 and i+2 are in flight (two 64-byte
+  // gathers) while entry i is added, which hides the random-HBM latency behind ~3.5k instructions.
   const int total = 2 * nwin;
-  if (nwin > 1) v = pop_window(sx, wbits);
-  else v = pop_window(sy, wbits);
-  raw_aff nxt = ld_raw(tab + v);
-#pragma unroll 2
+  auto next_index = [&](int g) -> const aff_packed* {  // consumes the next window of x, then of y
+    const uint32_t v = (g < nwin) ? pop_window(sx, wbits) : pop_window(sy, wbits);
+    return ped + (size_t)g * per + v;
+  };
+  xyzz acc = xyzz_from_aff(unpack_raw(ld_raw(next_index(0))));
+  raw_aff n1 = ld_raw(next_index(1 < total ? 1 : 0));
+  raw_aff n2 = n1;
+  if (total > 2) n2 = ld_raw(next_index(2));
   for (int i = 1; i < total; ++i) {
-    const aff q = unpack_raw(nxt);
-    if (i + 1 < total) {
-      tab += per;
-      v = (i + 1 < nwin) ? pop_window(sx, wbits) : pop_window(sy, wbits);
-      nxt = ld_raw(tab + v);
-    }
+    const aff q = unpack_raw(n1);
+    n1 = n2;
+    if (i + 2 < total) n2 = ld_raw(next_index(i + 2));
     acc = xyzz_madd(acc, q);
   }
   store_limbs(sX, n, e, acc.X);
