@@ -21,6 +21,7 @@ namespace sp {
 void release_pedersen_state();  // per-stream scratch, profiling events (pedersen.hip)
 void release_merkle_state();    // sparse-update staging (merkle.hip)
 void release_stark_state();     // twiddle / coset tables, work buffers (stark.hip)
+void release_ecdsa_state();     // per-signature window tables (ecdsa.hip)
 
 static Context g_ctx;
 static std::string g_err;
@@ -213,6 +214,7 @@ void sp_shutdown(void) {
   sp::release_pedersen_state();
   sp::release_merkle_state();
   sp::release_stark_state();
+  sp::release_ecdsa_state();
   if (g_ctx.ped) (void)hipFree(g_ctx.ped);
   if (g_ctx.gen) (void)hipFree(g_ctx.gen);
   g_ctx.ped = g_ctx.gen = nullptr;

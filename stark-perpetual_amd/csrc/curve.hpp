@@ -148,4 +148,27 @@ SP_HD jac jac_madd(const jac& p, const aff& q) {
   return r;
 }
 
+// "add-2007-bl": Jacobian + Jacobian, 11M + 5S.  Exceptional cases drive Z to 0 (see xyzz_madd).
+SP_HD jac jac_add(const jac& p, const jac& q) {
+  const fe Z1Z1 = fe_sqr(p.Z);
+  const fe Z2Z2 = fe_sqr(q.Z);
+  const fe U1 = fe_mul(p.X, Z2Z2);
+  const fe U2 = fe_mul(q.X, Z1Z1);
+  const fe S1 = fe_mul(fe_mul(p.Y, q.Z), Z2Z2);
+  const fe S2 = fe_mul(fe_mul(q.Y, p.Z), Z1Z1);
+  const fe H = fe_sub(U2, U1);                      // B=1
+  const fe I = fe_dbl(fe_carry(fe_dbl(fe_sqr(H))));  // 4 H^2, B=2 (lazy)
+  const fe J = fe_mul(H, I);
+  const fe rr = fe_carry(fe_dbl(fe_sub(S2, S1)));   // 2 (S2 - S1) -> N
+  const fe V = fe_mul(U1, I);
+  jac r;
+  r.X = fe_carry(fe_sub(fe_sub(fe_sqr(rr), J), fe_dbl(V)));
+  // Y3 = rr (V - X3) - 2 S1 J
+  r.Y = fe_mul_sub_mul(rr, fe_sub(V, r.X), fe_carry(fe_dbl(S1)), J);
+  // Z3 = ((Z1 + Z2)^2 - Z1Z1 - Z2Z2) H
+  const fe t = fe_carry(fe_add(p.Z, q.Z));
+  r.Z = fe_mul(fe_carry(fe_sub(fe_sub(fe_sqr(t), Z1Z1), Z2Z2)), H);
+  return r;
+}
+
 }  // namespace sp

@@ -6,7 +6,7 @@
 // exceptional case.  The group element is the same as  u1*G + u2*Q  with u1 = z w, u2 = r w mod N,
 // which is what this kernel evaluates:
 //   * u1*G  : sum of nwin entries of the EC_GEN window table (XYZZ mixed adds);
-//   * u2*Q  : Jacobian double-and-add on the per-item base point;
+//   * u2*Q  : Jacobian fixed signed-window ladder (w = 4) on the per-item base point;
 //   * x-only public keys (signature.py:229-238) are handled WITHOUT a modular square root (the
 //     field has 2-adicity 192, Tonelli-Shanks would cost more than the rest of the verification):
 //     with c = x^3 + x + beta and a formal Y, Y^2 = c, the multiples of Q = (x, Y) are (a_k, b_k Y),
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(128)
 ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr,
                     const uint64_t* __restrict__ ps, const uint64_t* __restrict__ pqx,
                     const uint64_t* __restrict__ pqy, uint8_t* __restrict__ result, size_t n,
-                    const aff_packed* __restrict__ gen, int wbits, int nwin) {
+                    const aff_packed* __restrict__ gen, int wbits, int nwin, int32_t* __restrict__ tab) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const u256 z = ld_u256(pz + 4 * e), r = ld_u256(pr + 4 * e), s = ld_u256(ps + 4 * e);
@@ -112,19 +112,74 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
   const u256 u1 = fe_pack(fn_from_mont(fn_mul(montn_of(z), w_m)));
   const u256 u2 = fe_pack(fn_from_mont(fn_mul(montn_of(r), w_m)));
 
-  // B' = u2 * base on y^2 = x^3 + a_coef x + ...  (binary double-and-add, MSB first)
-  jac B;
-  B.X = base.x; B.Y = base.y; B.Z = FE_ONE_M;
-  bool started = false;
-  for (int i = 251; i >= 0; --i) {
-    const bool bit = (u2.w[i >> 5] >> (i & 31)) & 1u;
-    if (started) {
-      B = jac_dbl(B, a_coef);
-      if (bit) B = jac_madd(B, base);
-    } else if (bit) {
-      started = true;
+  // B' = u2 * base on y^2 = x^3 + a_coef x + ...  Fixed signed window, w = 4, regular recoding:
+  // for odd k the digits d_i = 2 e_i - 15 (all odd, |d_i| <= 15) are read straight off the 4-bit
+  // windows e_i of E = (k - 1)/2 + 2^255, and the top digit is always +1 - every lane does the
+  // same 252 doublings + 63 additions (no divergent branch; the binary ladder paid a mixed
+  // addition on every bit because some lane always needed one).  Even k uses N - k and flips y.
+  // The eight odd multiples (2j+1)*base live in a per-signature table in HBM, limb-major.
+  const bool flip = (u2.w[0] & 1u) == 0;
+  u256 k = u2;
+  if (flip) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t d = (uint64_t)U256_N.w[i] - u2.w[i] - borrow;
+      k.w[i] = (uint32_t)d;
+      borrow = (d >> 32) & 1u;
     }
   }
+  u256 E;  // (k - 1) / 2 + 2^255   (k odd: k - 1 clears bit 0)
+#pragma unroll
+  for (int i = 0; i < 7; ++i) E.w[i] = (k.w[i] >> 1) | (k.w[i + 1] << 31);
+  E.w[7] = (k.w[7] >> 1) | 0x80000000u;
+  auto tab_at = [&](int entry, int limb) -> int32_t* { return tab + ((size_t)(entry * 27 + limb) * n + e); };
+  auto tab_store = [&](int entry, const jac& P) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      *tab_at(entry, l) = P.X.l[l];
+      *tab_at(entry, 9 + l) = P.Y.l[l];
+      *tab_at(entry, 18 + l) = P.Z.l[l];
+    }
+  };
+  jac B;
+  B.X = base.x; B.Y = base.y; B.Z = FE_ONE_M;
+  {
+    tab_store(0, B);
+    const jac twoQ = jac_dbl(B, a_coef);
+    jac odd = jac_madd(twoQ, base);  // 3Q
+    tab_store(1, odd);
+    for (int j = 2; j < 8; ++j) {
+      odd = jac_add(odd, twoQ);
+      tab_store(j, odd);
+    }
+  }
+  // top window is e = 8  ->  digit +1: start from Q itself, then 63 windows
+  {
+#pragma unroll
+    for (int i = 7; i > 0; --i) E.w[i] = (E.w[i] << 4) | (E.w[i - 1] >> 28);
+    E.w[0] <<= 4;
+  }
+  for (int wi = 0; wi < 63; ++wi) {
+    const uint32_t ew = E.w[7] >> 28;
+#pragma unroll
+    for (int i = 7; i > 0; --i) E.w[i] = (E.w[i] << 4) | (E.w[i - 1] >> 28);
+    E.w[0] <<= 4;
+    const int d = 2 * (int)ew - 15;
+    const int mag = (d < 0 ? -d : d) >> 1;  // table index of |d| = 2 mag + 1
+    jac T;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      T.X.l[l] = *tab_at(mag, l);
+      const int32_t y = *tab_at(mag, 9 + l);
+      T.Y.l[l] = d < 0 ? -y : y;
+      T.Z.l[l] = *tab_at(mag, 18 + l);
+    }
+    B = jac_dbl(jac_dbl(B, a_coef), a_coef);
+    B = jac_dbl(jac_dbl(B, a_coef), a_coef);
+    B = jac_add(B, T);
+  }
+  if (flip) B.Y = fe_neg(B.Y);
   const xyzz A = gen_mul(u1, gen, wbits, nwin);
 
   // one inversion for 1/ZZZ_A, 1/Z_B, 1/c
@@ -227,6 +282,10 @@ ecdsa_sign_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ 
 
 using namespace sp;
 
+static sp::DeviceBuffer g_verify_tab;
+namespace sp {
+void release_ecdsa_state() { g_verify_tab.release(); }
+}
 static inline unsigned nblocks(size_t n, unsigned tpb) { return (unsigned)((n + tpb - 1) / tpb); }
 
 extern "C" {
@@ -237,8 +296,10 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
+  // per-signature table of the eight odd multiples of the key: 8 x 27 limbs, limb-major
+  SP_HIP(g_verify_tab.reserve(n * 8 * 27 * sizeof(int32_t)));
   hipLaunchKernelGGL(ecdsa_verify_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z, r,
-                     s, qx, qy, result, n, c.gen, c.wbits, c.nwin);
+                     s, qx, qy, result, n, c.gen, c.wbits, c.nwin, (int32_t*)g_verify_tab.ptr);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }

@@ -168,6 +168,7 @@ def verify_codes(msg_hashes, rs, ss, public_keys):
     if n == 0:
         return []
     xonly = isinstance(public_keys[0], int)
+    assert all(isinstance(q, int) == xonly for q in public_keys), "mix of x-only and point keys"
     if xonly:
         qx, qy = [int(q) % FIELD_PRIME for q in public_keys], None
     else:

@@ -51,6 +51,19 @@ void t_xyzz_add(const uint32_t* xs, const uint32_t* ys, uint32_t* x, uint32_t* y
       p3{to_m(xs + 24), to_m(ys + 24)};
   xyzz_to_aff_plain(xyzz_add(xyzz_mmadd(p0, p1), xyzz_mmadd(p2, p3)), x, y);
 }
+// Jacobian full addition: (2*P0 + P1') + (P2 via dbl of P2) style mix: computes a*P + b*P style sum
+// via jac_add(jac(k1*P), jac(k2*P)) for small k1, k2 built by doubling/madd
+void t_jac_add(const uint32_t* px, const uint32_t* py, const uint32_t* qx, const uint32_t* qy, uint32_t* x,
+               uint32_t* y) {
+  aff p{to_m(px), to_m(py)}, q{to_m(qx), to_m(qy)};
+  jac a{p.x, p.y, FE_ONE_M}, b{q.x, q.y, FE_ONE_M};
+  a = jac_dbl(a, FE_ONE_M);          // 2P  (Z != 1)
+  b = jac_madd(jac_dbl(b, FE_ONE_M), q);  // 3Q  (Z != 1)
+  jac r = jac_add(a, b);             // 2P + 3Q
+  fe iz = fe_inv(r.Z), iz2 = fe_sqr(iz);
+  from_m(fe_mul(r.X, iz2), x);
+  from_m(fe_mul(r.Y, fe_mul(iz2, iz)), y);
+}
 // Jacobian double-and-add: k * P with plain scalar bits (MSB first), a = 1
 void t_jac_mul(const uint32_t* px, const uint32_t* py, const uint32_t* k, uint32_t* x, uint32_t* y) {
   aff q{to_m(px), to_m(py)};

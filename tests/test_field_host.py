@@ -153,6 +153,16 @@ def test_xyzz_chain_and_add(shim):
     assert (I(x), I(y)) == exp
 
 
+def test_jacobian_full_add(shim):
+    rng = random.Random(12)
+    x = (ctypes.c_uint32 * 8)()
+    y = (ctypes.c_uint32 * 8)()
+    for _ in range(6):
+        p, q = rand_point(rng), rand_point(rng)
+        shim.t_jac_add(W(p[0]), W(p[1]), W(q[0]), W(q[1]), x, y)
+        assert (I(x), I(y)) == R.ec_add(R.ec_mult(2, p), R.ec_mult(3, q))
+
+
 def test_jacobian_ladder(shim):
     rng = random.Random(6)
     x = (ctypes.c_uint32 * 8)()
