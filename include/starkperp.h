@@ -89,6 +89,8 @@ int sp_pedersen_chain_right(const uint64_t* elems, size_t n_elems, uint64_t* out
  * out[i] = H(...H(H(e0,e1),e2)...,e_{depth-1}) */
 int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, uint64_t* out,
                            uint8_t* status, void* stream);
+/* same with host pointers (status: OR of the item status bytes) */
+int sp_pedersen_chains(const uint64_t* elems, size_t width, size_t depth, uint64_t* out, uint8_t* status);
 
 /* ---- Merkle trees with node = pedersen_hash(left, right) ------------------------------------- */
 /* (merkle_multi_update call sites services/perpetual/cairo/state/state.cairo:155-173)           */

@@ -37,7 +37,12 @@ gather_children_kernel(const uint64_t* __restrict__ prev, const int2* __restrict
 }
 
 static DeviceBuffer g_sparse_buf;
-void release_merkle_state() { g_sparse_buf.release(); }
+// empty-subtree roots are a pure function of the empty leaf: cached on the host per leaf value
+static std::map<std::vector<uint64_t>, std::vector<uint64_t>> g_empty_cache;  // leaf -> 65 felts
+void release_merkle_state() {
+  g_sparse_buf.release();
+  g_empty_cache.clear();
+}
 
 }  // namespace sp
 
@@ -94,11 +99,27 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
   int rc = get_scratch_public(nn, s, 0);
   if (rc != SP_OK) return rc;
   SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), 0));
-  // empty-subtree roots: empties[k+1] = H(empties[k], empties[k])
-  SP_HIP(hipMemcpy(d_emp, empty_leaf, 32, hipMemcpyHostToDevice));
-  for (unsigned k = 0; k < height; ++k) {
-    rc = enqueue_pedersen(d_emp + 4 * k, 1, d_emp + 4 * k, 1, d_emp + 4 * (k + 1), 1, nullptr, s.flag, 1, 0, s);
-    if (rc != SP_OK) return rc;
+  // empty-subtree roots: empties[k+1] = H(empties[k], empties[k]); 64 sequential hashes the first
+  // time a given empty leaf is seen, then served from the host-side cache
+  {
+    std::vector<uint64_t> key(empty_leaf, empty_leaf + 4);
+    auto it = g_empty_cache.find(key);
+    if (it == g_empty_cache.end()) {
+      SP_HIP(hipMemcpy(d_emp, empty_leaf, 32, hipMemcpyHostToDevice));
+      uint64_t* d_full = nullptr;
+      SP_HIP(hipMalloc(&d_full, 65 * 32));
+      SP_HIP(hipMemcpy(d_full, empty_leaf, 32, hipMemcpyHostToDevice));
+      for (unsigned k2 = 0; k2 < 64; ++k2) {
+        rc = enqueue_pedersen(d_full + 4 * k2, 1, d_full + 4 * k2, 1, d_full + 4 * (k2 + 1), 1, nullptr, s.flag, 1, 0, s);
+        if (rc != SP_OK) { (void)hipFree(d_full); return rc; }
+      }
+      std::vector<uint64_t> all(65 * 4);
+      SP_HIP(hipDeviceSynchronize());
+      SP_HIP(hipMemcpy(all.data(), d_full, 65 * 32, hipMemcpyDeviceToHost));
+      (void)hipFree(d_full);
+      it = g_empty_cache.emplace(key, all).first;
+    }
+    SP_HIP(hipMemcpy(d_emp, it->second.data(), emp_bytes, hipMemcpyHostToDevice));
   }
   if (n == 0) {
     SP_HIP(hipDeviceSynchronize());

@@ -195,66 +195,6 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
   if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
 }
 
-// One lane finishes a hash on its own: x = X / ZZ, canonical, with status.
-__device__ __forceinline__ void finish_single(const xyzz& acc, const uint64_t* fx, const uint64_t* fy,
-                                              uint64_t* out, uint8_t* status, size_t e, unsigned* flag) {
-  uint8_t st = SP_HASH_OK;
-  if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
-  fe zz = acc.ZZ;
-  if (fe_is_zero(zz)) {
-    zz = FE_ONE_M;
-    st = SP_HASH_UNHASHABLE;
-  }
-  st_u256(out, fe_pack(fe_from_mont(fe_mul(acc.X, fe_inv(zz)))));
-  if (status) status[e] = st;
-  if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
-}
-
-// Fused small-batch kernel (n <= 8192): 8 lanes accumulate one hash, lane 0 of the group inverts
-// and writes the canonical x - one launch per tree level instead of two, no scratch round trip.
-__global__ void __launch_bounds__(256)
-ped_hash_small_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
-                      size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits, int nwin,
-                      uint64_t* __restrict__ out, size_t ostride, uint8_t* __restrict__ status,
-                      unsigned* __restrict__ flag) {
-  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t e_raw = gt >> 3;
-  const int sub = (int)(gt & 7);
-  const bool active = e_raw < n;
-  const size_t e = active ? e_raw : n - 1;
-  const uint64_t* fx = x + 4 * e * xstride;
-  const uint64_t* fy = y + 4 * e * ystride;
-  const xyzz acc = split_accumulate<3>(fx, fy, sub, ped, wbits, nwin);
-  if (!active || sub != 0) return;
-  finish_single(acc, fx, fy, out + 4 * e * ostride, status, e, flag);
-}
-
-// Top of a Merkle tree in ONE launch: a single 512-thread workgroup hashes the levels with
-// 64, 32, ..., 1 nodes (8 lanes per node), synchronising with __syncthreads() between levels
-// (a workgroup's global stores are visible to its own waves after the barrier).
-// `level` points at the 2 * n_first children; parents are appended behind each level.
-__global__ void __launch_bounds__(512)
-ped_tree_top_kernel(uint64_t* __restrict__ level, int n_first, const aff_packed* __restrict__ ped,
-                    int wbits, int nwin, unsigned* __restrict__ flag) {
-  uint64_t* cur = level;
-  for (int n = n_first; n >= 1; n >>= 1) {
-    uint64_t* nxt = cur + 4 * (size_t)(2 * n);
-    const int e_raw = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    // whole waves beyond the level's lanes skip the work (8 nodes per wave)
-    if ((threadIdx.x & ~63) < 8 * n) {
-      const bool active = e_raw < n;
-      const int e = active ? e_raw : n - 1;
-      const uint64_t* fx = cur + 4 * (size_t)(2 * e);
-      const uint64_t* fy = fx + 4;
-      const xyzz acc = split_accumulate<3>(fx, fy, sub, ped, wbits, nwin);
-      if (active && sub == 0) finish_single(acc, fx, fy, nxt + 4 * (size_t)e, nullptr, (size_t)e, flag);
-    }
-    __threadfence_block();
-    __syncthreads();
-    cur = nxt;
-  }
-}
-
 // Kernel B: thread t owns elements t, t+T, t+2T, ...; one inversion per thread.
 __global__ void __launch_bounds__(256)
 ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int32_t* __restrict__ sPre,
@@ -326,12 +266,6 @@ struct KernelProfile {
 };
 static KernelProfile g_prof;
 static bool g_split_enabled = getenv("STARKPERP_NO_SPLIT") == nullptr;  // A/B switches
-// Fused accumulate+invert and the single-launch tree top measured SLOWER than two kernels per level
-// (a lone wave issues v_mad_i64_i32 every ~11 cycles; the separate finish kernel runs its
-// 32-bit divsteps at ~5): kept behind opt-in switches for experiments.
-static bool g_fused_enabled = getenv("STARKPERP_FUSED") != nullptr;
-static bool g_treetop_enabled = getenv("STARKPERP_TREETOP") != nullptr;
-
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
   int32_t *X, *ZZ, *Pre;
@@ -382,20 +316,6 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
   const unsigned blocksA = (unsigned)((n + 255) / 256);
   const bool prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size();
   if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
-  const bool can8 = g_split_enabled && (2 * c.nwin) % 8 == 0 && (2 * c.nwin) / 8 >= 2;
-  if (can8 && n <= 8192 && g_fused_enabled) {
-    // fused accumulate + inversion: one launch, no scratch
-    const unsigned blocks = (unsigned)((8 * n + 255) / 256);
-    hipLaunchKernelGGL(ped_hash_small_kernel, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n, c.ped,
-                       c.wbits, c.nwin, out, os, status, flag);
-    if (prof) {
-      (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
-      g_prof.units.push_back(n);
-      g_prof.used += 2;
-    }
-    SP_HIP(hipGetLastError());
-    return SP_OK;
-  }
   // lanes per hash: fill ~2 waves per SIMD (131072 lanes) before falling back to one lane per hash
   int log_l = 0;
   if (g_split_enabled) {
@@ -558,6 +478,29 @@ int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, ui
   return SP_OK;
 }
 
+// Host-pointer variant of sp_pedersen_chains_dev: one call for `width` chains of `depth` words.
+int sp_pedersen_chains(const uint64_t* elems, size_t width, size_t depth, uint64_t* out, uint8_t* status) {
+  SP_REQUIRE_READY();
+  if (depth < 1) { set_error("chain depth must be >= 1"); return SP_ERR_BAD_ARGUMENT; }
+  if (width == 0) return SP_OK;
+  Context& c = ctx();
+  uint64_t *d_el, *d_out;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    SP_HIP(c.io.reserve((width * depth + width) * 32 + 64));
+    d_el = (uint64_t*)c.io.ptr;
+    d_out = d_el + 4 * width * depth;
+    SP_HIP(hipMemcpy(d_el, elems, width * depth * 32, hipMemcpyHostToDevice));
+  }
+  uint8_t st8 = 0;
+  int rc = sp_pedersen_chains_dev(d_el, width, depth, d_out, &st8, 0);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipDeviceSynchronize());
+  SP_HIP(hipMemcpy(out, d_out, width * 32, hipMemcpyDeviceToHost));
+  if (status) *status = st8;
+  return SP_OK;
+}
+
 int sp_pedersen_chain(const uint64_t* elems, size_t n_elems, uint64_t* out, uint8_t* status) {
   SP_REQUIRE_READY();
   if (n_elems < 1) { set_error("chain needs at least one element"); return SP_ERR_BAD_ARGUMENT; }
@@ -626,15 +569,7 @@ int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void
   if (rc != SP_OK) return rc;
   SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
   uint64_t* cur = levels;
-  const bool can8 = g_split_enabled && g_treetop_enabled && (2 * c.nwin) % 8 == 0 && (2 * c.nwin) / 8 >= 2;
   for (size_t n = n0; n > 1; n >>= 1) {
-    if (can8 && n <= 128) {
-      // the remaining levels (n/2, n/4, ..., 1 parents) in one single-workgroup launch
-      hipLaunchKernelGGL(ped_tree_top_kernel, dim3(1), dim3(512), 0, st, cur, (int)(n / 2), c.ped,
-                         c.wbits, c.nwin, s.flag);
-      SP_HIP(hipGetLastError());
-      break;
-    }
     uint64_t* nxt = cur + 4 * n;
     rc = enqueue_pedersen(cur, 2, cur + 4, 2, nxt, 1, nullptr, s.flag, n / 2, st, s);
     if (rc != SP_OK) return rc;

@@ -33,6 +33,8 @@ _SIGNATURES = {
     "sp_pedersen_point_batch": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_size_t]),
     "sp_pedersen_chain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_pedersen_chain_right": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_pedersen_chains": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
+                                          ctypes.c_void_p]),
     "sp_pedersen_chains_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_merkle_root": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,
@@ -108,10 +110,8 @@ MASK64 = (1 << 64) - 1
 def pack_felts(values):
     """ints (0 <= v < 2^256) -> ctypes uint64 array of 4 LE limbs each."""
     n = len(values)
-    buf = (ctypes.c_uint64 * (4 * n))()
-    raw = b"".join(int(v).to_bytes(32, "little") for v in values)
-    ctypes.memmove(buf, raw, 32 * n)
-    return buf
+    raw = b"".join([int(v).to_bytes(32, "little") for v in values])
+    return (ctypes.c_uint64 * (4 * n)).from_buffer_copy(raw) if n else (ctypes.c_uint64 * 0)()
 
 
 def unpack_felts(buf, n):

@@ -69,16 +69,25 @@ def pedersen_chain_right(elements):
 
 def pedersen_chains_many(chains):
     """Equal-depth chains: [H(...H(H(c[0], c[1]), c[2])..., c[-1]) for c in chains], evaluated
-    level by level across the whole batch (depth - 1 batched launches)."""
+    level by level across the whole batch on the device (depth - 1 batched launches, one host
+    round trip: sp_pedersen_chains)."""
     width = len(chains)
     if width == 0:
         return []
     depth = len(chains[0])
     assert depth >= 2 and all(len(c) == depth for c in chains)
-    acc = pedersen_hash_many([c[0] for c in chains], [c[1] for c in chains])
-    for j in range(2, depth):
-        acc = pedersen_hash_many(acc, [c[j] for c in chains])
-    return acc
+    flat = []
+    for j in range(depth):  # element j of chain i at index j * width + i
+        for c in chains:
+            v = c[j]
+            assert 0 <= v < FIELD_PRIME
+            flat.append(v)
+    lib = _lib.ensure_init()
+    out, st = new_felts(width), new_bytes(1)
+    _lib.check(lib.sp_pedersen_chains(pack_felts(flat), width, depth, out, st), "sp_pedersen_chains")
+    if st[0]:
+        _raise_hash_status(2 if st[0] & 2 else 1)
+    return unpack_felts(out, width)
 
 
 def pedersen_points_many(xs, ys):
