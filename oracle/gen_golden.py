@@ -71,6 +71,29 @@ def _order_msg(args):
     return ref_msgs.get_limit_order_msg(*args)
 
 
+def signature_fixtures(sig_data):
+    """(message_hash, r, s, public_key) tuples held by signature_test_data.json, each with the
+    reference's own verify() verdict (some of those JS-side fixtures are stale and verify False)."""
+    md = sig_data["meta_data"]
+    pairs = {
+        "party_a_order": sig_data["settlement"]["party_a_order"],
+        "party_b_order": sig_data["settlement"]["party_b_order"],
+        "transfer_order": sig_data["transfer_order"],
+        "conditional_transfer_order": sig_data["conditional_transfer_order"],
+        "multi_asset_order": sig_data["multi_asset_order"],
+    }
+    out = {}
+    for name, order in pairs.items():
+        z = int(md[name]["message_hash"], 16)
+        r, s = int(order["signature"]["r"], 16), int(order["signature"]["s"], 16)
+        pub = order.get("public_key")
+        if pub is None:
+            pub = hex(ref.private_to_stark_key(int(md[name]["private_key"], 16)))
+        out[name] = {"message_hash": hex(z), "r": hex(r), "s": hex(s), "public_key": pub,
+                     "reference_verify": bool(ref.verify(z, r, s, int(pub, 16)))}
+    return out
+
+
 def ref_position_hash(pos):
     """position/hash.cairo:22-74 evaluated with the reference's pedersen_hash."""
     public_key, collateral, assets = pos
@@ -131,6 +154,7 @@ def main():
                 "public_key": sig_data["settlement"]["party_a_order"]["public_key"],
                 "signature": sig_data["settlement"]["party_a_order"]["signature"],
             },
+            "signature_fixtures": signature_fixtures(sig_data),
             "keys_precomputed": keys,
             "perpetual_messages": msgs,
             "stark_cli_hash": {

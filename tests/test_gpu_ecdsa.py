@@ -118,6 +118,12 @@ def test_reference_signature_kat(sig):
     assert sig.private_to_stark_key(h(a["private_key"])) == pub
 
 
+def test_reference_signature_fixtures(sig):
+    for name, f in load("reference_kats.json")["signature_fixtures"].items():
+        got = sig.verify(h(f["message_hash"]), h(f["r"]), h(f["s"]), h(f["public_key"]))
+        assert got == f["reference_verify"], name
+
+
 def test_hash_api_arity_and_point(sig):
     g = load("g1_pedersen.json")["arity"]
     assert sig.pedersen_hash() == h(g["zero"]) == sig.SHIFT_POINT[0]

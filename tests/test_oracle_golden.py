@@ -50,6 +50,12 @@ def test_reference_signature_kat():
     assert R.verify(z, r, s, h(a["public_key"]))
 
 
+def test_reference_signature_fixtures():
+    for name, f in load("reference_kats.json")["signature_fixtures"].items():
+        got = R.verify(h(f["message_hash"]), h(f["r"]), h(f["s"]), h(f["public_key"]))
+        assert got == f["reference_verify"], name
+
+
 def test_rfc6979_a25():
     q = 0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551
     x = 0xC9AFA9D845BA75166B5C215767B1D6934E50C3DB36E89B127B8A622B120F6721
