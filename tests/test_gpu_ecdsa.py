@@ -183,3 +183,40 @@ def test_messages(sig):
     assert spm.price_msgs_many(pr) == [R.get_price_msg(*a) for a in pr]
     # the hash_function injection seam still works
     assert pm.get_price_msg(1, 2, 3, 4, hash_function=lambda a, b: a + b) == (2 << 40) + 1 + (4 << 32) + 3
+
+
+def test_verify_random_differential(batch):
+    """Random (mostly invalid) inputs, x-only and point keys: GPU result code == oracle verdict,
+    including which pre-assert fires."""
+    import random
+    rng = random.Random(2024)
+    cases = []
+    good_d = rng.randrange(1, N)
+    good_q = R.private_key_to_ec_point_on_stark_curve(good_d)
+    for i in range(60):
+        z = rng.choice([0, 1, rng.randrange(2**251), rng.randrange(2**251), 2**251 - 1, 2**251 + rng.randrange(100)])
+        r = rng.choice([0, 1, rng.randrange(2**251), 2**251, rng.randrange(2**252)])
+        s = rng.choice([0, 1, rng.randrange(N), N - 1, N, rng.randrange(N, 2**252)])
+        if i % 3 == 0:  # a genuinely valid signature now and then
+            z = rng.randrange(2**251)
+            r, s = R.sign(z, good_d)
+            key = good_q[0] if i % 2 else good_q
+        elif i % 3 == 1:
+            key = rng.randrange(P)  # random x: on the curve about half of the time
+        else:
+            key = good_q if i % 2 else (good_q[0], (good_q[1] + (i % 5 == 0)) % P)
+        cases.append((z, r, s, key))
+
+    def oracle_verdict(z, r, s, key):
+        try:
+            return 1 if R.verify(z, r, s, key) else 0
+        except AssertionError as e:
+            msg = str(e)
+            return {"s": 2, "r": 3, "w": 4, "msg_hash": 5}.get(msg.split(" ")[0], 6) if msg else 6
+
+    for xonly in (True, False):
+        sub = [c for c in cases if isinstance(c[3], int) == xonly]
+        codes = batch.verify_codes([c[0] for c in sub], [c[1] for c in sub], [c[2] for c in sub],
+                                   [c[3] for c in sub])
+        for c, code in zip(sub, codes):
+            assert code == oracle_verdict(*c), c
