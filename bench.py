@@ -51,7 +51,7 @@ def _cpu_hash_chunk(pairs):
     return [ref_py.pedersen_hash(a, b) for a, b in pairs]
 
 
-def cpu_baseline(leaf_ints, budget_s=12.0):
+def cpu_baseline(leaf_ints, budget_s=8.0):
     """Oracle ("port" of the reference algorithm: affine adds, one ext-Euclid inversion each) on
     the first level of the same tree, all host cores, bounded sample."""
     import multiprocessing as mp
@@ -79,6 +79,20 @@ def cpu_baseline(leaf_ints, budget_s=12.0):
         "sample": "first %d node hashes of level 1 of the same 2^16-leaf tree (oracle/ref_py.py, "
                   "multiprocessing over %d cores, %.1f s)" % (n, cores, dt),
     }, flat
+
+
+def cpu_baseline_c(leaf_ints, gpu_root):
+    """Second CPU baseline: the plain-C restatement of the same reference algorithm
+    (oracle/starkref.c: affine adds, one inversion each), OpenMP over the host cores, on the WHOLE
+    2^16-leaf rebuild - which is also a full-size parity check of the timed tree."""
+    from oracle import cref
+    t0 = time.time()
+    levels = cref.merkle_levels(leaf_ints)
+    dt = time.time() - t0
+    return {"value": (len(leaf_ints) - 1) / dt, "unit": "hashes/s", "cores": cref.max_threads(),
+            "kind": "port", "sample": "the complete 2^16-leaf rebuild (65535 hashes) in %.2f s, oracle/starkref.c "
+                                      "with OpenMP" % dt,
+            "root_matches_gpu": levels[-1][0] == gpu_root}
 
 
 def pmc_traffic_per_launch():
@@ -287,6 +301,8 @@ def main():
                 len(cpu_out))
             base["matches_gpu"] = gpu_l1 == cpu_out
             result["cpu_baseline"] = base
+            result["cpu_baseline_c"] = cpu_baseline_c(leaf_ints, _lib.unpack_felts(
+                (ctypes.c_uint64 * 4).from_buffer_copy(levels[-1:].cpu().numpy().astype("<i8").tobytes()), 1)[0])
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,293 @@
+/*
+ * ORACLE (test infrastructure, NOT product code): plain-C restatement of the reference's
+ * Pedersen hash and Stark-curve ECDSA verification, following the reference ALGORITHM step by
+ * step - affine chord/tangent arithmetic with one modular inversion per group operation, LSB-first
+ * 252-step hash loop, three 251-step "mimic the AIR" ladders - so it can serve as the CPU baseline
+ * and as a fast checker at full workload sizes.  Reference (paths under /root/reference/src):
+ *   starkware/crypto/signature/math_utils.py:50-100   div_mod / ec_add / ec_double / ec_mult
+ *   starkware/crypto/signature/signature.py:176-260   mimic_ec_mult_air / verify
+ *   starkware/crypto/signature/signature.py:296-318   pedersen_hash
+ * Parity status: PINNED by tests/test_oracle_c.py against the reference-generated goldens
+ * (tests/golden/g1, g2, g4, g6_c2) - the same vectors that pin oracle/ref_py.py.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * Build: gcc -O3 -fopenmp -shared -fPIC oracle/starkref.c -o oracle/_build/libstarkref.so
+ * Felts are 4 x uint64 little-endian, plain integers.
+ */
+#include <stdint.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t w[4]; } u256;
+
+static const u256 P = {{1ull, 0ull, 0ull, 0x0800000000000011ull}};
+static const u256 N = {{0x1e66a241adc64d2full, 0xb781126dcae7b232ull, 0xffffffffffffffffull, 0x0800000000000010ull}};
+static const u256 BETA = {{0xf4cdfcb99cee9e89ull, 0x609ad26c15c915c1ull, 0x150e596d72f7a8c5ull, 0x06f21413efbe40deull}};
+/* the six independent constant points (pedersen_params.json indices 0, 1, 2, 250, 254, 502) */
+static const u256 PTS[6][2] = {
+  {{{0x551fde4050ca6804ull, 0x716b0b1022947733ull, 0x00ee1b87eb599f16ull, 0x049ee3eba8c16007ull}},
+   {{0xd0405d266e10268aull, 0x4e621062c0e056c1ull, 0xf346d49d06ea0ed3ull, 0x03ca0cfe4b3bc6ddull}}},
+  {{{0x3d723d8bc943cfcaull, 0xdeacfd9b0d1819e0ull, 0x7beced415a40f0c7ull, 0x01ef15c18599971bull}},
+   {{0x2873000c36e8dc1full, 0xde53ecd11abe43a3ull, 0xb7be4801df46ec62ull, 0x005668060aa49730ull}}},
+  {{{0x1080d17957ebe47bull, 0x8fa8120b6d56eb0cull, 0x969c748655fca9e5ull, 0x0234287dcbaffe7full}},
+   {{0x6ed0268ee89e5615ull, 0x940135dd7a6c94ccull, 0x1e889527d41f4e39ull, 0x03b056f100f96fb2ull}}},
+  {{{0xb7a6932dba8aa378ull, 0x99099ec1de5e3018ull, 0x3f9dab2656558f33ull, 0x04fa56f376c83db3ull}},
+   {{0x5168f4e80ff5b54dull, 0x562761f92a7a23b4ull, 0x8113e0c0e47e4401ull, 0x03fa0984c931c9e3ull}}},
+  {{{0x3aa372f0bd2d6997ull, 0x40c690c74709e90full, 0x764910f75b45f74bull, 0x04ba4cc166be8decull}},
+   {{0x48151f27b24b219cull, 0xcac5c59a5ce5ae7cull, 0x4b971e46c4ede85full, 0x0040301cf5c1751full}}},
+  {{{0xd36ff12c49a58202ull, 0x2ca65048d53fb325ull, 0x6e44cca8f61a63bbull, 0x054302dcb0e6cc1cull}},
+   {{0x879dcc77e99c2426ull, 0xce98ad783c25561aull, 0xb348046268d8ae25ull, 0x01b77b3e37d13504ull}}},
+};
+
+/* ---- 256-bit helpers ---- */
+static int is_zero(const u256* a) { return (a->w[0] | a->w[1] | a->w[2] | a->w[3]) == 0; }
+static int cmp(const u256* a, const u256* b) {
+  for (int i = 3; i >= 0; --i) { if (a->w[i] != b->w[i]) return a->w[i] < b->w[i] ? -1 : 1; }
+  return 0;
+}
+static uint64_t add_to(u256* r, const u256* a, const u256* b) {
+  u128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (u128)a->w[i] + b->w[i]; r->w[i] = (uint64_t)c; c >>= 64; }
+  return (uint64_t)c;
+}
+static uint64_t sub_to(u256* r, const u256* a, const u256* b) {
+  uint64_t borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 d = (u128)a->w[i] - b->w[i] - borrow;
+    r->w[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1;
+  }
+  return borrow;
+}
+static void shr1(u256* a, uint64_t top) {
+  for (int i = 0; i < 3; ++i) a->w[i] = (a->w[i] >> 1) | (a->w[i + 1] << 63);
+  a->w[3] = (a->w[3] >> 1) | (top << 63);
+}
+static void addmod(u256* r, const u256* a, const u256* b, const u256* m) {
+  uint64_t c = add_to(r, a, b);
+  if (c || cmp(r, m) >= 0) sub_to(r, r, m);
+}
+static void submod(u256* r, const u256* a, const u256* b, const u256* m) {
+  if (sub_to(r, a, b)) add_to(r, r, m);
+}
+/* plain a*b mod m: 512-bit schoolbook product, then bitwise-free reduction by repeated shifting
+ * would be slow; use Montgomery twice (a*b*R^-1, then * R^2 * R^-1). */
+typedef struct { u256 m; uint64_t n0inv; u256 r2; } modulus;
+static void mont_mul(u256* out, const u256* a, const u256* b, const modulus* md) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a->w[j] * b->w[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+    uint64_t q = t[0] * md->n0inv;
+    c = (u128)q * md->m.w[0] + t[0]; c >>= 64;
+    for (int j = 1; j < 4; ++j) { c += (u128)q * md->m.w[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  u256 r = {{t[0], t[1], t[2], t[3]}};
+  if (t[4] || cmp(&r, &md->m) >= 0) sub_to(&r, &r, &md->m);
+  *out = r;
+}
+static modulus MP, MN;
+static int g_ready = 0;
+static void mulmod(u256* r, const u256* a, const u256* b, const modulus* md) {
+  u256 t; mont_mul(&t, a, b, md); mont_mul(r, &t, &md->r2, md);
+}
+/* R^2 mod m by 512 doublings of 1 */
+static void init_modulus(modulus* md, const u256* m, uint64_t n0inv) {
+  md->m = *m; md->n0inv = n0inv;
+  u256 x = {{1, 0, 0, 0}};
+  for (int i = 0; i < 512; ++i) addmod(&x, &x, &x, m);
+  md->r2 = x;
+}
+/* modular inverse by the binary extended Euclidean algorithm (the role of sympy's igcdex in
+ * math_utils.py:54); returns 0 when a == 0 (gcd != 1 -> the reference asserts). */
+static int invmod(u256* r, const u256* a, const u256* m) {
+  if (is_zero(a)) return 0;
+  u256 u = *a, v = *m, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
+  const u256 one = {{1, 0, 0, 0}};
+  while (cmp(&u, &one) != 0 && cmp(&v, &one) != 0) {
+    while ((u.w[0] & 1) == 0) {
+      shr1(&u, 0);
+      if (x1.w[0] & 1) { uint64_t c = add_to(&x1, &x1, m); shr1(&x1, c); } else shr1(&x1, 0);
+    }
+    while ((v.w[0] & 1) == 0) {
+      shr1(&v, 0);
+      if (x2.w[0] & 1) { uint64_t c = add_to(&x2, &x2, m); shr1(&x2, c); } else shr1(&x2, 0);
+    }
+    if (cmp(&u, &v) >= 0) { sub_to(&u, &u, &v); submod(&x1, &x1, &x2, m); }
+    else { sub_to(&v, &v, &u); submod(&x2, &x2, &x1, m); }
+  }
+  *r = cmp(&u, &one) == 0 ? x1 : x2;
+  return 1;
+}
+
+/* ---- affine group law, math_utils.py:59-88; return 0 where the reference asserts ---- */
+typedef struct { u256 x, y; } point;
+static int ec_add(point* r, const point* a, const point* b) {
+  u256 dx, dy, inv, lam, t;
+  submod(&dx, &a->x, &b->x, &P);
+  if (is_zero(&dx)) return 0;                       /* assert (x1 - x2) % p != 0 */
+  submod(&dy, &a->y, &b->y, &P);
+  invmod(&inv, &dx, &P);
+  mulmod(&lam, &dy, &inv, &MP);
+  mulmod(&t, &lam, &lam, &MP);
+  submod(&t, &t, &a->x, &P); submod(&t, &t, &b->x, &P);
+  u256 y; submod(&y, &a->x, &t, &P); mulmod(&y, &lam, &y, &MP); submod(&y, &y, &a->y, &P);
+  r->x = t; r->y = y;
+  return 1;
+}
+static int ec_double(point* r, const point* a) {
+  if (is_zero(&a->y)) return 0;                     /* assert y != 0 */
+  u256 xx, num, den, inv, lam, t;
+  const u256 one = {{1, 0, 0, 0}};
+  mulmod(&xx, &a->x, &a->x, &MP);
+  addmod(&num, &xx, &xx, &P); addmod(&num, &num, &xx, &P); addmod(&num, &num, &one, &P); /* 3x^2 + alpha */
+  addmod(&den, &a->y, &a->y, &P);
+  invmod(&inv, &den, &P);
+  mulmod(&lam, &num, &inv, &MP);
+  mulmod(&t, &lam, &lam, &MP);
+  submod(&t, &t, &a->x, &P); submod(&t, &t, &a->x, &P);
+  u256 y; submod(&y, &a->x, &t, &P); mulmod(&y, &lam, &y, &MP); submod(&y, &y, &a->y, &P);
+  r->x = t; r->y = y;
+  return 1;
+}
+
+static point CONST_POINTS[506];
+static void init_tables(void) {
+  if (g_ready) return;
+  init_modulus(&MP, &P, 0xffffffffffffffffull);
+  init_modulus(&MN, &N, 0xbb6b3c4ce8bde631ull);
+  CONST_POINTS[0].x = PTS[0][0]; CONST_POINTS[0].y = PTS[0][1];
+  CONST_POINTS[1].x = PTS[1][0]; CONST_POINTS[1].y = PTS[1][1];
+  const int start[4] = {2, 250, 254, 502}, count[4] = {248, 4, 248, 4};
+  for (int b = 0; b < 4; ++b) {
+    point q; q.x = PTS[2 + b][0]; q.y = PTS[2 + b][1];
+    for (int j = 0; j < count[b]; ++j) { CONST_POINTS[start[b] + j] = q; point d; ec_double(&d, &q); q = d; }
+  }
+  g_ready = 1;
+}
+
+/* signature.py:300-318.  status: 0 ok, 1 input out of range, 2 "Unhashable input." */
+static int pedersen_one(const u256* x, const u256* y, u256* out) {
+  if (cmp(x, &P) >= 0 || cmp(y, &P) >= 0) return 1;
+  point acc = CONST_POINTS[0];
+  const u256* el[2] = {x, y};
+  for (int e = 0; e < 2; ++e) {
+    u256 s = *el[e];
+    for (int j = 0; j < 252; ++j) {
+      const point* c = &CONST_POINTS[2 + 252 * e + j];
+      if (cmp(&acc.x, &c->x) == 0) return 2;
+      if (s.w[0] & 1) { point t; ec_add(&t, &acc, c); acc = t; }
+      shr1(&s, 0);
+    }
+  }
+  *out = acc.x;
+  return 0;
+}
+
+/* signature.py:176-190.  returns 0 on any assertion */
+static int mimic_ec_mult_air(point* r, const u256* m_in, const point* pt_in, const point* shift) {
+  static const u256 TWO251 = {{0, 0, 0, 0x0800000000000000ull}};
+  if (is_zero(m_in) || cmp(m_in, &TWO251) >= 0) return 0;
+  u256 m = *m_in; point acc = *shift, pt = *pt_in;
+  for (int i = 0; i < 251; ++i) {
+    if (cmp(&acc.x, &pt.x) == 0) return 0;
+    if (m.w[0] & 1) { point t; if (!ec_add(&t, &acc, &pt)) return 0; acc = t; }
+    point d; if (!ec_double(&d, &pt)) return 0; pt = d;
+    shr1(&m, 0);
+  }
+  if (!is_zero(&m)) return 0;
+  *r = acc;
+  return 1;
+}
+static int on_curve(const point* q) {
+  u256 l, r3, t;
+  mulmod(&l, &q->y, &q->y, &MP);
+  mulmod(&t, &q->x, &q->x, &MP); mulmod(&r3, &t, &q->x, &MP);
+  addmod(&r3, &r3, &q->x, &P); addmod(&r3, &r3, &BETA, &P);
+  return cmp(&l, &r3) == 0;
+}
+/* verify with a point key, signature.py:217-260.  codes as include/starkperp.h SP_VERIFY_* */
+static int verify_point(const u256* z, const u256* r, const u256* s, const point* q) {
+  static const u256 TWO251 = {{0, 0, 0, 0x0800000000000000ull}};
+  if (is_zero(s) || cmp(s, &N) >= 0) return 2;
+  u256 w; invmod(&w, s, &N);
+  if (is_zero(r) || cmp(r, &TWO251) >= 0) return 3;
+  if (is_zero(&w) || cmp(&w, &TWO251) >= 0) return 4;
+  if (cmp(z, &TWO251) >= 0) return 5;
+  if (!on_curve(q)) return 6;
+  point shift = CONST_POINTS[0], mshift = CONST_POINTS[0], zg, rq, b, wb, fin;
+  sub_to(&mshift.y, &P, &shift.y);
+  if (!mimic_ec_mult_air(&zg, z, &CONST_POINTS[1], &mshift)) return 0;
+  if (!mimic_ec_mult_air(&rq, r, q, &shift)) return 0;
+  if (!ec_add(&b, &zg, &rq)) return 0;
+  if (!mimic_ec_mult_air(&wb, &w, &b, &shift)) return 0;
+  if (!ec_add(&fin, &wb, &mshift)) return 0;
+  return cmp(r, &fin.x) == 0 ? 1 : 0;
+}
+
+/* ---- exported batch entry points ---- */
+void cref_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n) {
+  init_tables();
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long i = 0; i < (long)n; ++i) {
+    u256 a, b, o = {{0, 0, 0, 0}};
+    memcpy(&a, x + 4 * i, 32); memcpy(&b, y + 4 * i, 32);
+    status[i] = (uint8_t)pedersen_one(&a, &b, &o);
+    memcpy(out + 4 * i, &o, 32);
+  }
+}
+/* full rebuild over 2^height leaves; levels holds 2^(height+1) - 1 felts, leaves first */
+void cref_merkle_build(uint64_t* levels, unsigned height) {
+  init_tables();
+  uint64_t* cur = levels;
+  for (size_t n = (size_t)1 << height; n > 1; n >>= 1) {
+    uint64_t* nxt = cur + 4 * n;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long i = 0; i < (long)(n / 2); ++i) {
+      u256 a, b, o = {{0, 0, 0, 0}};
+      memcpy(&a, cur + 8 * i, 32); memcpy(&b, cur + 8 * i + 4, 32);
+      pedersen_one(&a, &b, &o);
+      memcpy(nxt + 4 * i, &o, 32);
+    }
+    cur = nxt;
+  }
+}
+/* private_key_to_ec_point_on_stark_curve (signature.py:104-106) by the recursion shape of
+ * ec_mult (math_utils.py:91-100): double the base while the scalar is even, add on odd. */
+void cref_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, size_t n) {
+  init_tables();
+#pragma omp parallel for schedule(dynamic, 4)
+  for (long i = 0; i < (long)n; ++i) {
+    u256 m; memcpy(&m, d + 4 * i, 32);
+    point base = CONST_POINTS[1], pend[512]; int np = 0;
+    const u256 one = {{1, 0, 0, 0}};
+    while (cmp(&m, &one) != 0) {
+      if ((m.w[0] & 1) == 0) { shr1(&m, 0); point t; ec_double(&t, &base); base = t; }
+      else { m.w[0] -= 1; pend[np++] = base; }
+    }
+    point acc = base;
+    for (int k = np - 1; k >= 0; --k) { point t; ec_add(&t, &acc, &pend[k]); acc = t; }
+    memcpy(qx + 4 * i, &acc.x, 32); memcpy(qy + 4 * i, &acc.y, 32);
+  }
+}
+/* verify with point keys; result codes as SP_VERIFY_* */
+void cref_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* s, const uint64_t* qx,
+                       const uint64_t* qy, uint8_t* result, size_t n) {
+  init_tables();
+#pragma omp parallel for schedule(dynamic, 1)
+  for (long i = 0; i < (long)n; ++i) {
+    u256 a, b, c; point q;
+    memcpy(&a, z + 4 * i, 32); memcpy(&b, r + 4 * i, 32); memcpy(&c, s + 4 * i, 32);
+    memcpy(&q.x, qx + 4 * i, 32); memcpy(&q.y, qy + 4 * i, 32);
+    result[i] = (uint8_t)verify_point(&a, &b, &c, &q);
+  }
+}
+int cref_max_threads(void) {
+#ifdef _OPENMP
+  extern int omp_get_max_threads(void);
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

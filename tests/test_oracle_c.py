@@ -1,0 +1,56 @@
+"""Pins the C oracle (oracle/starkref.c) against the reference-generated goldens and against the
+Python oracle; it is what makes full-size CPU checks and the cpu_baseline leg fast."""
+import json
+import os
+
+import workloads as wl
+from oracle import cref
+from oracle import ref_py as R
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+P = R.FIELD_PRIME
+
+
+def load(name):
+    return json.load(open(os.path.join(GOLD, name)))
+
+
+def h(s):
+    return int(s, 16)
+
+
+def test_pedersen_full_golden_and_edges():
+    g = load("g1_pedersen.json")
+    pairs = wl.pedersen_pairs(g["n"], seed=g["seed"])
+    out, st = cref.pedersen_hash_many([p[0] for p in pairs], [p[1] for p in pairs])
+    assert not any(st) and out == [h(v) for v in g["all"]]
+    xs, ys, exp = zip(*[(h(a), h(b), h(o)) for a, b, o in g["edge"]])
+    out, st = cref.pedersen_hash_many(xs, ys)
+    assert not any(st) and out == list(exp)
+    out, st = cref.pedersen_hash_many([P, 1], [0, P + 5])
+    assert st == [1, 1]
+    k = load("reference_kats.json")
+    for case in k["hash_test"].values():
+        assert cref.pedersen_hash_many([h(case["input_1"])], [h(case["input_2"])])[0] == [h(case["output"])]
+
+
+def test_c2_full_tree_matches_reference():
+    g = load("g6_c2_tree.json")
+    levels = cref.merkle_levels(wl.leaves(1 << 16, seed=g["seed"]))
+    assert levels[-1][0] == h(g["root"])
+    assert [wl.digest_felts(l) for l in levels] == g["level_digests"]
+
+
+def test_public_keys():
+    keys = load("g2_keys.json")["keys"]
+    assert cref.public_keys_many([h(d) for d, _, _ in keys]) == [(h(x), h(y)) for _, x, y in keys]
+
+
+def test_verify_point_key_cases():
+    cases = [c for c in load("g4_verify.json")["cases"] if isinstance(c["key"], list)]
+    codes = cref.verify_codes([h(c["z"]) for c in cases], [h(c["r"]) for c in cases],
+                              [h(c["s"]) for c in cases], [(h(c["key"][0]), h(c["key"][1])) for c in cases])
+    names = {2: "assert:s", 3: "assert:r", 4: "assert:w", 5: "assert:msg_hash", 6: "assert:"}
+    for c, code in zip(cases, codes):
+        got = {0: "false", 1: "true"}.get(code) or names[code]
+        assert got == c["expect"], c["label"]
