@@ -220,3 +220,26 @@ def test_verify_random_differential(batch):
                                    [c[3] for c in sub])
         for c, code in zip(sub, codes):
             assert code == oracle_verdict(*c), c
+
+
+def test_verify_1024_vs_c_oracle(batch):
+    """A thousand signatures (valid and corrupted) against the C oracle's three-ladder verify."""
+    import random
+    from oracle import cref
+    rng = random.Random(5150)
+    n = 1024
+    ds = [rng.randrange(1, N) for _ in range(n)]
+    zs = [rng.randrange(2**251) for _ in range(n)]
+    ks = [rng.randrange(1, N) for _ in range(n)]
+    pubs = batch.public_keys_many(ds)
+    assert pubs[:64] == cref.public_keys_many(ds[:64])
+    rs, ss, st = batch.sign_attempt_many(zs, ds, ks)
+    assert st.count(0) == n
+    for i in range(0, n, 3):
+        ss[i] = (ss[i] % (N - 1)) + 1
+    for i in range(1, n, 7):
+        zs[i] = (zs[i] + 1) % 2**251
+    exp = cref.verify_codes(zs, rs, ss, pubs)
+    assert 200 < exp.count(1) < n
+    assert batch.verify_codes(zs, rs, ss, pubs) == exp
+    assert batch.verify_codes(zs, rs, ss, [q[0] for q in pubs]) == exp

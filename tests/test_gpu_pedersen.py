@@ -108,3 +108,16 @@ def test_shutdown_and_reinit_with_other_window(batch):
         assert batch.merkle_root(lv) == h(load("g6_merkle.json")["roots_seed_100_plus_h"]["8"])
     lib.sp_shutdown()
     _lib.ensure_init()
+
+
+def test_bulk_and_split_paths_vs_c_oracle(batch):
+    """Every accumulate variant (1, 2, 4, 8 lanes per hash are picked by batch size) against the C
+    oracle on seeded inputs, plus out-of-range status propagation inside a large batch."""
+    from oracle import cref
+    rng = random.Random(77)
+    for n in (70000, 40000, 20000, 3000):
+        xs = [rng.randrange(P) for _ in range(n)]
+        ys = [rng.randrange(P) for _ in range(n)]
+        exp, st = cref.pedersen_hash_many(xs, ys)
+        assert not any(st)
+        assert batch.pedersen_hash_many(xs, ys) == exp, n
