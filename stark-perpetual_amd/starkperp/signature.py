@@ -108,21 +108,13 @@ def inv_mod_curve_size(x: int) -> int:
 
 
 def generate_k_rfc6979(msg_hash: int, priv_key: int, seed: Optional[int] = None) -> int:
-    """:117-134."""
-    # One-nibble pad for consistency with elliptic.js (:119-121).
-    if 1 <= msg_hash.bit_length() % 8 <= 4 and msg_hash.bit_length() >= 248:
-        msg_hash *= 16
-    if seed is None:
-        extra_entropy = b""
-    else:
-        extra_entropy = seed.to_bytes(math.ceil(seed.bit_length() / 8), "big")
-    return generate_k(
-        EC_ORDER,
-        priv_key,
-        hashlib.sha256,
-        msg_hash.to_bytes(math.ceil(msg_hash.bit_length() / 8), "big"),
-        extra_entropy=extra_entropy,
-    )
+    """:117-134.  RFC 6979 nonce for (message, key); `seed` becomes the extra entropy of the retry."""
+    bits = msg_hash.bit_length()
+    if bits >= 248 and 1 <= bits % 8 <= 4:
+        msg_hash <<= 4  # one-nibble pad, elliptic.js convention (:119-121)
+    entropy = b"" if seed is None else seed.to_bytes((seed.bit_length() + 7) // 8, "big")
+    message = msg_hash.to_bytes((msg_hash.bit_length() + 7) // 8, "big")
+    return generate_k(EC_ORDER, priv_key, hashlib.sha256, message, extra_entropy=entropy)
 
 
 def sign(msg_hash: int, priv_key: int, seed: Optional[int] = None) -> ECSignature:
@@ -133,17 +125,17 @@ def sign(msg_hash: int, priv_key: int, seed: Optional[int] = None) -> ECSignatur
 
 
 def mimic_ec_mult_air(m: int, point: ECPoint, shift_point: ECPoint) -> ECPoint:
-    """:176-190.  Kept for API compatibility (Python ints); verify() uses the GPU kernel."""
+    """:176-190: m * point + shift_point the way the AIR does it (LSB first, always double, assert
+    on every x-collision).  Python-int helper kept for API compatibility; verify() runs on the GPU."""
     assert 0 < m < 2**N_ELEMENT_BITS_ECDSA
-    partial_sum = shift_point
-    for _ in range(N_ELEMENT_BITS_ECDSA):
-        assert partial_sum[0] != point[0]
-        if m & 1:
-            partial_sum = ec_add(partial_sum, point, FIELD_PRIME)
-        point = ec_double(point, ALPHA, FIELD_PRIME)
-        m >>= 1
-    assert m == 0
-    return partial_sum
+    acc, base = shift_point, point
+    for step in range(N_ELEMENT_BITS_ECDSA):
+        assert acc[0] != base[0]
+        if (m >> step) & 1:
+            acc = ec_add(acc, base, FIELD_PRIME)
+        base = ec_double(base, ALPHA, FIELD_PRIME)
+    assert m >> N_ELEMENT_BITS_ECDSA == 0
+    return acc
 
 
 def is_point_on_curve(x: int, y: int) -> bool:
@@ -172,18 +164,19 @@ def verify(msg_hash: int, r: int, s: int, public_key: Union[int, ECPoint]) -> bo
     return code == batch.VERIFY_TRUE
 
 
-def grind_key(key_seed: int, key_value_limit: int) -> int:  # type: ignore[return]
-    """:263-288 - sha256 rejection sampling, host only."""
-    max_allowed_value = 2**256 - (2**256 % key_value_limit)
+def grind_key(key_seed: int, key_value_limit: int) -> int:
+    """:263-288: sha256(seed || index) rejection sampling to a uniform value below the limit
+    (host only; minimal-length big-endian encodings, at least one byte, like the JS twin)."""
+    ceiling = (2**256 // key_value_limit) * key_value_limit  # largest multiple of the limit
 
-    def to_bytes_no_pad(x: int) -> bytes:
-        return x.to_bytes(length=max(1, (x.bit_length() + 7) // 8), byteorder="big", signed=False)
+    def minimal_bytes(value: int) -> bytes:
+        return value.to_bytes(max(1, (value.bit_length() + 7) // 8), "big")
 
+    prefix = minimal_bytes(key_seed)
     for index in itertools.count():
-        digest = hashlib.sha256(to_bytes_no_pad(key_seed) + to_bytes_no_pad(index)).hexdigest()
-        key = int(digest, 16)
-        if key < max_allowed_value:
-            return key % key_value_limit
+        candidate = int.from_bytes(hashlib.sha256(prefix + minimal_bytes(index)).digest(), "big")
+        if candidate < ceiling:
+            return candidate % key_value_limit
 
 
 def pedersen_hash(*elements: int) -> int:
