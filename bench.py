@@ -3,12 +3,14 @@
 bench.py - headline benchmark of the MI355X hot path (contract: see the build brief).
 
 A "step" is one rebuild of a 2^16-leaf Pedersen Merkle tree per GPU (BASELINE.json configs[1]:
-"2^16-leaf position-tree Merkle rebuild"), inputs resident in HBM.  With N > 1 ranks the job is a
-tree of N * 2^16 leaves: every rank rebuilds its own 2^16-leaf subtree (no data-path collective),
-then the N sub-roots are exchanged with one RCCL all_gather (N x 32 bytes) and the log2(N) top
-levels are hashed on every rank - weak scaling.
+"2^16-leaf position-tree Merkle rebuild"), inputs resident in HBM.  Steps are independent, so the K
+steps are advanced in lockstep groups of (by default) 16 trees per library call - the upper levels
+of one rebuild are latency-bound and would leave most of the chip idle.  With N > 1 ranks every
+step is a tree of N * 2^16 leaves: each rank rebuilds its own 2^16-leaf subtree (no data-path
+collective), the N sub-roots are exchanged with one RCCL all_gather (N x 32 bytes per tree) and the
+log2(N) top levels are hashed on every rank - weak scaling.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 64 --warmup 16
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -24,9 +26,8 @@ import os
 import sys
 import time
 
-# 16 independent trees are kept in flight on 16 HIP streams; the runtime default of 4 hardware
-# queues would serialise them (measured: 4 queues 1.2e8, 16 queues 1.9e8 hashes/s, 32 worse).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# One hardware queue per HIP stream in use (the runtime default of 4 is enough for the default 2).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "stark-perpetual_amd"))
@@ -110,18 +111,19 @@ def pmc_traffic_per_launch():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=16,
-                    help="HIP streams the K steps are issued on round-robin (independent trees "
-                         "overlap: the upper levels of one rebuild are latency-bound and leave most "
-                         "of the chip idle); 1 = strictly one tree at a time")
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--trees-per-call", type=int, default=16,
+                    help="independent 2^16-leaf rebuilds advanced in lockstep by one library call "
+                         "(sp_merkle_forest_dev: one launch pair per level serves all of them; the upper "
+                         "levels of a single rebuild are latency-bound and leave most of the chip idle); "
+                         "1 = strictly one tree per call")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the lockstep calls are issued on round-robin")
     ap.add_argument("--workload", choices=["merkle", "airfri"], default="merkle",
                     help="merkle = BASELINE.json configs[1] (default, the headline line); airfri = one "
                          "2^20-row AIR+FRI commit job per GPU per step (configs[3]; with N GPUs the "
                          "N * 2^20-row trace of configs[4] as disjoint row ranges, roots combined over RCCL)")
-    ap.add_argument("--no-graphs", dest="graphs", action="store_false",
-                    help="issue every launch eagerly instead of replaying one hipGraph per tree")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -145,60 +147,65 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from starkperp import _lib
-    from starkperp.distributed import combine_subroots_dev
 
     lib = _lib.ensure_init(local_rank)
     if args.workload == "airfri":
         return run_airfri(args, torch, dist, lib, _lib, dev, rank, world)
     n_leaves = 1 << HEIGHT
     n_streams = max(1, args.streams)
+    log_b = max(0, min(6, int(args.trees_per_call).bit_length() - 1))
+    B = 1 << log_b  # independent rebuilds advanced in lockstep by one sp_merkle_forest_dev call
+
+    def forest_felts(lt):
+        return sum(1 << (HEIGHT + lt - k) for k in range(HEIGHT + 1))
+
     leaves = seeded_felts(torch, n_leaves, 1000 + rank, dev)
     slots = []
     for si in range(n_streams):
-        lv = torch.zeros((2 * n_leaves - 1, 4), dtype=torch.int64, device=dev)
-        lv[:n_leaves] = leaves
+        lv = torch.zeros((forest_felts(log_b), 4), dtype=torch.int64, device=dev)
+        lv[: B * n_leaves] = leaves.repeat(B, 1)  # every tree of the forest gets the same seeded leaves
         slots.append({
             "levels": lv,
-            "gathered": torch.zeros((max(world, 1), 4), dtype=torch.int64, device=dev),
-            "top": torch.zeros((2 * max(world, 1) - 1, 4), dtype=torch.int64, device=dev),
+            "gathered": torch.zeros((max(world, 1), B, 4), dtype=torch.int64, device=dev),
+            "top": torch.zeros((2 * max(world, 1) * B - B, 4), dtype=torch.int64, device=dev),
             "stream": torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream(device=dev),
         })
     levels = slots[0]["levels"]
     stream = torch.cuda.current_stream().cuda_stream
-    step_counter = [0]
+    call_counter = [0]
 
-    def run_slot(sl):
-        h = sl["stream"].cuda_stream
-        _lib.check(lib.sp_merkle_build_dev(sl["levels"].data_ptr(), HEIGHT, None, h), "merkle")
-        if world > 1:
-            combine_subroots_dev(lib, dist, sl["levels"][-1], sl["gathered"], sl["top"], h)
-
-    # The ~35 launches of one rebuild are captured once per slot into a hipGraph and replayed:
-    # with several trees in flight the eager path is host-launch bound (~0.6 ms of API calls per tree).
-    use_graphs = args.graphs and world == 1 and n_streams > 1
-    if n_streams > 1:
-        for sl in slots:  # size per-stream scratch up front (no allocation inside a capture / the timed region)
-            with torch.cuda.stream(sl["stream"]):
-                run_slot(sl)
-        torch.cuda.synchronize()
-
-    def capture_graphs():
-        for sl in slots:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=sl["stream"]):
-                run_slot(sl)
-            sl["graph"] = g
-
-    def step():
-        nonlocal use_graphs
-        sl = slots[step_counter[0] % n_streams]
-        step_counter[0] += 1
-        if use_graphs:
-            with torch.cuda.stream(sl["stream"]):
-                sl["graph"].replay()
-            return
+    def issue(lt):
+        """One lockstep call: 2^lt complete 2^16-leaf rebuilds (+ the cross-rank combine)."""
+        sl = slots[call_counter[0] % n_streams]
+        call_counter[0] += 1
+        nb = 1 << lt
         with torch.cuda.stream(sl["stream"]):
-            run_slot(sl)
+            h = sl["stream"].cuda_stream
+            _lib.check(lib.sp_merkle_forest_dev(sl["levels"].data_ptr(), lt, HEIGHT, None, h), "forest")
+            if world > 1:
+                # roots of this rank's nb trees are the last nb felts of its (2^lt)-tree forest
+                off = forest_felts(lt) - nb
+                roots = sl["levels"][off : off + nb]
+                g = sl["gathered"][:, :nb]
+                if nb == B:
+                    dist.all_gather_into_tensor(g.reshape(world * nb, 4), roots)
+                else:
+                    tmp = torch.empty((world * nb, 4), dtype=torch.int64, device=dev)
+                    dist.all_gather_into_tensor(tmp, roots.contiguous())
+                    g = tmp.reshape(world, nb, 4)
+                # job tree j = sub-roots of tree j from every rank: forest of nb trees of height log2(world)
+                top = sl["top"]
+                top[: world * nb] = g.transpose(0, 1).reshape(world * nb, 4)
+                _lib.check(lib.sp_merkle_forest_dev(top.data_ptr(), lt, world.bit_length() - 1, None, h), "combine")
+
+    def plan(k):
+        """K steps (trees) as lockstep calls of <= B trees: greedy powers of two."""
+        out = []
+        while k > 0:
+            lt = min(log_b, k.bit_length() - 1)
+            out.append(lt)
+            k -= 1 << lt
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -206,29 +213,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    launches_per_step = HEIGHT + 8
-    if use_graphs:
-        capture_graphs()
-    for _ in range(args.warmup):
-        step()
+    for sl in slots:  # size every stream's scratch before the timed region
+        issue(log_b)
+    for lt in plan(args.warmup):
+        issue(lt)
     fence()
-    if not use_graphs:
-        _lib.check(lib.sp_profile_begin(args.steps * launches_per_step), "profile_begin")
+    timed_plan = plan(args.steps)
+    launches_per_call = HEIGHT + 8
+    _lib.check(lib.sp_profile_begin(len(timed_plan) * launches_per_call), "profile_begin")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for lt in timed_plan:
+        issue(lt)
     fence()
     elapsed = time.perf_counter() - t0
-    if use_graphs:
-        # HIP events captured into a graph cannot be read back (hipEventElapsedTime: invalid
-        # resource handle), so the dominant kernel is timed by re-issuing the same K steps eagerly
-        # on the same streams right after the timed region - same kernels, same overlap pattern.
-        use_graphs = False
-        _lib.check(lib.sp_profile_begin(args.steps * launches_per_step), "profile_begin")
-        for _ in range(args.steps):
-            step()
-        fence()
-        use_graphs = True
     k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
     _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)),
                "profile_end")
@@ -262,8 +259,8 @@ def main():
                 "tree_height": HEIGHT,
                 "leaves_per_gpu": n_leaves,
                 "hashes_per_step": hashes_per_step,
+                "trees_per_call": B,
                 "streams": n_streams,
-                "hip_graphs": bool(use_graphs),
                 "window_bits": int(lib.sp_window_bits()),
                 "table_mib": lib.sp_table_bytes() / 2**20,
                 "combine": "none" if world == 1 else "all_gather of %d sub-roots (RCCL) + %d top hashes" % (
@@ -279,9 +276,7 @@ def main():
                 "traffic": pmc_traffic_per_launch(),
                 "launches": int(k_launches.value),
                 "avg_launch_us": avg_launch_s * 1e6,
-                "timing": ("HIP events around every launch, eager re-issue of the same K steps after the "
-                           "graph-replayed timed region") if use_graphs else
-                          "HIP events around every launch inside the timed region",
+                "timing": "HIP events around every launch inside the timed region",
                 "note": "integer-ALU bound kernel (DESIGN.md): ~2.9e3 v_mad_i64_i32 per window add; "
                         "HBM fraction is reported because the contract asks for it",
             },

@@ -557,19 +557,26 @@ int sp_pedersen_chain_right(const uint64_t* elems, size_t n_elems, uint64_t* out
   return SP_OK;
 }
 
-int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void* stream) {
+// Forest of 2^log_trees independent trees of the given height, built in lockstep: the leaves of
+// all trees are concatenated (tree t owns leaves [t 2^height, (t+1) 2^height)), so level k of the
+// forest is one contiguous array of 2^(log_trees + height - k) nodes and ONE launch pair per level
+// serves every tree.  Stops after `height` levels: the last level holds the 2^log_trees roots.
+// Buffer: sum_{k=0..height} 2^(log_trees + height - k) felts, level-major, leaves first.
+int sp_merkle_forest_dev(uint64_t* levels, unsigned log_trees, unsigned height, uint8_t* status,
+                         void* stream) {
   SP_REQUIRE_READY();
-  if (height > 40) { set_error("height too large for a full rebuild"); return SP_ERR_BAD_ARGUMENT; }
+  if (height + log_trees > 40) { set_error("forest too large"); return SP_ERR_BAD_ARGUMENT; }
   Context& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   hipStream_t st = (hipStream_t)stream;
-  const size_t n0 = (size_t)1 << height;
+  const size_t n0 = (size_t)1 << (height + log_trees);
   Scratch s;
   int rc = get_scratch(n0 / 2 + 1, s, st);
   if (rc != SP_OK) return rc;
   SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
   uint64_t* cur = levels;
-  for (size_t n = n0; n > 1; n >>= 1) {
+  size_t n = n0;
+  for (unsigned k = 0; k < height; ++k, n >>= 1) {
     uint64_t* nxt = cur + 4 * n;
     rc = enqueue_pedersen(cur, 2, cur + 4, 2, nxt, 1, nullptr, s.flag, n / 2, st, s);
     if (rc != SP_OK) return rc;
@@ -577,6 +584,10 @@ int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void
   }
   if (status) SP_HIP(hipMemcpyAsync(status, s.flag, 1, hipMemcpyDeviceToHost, st));
   return SP_OK;
+}
+
+int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void* stream) {
+  return sp_merkle_forest_dev(levels, 0, height, status, stream);
 }
 
 int sp_merkle_root(const uint64_t* leaves, unsigned height, uint64_t* root, uint64_t* levels_out,

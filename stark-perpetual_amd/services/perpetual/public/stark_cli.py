@@ -12,6 +12,9 @@ import os
 import sys
 import traceback
 
+# the CLI never uses torch: stay on the system HIP runtime (keeps stderr empty, see starkperp._lib)
+os.environ.setdefault("STARKPERP_SKIP_TORCH_RUNTIME", "1")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", "..", ".."))  # .../stark-perpetual_amd
 if _PKG_ROOT not in sys.path:

@@ -40,6 +40,8 @@ _SIGNATURES = {
     "sp_merkle_root": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p]),
     "sp_merkle_build_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_merkle_forest_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p,
+                                            ctypes.c_void_p]),
     "sp_merkle_sparse_root": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                              ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p]),
@@ -63,6 +65,29 @@ def declared_symbols():
     return sorted(_SIGNATURES)
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so with the same
+    SONAME as /opt/rocm's; whichever is loaded first serves both.  If libstarkperp pulled in the
+    system runtime first, a later `import torch` would bind its kernels to it and report
+    "No HIP GPUs are available".  So when torch is installed, its runtime is loaded first
+    (without importing torch); without torch the system runtime is used."""
+    import importlib.util
+    if os.environ.get("STARKPERP_SKIP_TORCH_RUNTIME"):  # processes that never touch torch (the CLI)
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen the library and attach prototypes (does not touch the GPU)."""
     global _lib
@@ -72,6 +97,7 @@ def load():
                 raise StarkPerpError(
                     "libstarkperp.so not built (%s); run `python __graft_entry__.py` or "
                     "`make -C stark-perpetual_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+            _preload_torch_hip_runtime()
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in _SIGNATURES.items():
                 fn = getattr(lib, name, None)

@@ -144,6 +144,34 @@ def merkle_root(leaves):
     return unpack_felts(root, 1)[0]
 
 
+def merkle_roots_many(trees):
+    """Roots of 2^k independent trees of equal power-of-two size, built in lockstep
+    (sp_merkle_forest_dev: one launch pair per level for all trees)."""
+    import torch  # device staging for the forest buffer
+    count = len(trees)
+    assert count >= 1 and count & (count - 1) == 0
+    n = len(trees[0])
+    assert n >= 1 and n & (n - 1) == 0 and all(len(t) == n for t in trees)
+    height, log_trees = n.bit_length() - 1, count.bit_length() - 1
+    flat = [v for t in trees for v in t]
+    for v in flat:
+        assert 0 <= v < FIELD_PRIME
+    lib = _lib.ensure_init()
+    total = sum(1 << (height + log_trees - k) for k in range(height + 1))
+    import numpy as np
+    raw = b"".join(int(v).to_bytes(32, "little") for v in flat)
+    buf = torch.zeros((total, 4), dtype=torch.int64, device="cuda")
+    buf[: len(flat)] = torch.from_numpy(np.frombuffer(raw, dtype="<i8").reshape(len(flat), 4).copy()).cuda()
+    st = new_bytes(1)
+    _lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), log_trees, height, st,
+                                        torch.cuda.current_stream().cuda_stream), "sp_merkle_forest_dev")
+    torch.cuda.synchronize()
+    if st[0]:
+        _raise_hash_status(2 if st[0] & 2 else 1)
+    rootraw = buf[total - count :].cpu().numpy().astype("<i8").tobytes()
+    return [int.from_bytes(rootraw[32 * i : 32 * i + 32], "little") for i in range(count)]
+
+
 def merkle_sparse_root(height, modifications, empty_leaf=0):
     """Root of the height-`height` tree (<= 64) holding {index: leaf} and `empty_leaf` elsewhere:
     the multi-update walk of starkware/python/merkle_tree.py:4-26 with every hash on the GPU."""
