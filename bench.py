@@ -160,17 +160,31 @@ def main():
         return sum(1 << (HEIGHT + lt - k) for k in range(HEIGHT + 1))
 
     leaves = seeded_felts(torch, n_leaves, 1000 + rank, dev)
+
+    def plan(k):
+        """K steps (trees) as lockstep calls of <= B trees: greedy powers of two."""
+        out = []
+        while k > 0:
+            lt = min(log_b, k.bit_length() - 1)
+            out.append(lt)
+            k -= 1 << lt
+        return out
+
+    sizes = sorted(set([log_b] + plan(args.warmup) + plan(args.steps)))
     slots = []
     for si in range(n_streams):
-        lv = torch.zeros((forest_felts(log_b), 4), dtype=torch.int64, device=dev)
-        lv[: B * n_leaves] = leaves.repeat(B, 1)  # every tree of the forest gets the same seeded leaves
+        bufs = {}
+        for lt in sizes:  # one forest buffer per call size, every tree seeded with the same leaves
+            lv = torch.zeros((forest_felts(lt), 4), dtype=torch.int64, device=dev)
+            lv[: n_leaves << lt] = leaves.repeat(1 << lt, 1)
+            bufs[lt] = lv
         slots.append({
-            "levels": lv,
-            "gathered": torch.zeros((max(world, 1), B, 4), dtype=torch.int64, device=dev),
+            "levels": bufs,
+            "gathered": torch.zeros((max(world, 1) * B, 4), dtype=torch.int64, device=dev),
             "top": torch.zeros((2 * max(world, 1) * B - B, 4), dtype=torch.int64, device=dev),
             "stream": torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream(device=dev),
         })
-    levels = slots[0]["levels"]
+    levels = slots[0]["levels"][log_b]
     stream = torch.cuda.current_stream().cuda_stream
     call_counter = [0]
 
@@ -181,31 +195,16 @@ def main():
         nb = 1 << lt
         with torch.cuda.stream(sl["stream"]):
             h = sl["stream"].cuda_stream
-            _lib.check(lib.sp_merkle_forest_dev(sl["levels"].data_ptr(), lt, HEIGHT, None, h), "forest")
+            buf = sl["levels"][lt]
+            _lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), lt, HEIGHT, None, h), "forest")
             if world > 1:
-                # roots of this rank's nb trees are the last nb felts of its (2^lt)-tree forest
-                off = forest_felts(lt) - nb
-                roots = sl["levels"][off : off + nb]
-                g = sl["gathered"][:, :nb]
-                if nb == B:
-                    dist.all_gather_into_tensor(g.reshape(world * nb, 4), roots)
-                else:
-                    tmp = torch.empty((world * nb, 4), dtype=torch.int64, device=dev)
-                    dist.all_gather_into_tensor(tmp, roots.contiguous())
-                    g = tmp.reshape(world, nb, 4)
-                # job tree j = sub-roots of tree j from every rank: forest of nb trees of height log2(world)
+                roots = buf[buf.shape[0] - nb :]  # this rank's nb sub-roots (last level of the forest)
+                g = sl["gathered"][: world * nb]
+                dist.all_gather_into_tensor(g, roots)  # g[r * nb + t] = sub-root of tree t on rank r
+                # job tree t = the sub-roots of tree t from every rank: nb trees of height log2(world)
                 top = sl["top"]
-                top[: world * nb] = g.transpose(0, 1).reshape(world * nb, 4)
+                top[: world * nb] = g.reshape(world, nb, 4).transpose(0, 1).reshape(world * nb, 4)
                 _lib.check(lib.sp_merkle_forest_dev(top.data_ptr(), lt, world.bit_length() - 1, None, h), "combine")
-
-    def plan(k):
-        """K steps (trees) as lockstep calls of <= B trees: greedy powers of two."""
-        out = []
-        while k > 0:
-            lt = min(log_b, k.bit_length() - 1)
-            out.append(lt)
-            k -= 1 << lt
-        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -292,7 +291,7 @@ def main():
             # the sample doubles as one more parity check of the timed tree
             gpu_l1 = _lib.unpack_felts(
                 (ctypes.c_uint64 * (4 * len(cpu_out))).from_buffer_copy(
-                    levels[n_leaves : n_leaves + len(cpu_out)].cpu().numpy().astype("<i8").tobytes()),
+                    levels[(n_leaves << log_b) : (n_leaves << log_b) + len(cpu_out)].cpu().numpy().astype("<i8").tobytes()),
                 len(cpu_out))
             base["matches_gpu"] = gpu_l1 == cpu_out
             result["cpu_baseline"] = base
