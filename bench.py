@@ -147,6 +147,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from starkperp import _lib
+    from starkperp.distributed import combine_forest_dev
 
     lib = _lib.ensure_init(local_rank)
     if args.workload == "airfri":
@@ -198,13 +199,7 @@ def main():
             buf = sl["levels"][lt]
             _lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), lt, HEIGHT, None, h), "forest")
             if world > 1:
-                roots = buf[buf.shape[0] - nb :]  # this rank's nb sub-roots (last level of the forest)
-                g = sl["gathered"][: world * nb]
-                dist.all_gather_into_tensor(g, roots)  # g[r * nb + t] = sub-root of tree t on rank r
-                # job tree t = the sub-roots of tree t from every rank: nb trees of height log2(world)
-                top = sl["top"]
-                top[: world * nb] = g.reshape(world, nb, 4).transpose(0, 1).reshape(world * nb, 4)
-                _lib.check(lib.sp_merkle_forest_dev(top.data_ptr(), lt, world.bit_length() - 1, None, h), "combine")
+                combine_forest_dev(lib, dist, buf[buf.shape[0] - nb :], sl["gathered"], sl["top"], lt, h)
 
     def fence():
         torch.cuda.synchronize()

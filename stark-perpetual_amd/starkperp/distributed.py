@@ -63,3 +63,38 @@ def combine_subroots_dev(lib, dist, subroot_row, gathered, top, stream):
     assert 1 << height == world
     _lib.check(lib.sp_merkle_build_dev(top.data_ptr(), height, None, stream), "sp_merkle_build_dev")
     return top[-1]
+
+
+# ---- forests: nb independent trees per rank, combined tree by tree ------------------------------
+def forest_gather_layout(gathered_rank_major, world: int, nb: int):
+    """`gathered_rank_major[r * nb + t]` = sub-root of tree t on rank r (what all_gather returns)
+    -> tree-major leaves `[t * world + r]` of the nb top trees (contiguous leaves per tree)."""
+    return [gathered_rank_major[r * nb + t] for t in range(nb) for r in range(world)]
+
+
+def combine_forest_subroots(dist, torch, local_roots: Sequence[int], hash_many, device=None, group=None):
+    """Host-int version: every rank holds the sub-roots of nb trees; returns the nb job roots
+    (tree t = the sub-roots of tree t from every rank, in rank order)."""
+    world = dist.get_world_size(group)
+    nb = len(local_roots)
+    mine = torch.stack([felt_to_tensor(torch, v, device) for v in local_roots])
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    rank_major = [tensor_to_felt(row) for t in out for row in t]
+    leaves = forest_gather_layout(rank_major, world, nb)
+    return [combine_subroots(leaves[t * world : (t + 1) * world], hash_many) for t in range(nb)]
+
+
+def combine_forest_dev(lib, dist, roots, gathered, top, log_trees: int, stream):
+    """Device-resident version used by bench.py.  roots: [nb, 4] view of this rank's sub-roots;
+    gathered: >= [world * nb, 4]; top: >= [nb * (2 * world - 1), 4].  One all_gather (RCCL) of
+    world * nb * 32 bytes, then the nb top trees as one lockstep forest of height log2(world)."""
+    from . import _lib
+    nb = 1 << log_trees
+    world = dist.get_world_size()
+    g = gathered[: world * nb]
+    dist.all_gather_into_tensor(g, roots)
+    top[: world * nb] = g.reshape(world, nb, 4).transpose(0, 1).reshape(world * nb, 4)
+    _lib.check(lib.sp_merkle_forest_dev(top.data_ptr(), log_trees, world.bit_length() - 1, None, stream),
+               "sp_merkle_forest_dev")
+    return top[nb * (2 * world - 1) - nb : nb * (2 * world - 1)]

@@ -42,6 +42,40 @@ def test_sharded_root_matches_single(world):
     assert sorted(results) == [(r, True) for r in range(world)]
 
 
+def _forest_worker(rank, world, port, trees, expect, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from starkperp import distributed as D
+    hash_many = lambda a, b: [R.pedersen_hash(x, y) for x, y in zip(a, b)]
+    per = len(trees[0]) // world
+    local = [R.merkle_root(t[rank * per : (rank + 1) * per]) for t in trees]
+    roots = D.combine_forest_subroots(dist, torch, local, hash_many)
+    q.put((rank, roots == expect))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forest_combine_matches_single():
+    """nb = 4 trees sharded over 2 ranks: the tree-major regrouping of the gathered sub-roots
+    (the same layout bench.py's device path uses) reproduces every tree's root."""
+    world = 2
+    trees = [wl.leaves(8, seed=70 + i) for i in range(4)]
+    expect = [R.merkle_root(t) for t in trees]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_forest_worker, args=(r, world, port, trees, expect, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, True) for r in range(world)]
+    from starkperp import distributed as D
+    assert D.forest_gather_layout(["r0t0", "r0t1", "r1t0", "r1t1"], 2, 2) == ["r0t0", "r1t0", "r0t1", "r1t1"]
+
+
 def test_shard_range_covers():
     from starkperp import distributed as D
     for n in (0, 1, 7, 8, 4096):
