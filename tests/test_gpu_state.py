@@ -95,3 +95,38 @@ def test_persistent_tree_and_position_updates():
     got = state.hash_position_updates(ups)
     for (k, prev, new), (gk, gp, gn) in zip(ups, got):
         assert gk == k and gp == R.position_hash(*prev) and gn == R.position_hash(*new)
+
+
+def test_combine_forest_dev_with_fake_collective():
+    """bench.py's N > 1 combine on one GPU: a stand-in `dist` whose all_gather returns this rank's
+    sub-roots from every 'rank' (deterministically perturbed), checked against the oracle."""
+    import torch
+    from starkperp import _lib, stark
+    from starkperp.distributed import combine_forest_dev
+
+    lib = _lib.ensure_init()
+    for world in (2, 4):
+        for log_trees in (0, 2):
+            nb = 1 << log_trees
+            rng = random.Random(world * 10 + nb)
+            per_rank = [[rng.randrange(P) for _ in range(nb)] for _ in range(world)]  # [rank][tree]
+
+            class FakeDist:
+                @staticmethod
+                def get_world_size(group=None):
+                    return world
+
+                @staticmethod
+                def all_gather_into_tensor(out, inp):
+                    flat = [v for r in range(world) for v in per_rank[r]]
+                    out.copy_(stark.felts_to_tensor(flat))
+
+            roots = stark.felts_to_tensor(per_rank[0])
+            gathered = torch.zeros((world * nb, 4), dtype=torch.int64, device="cuda")
+            top = torch.zeros((nb * (2 * world - 1), 4), dtype=torch.int64, device="cuda")
+            out = combine_forest_dev(lib, FakeDist, roots, gathered, top, log_trees,
+                                     torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = stark.tensor_to_felts(out)
+            exp = [R.merkle_root([per_rank[r][t] for r in range(world)]) for t in range(nb)]
+            assert got == exp, (world, nb)
