@@ -4,7 +4,7 @@ bench.py - headline benchmark of the MI355X hot path (contract: see the build br
 
 A "step" is one rebuild of a 2^16-leaf Pedersen Merkle tree per GPU (BASELINE.json configs[1]:
 "2^16-leaf position-tree Merkle rebuild"), inputs resident in HBM.  Steps are independent, so the K
-steps are advanced in lockstep groups of (by default) 16 trees per library call - the upper levels
+steps are advanced in lockstep groups of (by default) 32 trees per library call - the upper levels
 of one rebuild are latency-bound and would leave most of the chip idle.  With N > 1 ranks every
 step is a tree of N * 2^16 leaves: each rank rebuilds its own 2^16-leaf subtree (no data-path
 collective), the N sub-roots are exchanged with one RCCL all_gather (N x 32 bytes per tree) and the
@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--trees-per-call", type=int, default=16,
+    ap.add_argument("--trees-per-call", type=int, default=32,
                     help="independent 2^16-leaf rebuilds advanced in lockstep by one library call "
                          "(sp_merkle_forest_dev: one launch pair per level serves all of them; the upper "
                          "levels of a single rebuild are latency-bound and leave most of the chip idle); "
