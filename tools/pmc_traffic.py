@@ -3,8 +3,8 @@
 profiles/r01_pmc_traffic.json.  Run on the GPU box:
 
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o b -- python bench.py --no-cpu-baseline --no-extras --streams 1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o b -- python bench.py --no-cpu-baseline --no-extras --streams 1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o b -- python bench.py --no-cpu-baseline --no-extras
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o b -- python bench.py --no-cpu-baseline --no-extras
   python tools/pmc_traffic.py gpurun_out/pmc_fetch/b_counter_collection.csv gpurun_out/pmc_write/b_counter_collection.csv
 
 Units (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB.  The guide's gfx950
