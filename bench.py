@@ -160,7 +160,7 @@ def main():
     def forest_felts(lt):
         return sum(1 << (HEIGHT + lt - k) for k in range(HEIGHT + 1))
 
-    leaves = seeded_felts(torch, n_leaves, 1000 + rank, dev)
+    leaves = seeded_felts(torch, n_leaves << log_b, 1000 + rank, dev)  # distinct leaves for every tree
 
     def plan(k):
         """K steps (trees) as lockstep calls of <= B trees: greedy powers of two."""
@@ -175,9 +175,9 @@ def main():
     slots = []
     for si in range(n_streams):
         bufs = {}
-        for lt in sizes:  # one forest buffer per call size, every tree seeded with the same leaves
+        for lt in sizes:  # one forest buffer per call size; tree t always gets the same seeded leaves
             lv = torch.zeros((forest_felts(lt), 4), dtype=torch.int64, device=dev)
-            lv[: n_leaves << lt] = leaves.repeat(1 << lt, 1)
+            lv[: n_leaves << lt] = leaves[: n_leaves << lt]
             bufs[lt] = lv
         slots.append({
             "levels": bufs,
@@ -291,7 +291,8 @@ def main():
             base["matches_gpu"] = gpu_l1 == cpu_out
             result["cpu_baseline"] = base
             result["cpu_baseline_c"] = cpu_baseline_c(leaf_ints, _lib.unpack_felts(
-                (ctypes.c_uint64 * 4).from_buffer_copy(levels[-1:].cpu().numpy().astype("<i8").tobytes()), 1)[0])
+                (ctypes.c_uint64 * 4).from_buffer_copy(
+                    levels[levels.shape[0] - B : levels.shape[0] - B + 1].cpu().numpy().astype("<i8").tobytes()), 1)[0])
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
