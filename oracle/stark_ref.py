@@ -194,3 +194,92 @@ def commit_rows(columns):
             acc = R.pedersen_hash(acc, col[i])
         leaves.append(acc)
     return R.merkle_root(leaves)
+
+
+# ---- verifier of starkperp.stark.prove (test infrastructure) -------------------------------------
+import hashlib as _hashlib
+
+
+def transcript_challenge(label, *values, modulus=P):
+    h = _hashlib.sha256(label.encode())
+    for v in values:
+        h.update(int(v).to_bytes(32, "big"))
+    return int.from_bytes(h.digest() + _hashlib.sha256(h.digest()).digest(), "big") % modulus
+
+
+def _root_from_path(leaf, index, path, hash2):
+    node = leaf
+    for sib in path:
+        node = hash2(sib, node) if index & 1 else hash2(node, sib)
+        index >>= 1
+    return node
+
+
+def verify_proof(proof, hash2=R.pedersen_hash, final_log=6):
+    """Checks a proof produced by the GPU prover: Merkle openings, the AIR relation between the
+    opened trace rows and the composition column at every queried point, FRI fold consistency down
+    to the final layer, and the degree bound of the final layer.  Returns (ok, reason)."""
+    n, seed, shift = proof["n"], proof["seed"], proof["shift"]
+    m = BLOWUP * n
+    log_m = m.bit_length() - 1
+    root_t, roots, final = proof["trace_root"], proof["layer_roots"], proof["final_layer"]
+    n_layers = log_m - final_log
+    if len(roots) != n_layers or len(final) != 1 << final_log:
+        return False, "shape"
+    alphas = [transcript_challenge("alpha", seed, root_t, k) for k in range(N_CONSTRAINTS)]
+    betas = [transcript_challenge("beta", seed, roots[k], k + 1) for k in range(n_layers)]
+    per = periodic_lde(n, shift)
+    w = root_of_unity(log_m)
+    zinv = [pow((pow(shift, n, P) * pow(w, n * k, P) - 1) % P, -1, P) for k in range(BLOWUP)]
+    # final layer: degree < 3n / 2^n_layers on the domain shift^(2^n_layers) * <w_64>
+    fshift = shift
+    for _ in range(n_layers):
+        fshift = fshift * fshift % P
+    if not poly_degree_bound_check(final, fshift, (3 * n >> n_layers) - 1):
+        return False, "final layer degree"
+    for qi, q in enumerate(proof["queries"]):
+        j = transcript_challenge("query", seed, root_t, *roots, *final, qi, modulus=m // 2)
+        if q["index"] != j:
+            return False, "query index"
+        # trace openings: rows j, j+4, j+m/2, j+m/2+4
+        want_rows = [j, (j + BLOWUP) % m, j + m // 2, (j + m // 2 + BLOWUP) % m]
+        if [t["row"] for t in q["trace"]] != want_rows:
+            return False, "trace rows"
+        for t in q["trace"]:
+            leaf = t["values"][0]
+            for v in t["values"][1:]:
+                leaf = hash2(leaf, v)
+            if _root_from_path(leaf, t["row"], t["path"], hash2) != root_t:
+                return False, "trace path"
+        # composition at the two layer-0 positions must follow from the trace openings
+        for side, pos in enumerate((j, j + m // 2)):
+            cur, nxt = q["trace"][2 * side]["values"], q["trace"][2 * side + 1]["values"]
+            pv = [tab[pos % (BLOWUP * 512)] for tab in per]
+            cv = constraint_values(cur, nxt, pv)
+            expect = sum(a * c for a, c in zip(alphas, cv)) % P * zinv[pos % BLOWUP] % P
+            if q["layers"][0][side]["value"] != expect:
+                return False, "composition value"
+        # FRI consistency
+        jk, s, mk = j, shift, m
+        for k in range(n_layers):
+            jk %= mk // 2
+            a, b = q["layers"][k]
+            if (a["pos"], b["pos"]) != (jk, jk + mk // 2):
+                return False, "layer positions"
+            for o in (a, b):
+                if _root_from_path(o["value"], o["pos"], o["path"], hash2) != roots[k]:
+                    return False, "layer path"
+            wk = root_of_unity(mk.bit_length() - 1)
+            x = s * pow(wk, jk, P) % P
+            folded = ((a["value"] + b["value"]) * pow(2, -1, P)
+                      + betas[k] * (a["value"] - b["value"]) % P * pow(2 * x, -1, P)) % P
+            if k + 1 < n_layers:
+                nxt_pair = q["layers"][k + 1]
+                nxt_val = nxt_pair[0]["value"] if jk < mk // 4 else nxt_pair[1]["value"]
+            else:
+                nxt_val = final[jk]
+            if folded != nxt_val:
+                return False, "fold consistency at layer %d" % k
+            s = s * s % P
+            mk //= 2
+    return True, "ok"

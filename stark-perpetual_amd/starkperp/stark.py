@@ -159,3 +159,84 @@ def prove_commitments(xs, ys, alphas, betas, final_log=6, shift=FIELD_GEN):
         if layer.shape[0] > (1 << final_log):
             roots.append(commit_rows(layer.unsqueeze(0)))
     return [root_of(r) for r in roots], tensor_to_felts(layer)
+
+
+# ---- a checkable proof: Fiat-Shamir transcript, query openings -----------------------------------
+# Build-defined like the rest of this module (the reference has no prover).  The transcript hash
+# is SHA-256 (host); every commitment / opening hash is the reference's pedersen_hash on the GPU.
+import hashlib as _hashlib
+
+
+def transcript_challenge(label: str, *values: int, modulus: int = FIELD_PRIME) -> int:
+    h = _hashlib.sha256(label.encode())
+    for v in values:
+        h.update(int(v).to_bytes(32, "big"))
+    return int.from_bytes(h.digest() + _hashlib.sha256(h.digest()).digest(), "big") % modulus
+
+
+def _path_indices(n_leaves: int, idx: int):
+    """Flat indices (into a leaves-first levels buffer) of the siblings along the path of leaf idx."""
+    out, off, width, i = [], 0, n_leaves, idx
+    while width > 1:
+        out.append(off + (i ^ 1))
+        off += width
+        width >>= 1
+        i >>= 1
+    return out
+
+
+def _gather_felts(t, indices):
+    torch = _torch()
+    idx = torch.tensor(indices, dtype=torch.int64, device=t.device)
+    return tensor_to_felts(t.index_select(0, idx))
+
+
+def prove(xs, ys, n_queries: int = 8, seed: int = 0, final_log: int = 6, shift: int = FIELD_GEN):
+    """Proof that the trace of the hashes (xs[i], ys[i]) satisfies the Pedersen-step AIR:
+    commitments to the trace LDE, the composition column and every FRI layer, the final layer in
+    the clear, and for each query the openings a verifier needs (oracle/stark_ref.verify_proof)."""
+    P = FIELD_PRIME
+    n = 512 * xs.shape[0]
+    M = n << BLOWUP_LOG
+    trace = pedersen_trace(xs, ys)
+    trace_lde = lde(trace)
+    lv_trace = commit_rows(trace_lde)
+    root_t = root_of(lv_trace)
+    alphas = [transcript_challenge("alpha", seed, root_t, k) for k in range(N_CONSTRAINTS)]
+    per = periodic_lde(n, shift, xs.device)
+    comp = air_eval(trace_lde, per, n, alphas, shift)
+    layers, level_bufs, roots = [comp], [], []
+    s = shift
+    while True:
+        cur = layers[-1]
+        lv = commit_rows(cur.unsqueeze(0))
+        level_bufs.append(lv)
+        roots.append(root_of(lv))
+        beta = transcript_challenge("beta", seed, roots[-1], len(roots))
+        nxt = fri_fold(cur, beta, s)
+        s = s * s % P
+        layers.append(nxt)
+        if nxt.shape[0] <= (1 << final_log):
+            break
+    final = tensor_to_felts(layers[-1])
+    queries = []
+    for q in range(n_queries):
+        j = transcript_challenge("query", seed, root_t, *roots, *final, q, modulus=M // 2)
+        entry = {"index": j, "trace": [], "layers": []}
+        for pos in (j, j + M // 2):
+            for row in (pos, (pos + (1 << BLOWUP_LOG)) % M):
+                vals = [tensor_to_felts(trace_lde[c][row : row + 1])[0] for c in range(4)]
+                entry["trace"].append({"row": row, "values": vals,
+                                       "path": _gather_felts(lv_trace, _path_indices(M, row))})
+        jk = j
+        for k, (layer, lv) in enumerate(zip(layers[:-1], level_bufs)):
+            mk = layer.shape[0]
+            jk %= mk // 2
+            pair = []
+            for pos in (jk, jk + mk // 2):
+                pair.append({"pos": pos, "value": tensor_to_felts(layer[pos : pos + 1])[0],
+                             "path": _gather_felts(lv, _path_indices(mk, pos))})
+            entry["layers"].append(pair)
+        queries.append(entry)
+    return {"n": n, "seed": seed, "shift": shift, "trace_root": root_t, "layer_roots": roots,
+            "final_layer": final, "queries": queries}

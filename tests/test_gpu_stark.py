@@ -138,3 +138,41 @@ def test_full_size_pipeline_properties(stark):
         layer = stark.fri_fold(layer, betas[k], s)
         s = s * s % P
     assert not S.poly_degree_bound_check(stark.tensor_to_felts(layer), s, 47)
+
+
+def test_prove_then_verify_small(stark):
+    """GPU prover -> CPU verifier round trip on a 1024-row trace, plus tampering."""
+    import copy
+    rng = random.Random(21)
+    inputs = [(rng.randrange(P), rng.randrange(P)) for _ in range(2)]
+    xs = stark.felts_to_tensor([a for a, _ in inputs])
+    ys = stark.felts_to_tensor([b for _, b in inputs])
+    proof = stark.prove(xs, ys, n_queries=3, seed=7)
+    ok, why = S.verify_proof(proof)
+    assert ok, why
+    bad = copy.deepcopy(proof)
+    bad["queries"][0]["trace"][0]["values"][1] ^= 1
+    assert S.verify_proof(bad) == (False, "trace path")
+    bad = copy.deepcopy(proof)
+    bad["queries"][1]["layers"][2][0]["value"] ^= 1
+    assert not S.verify_proof(bad)[0]
+    bad = copy.deepcopy(proof)
+    bad["final_layer"][5] ^= 1
+    assert not S.verify_proof(bad)[0]
+
+
+def test_prove_then_verify_full_size(stark):
+    """2^20-row trace proved on the GPU, verified on the CPU with the C oracle's hash."""
+    import torch
+    from oracle import cref
+    m = 2048
+    g = torch.Generator().manual_seed(19)
+    xs = torch.randint(0, 2**62, (m, 4), dtype=torch.int64, generator=g)
+    ys = torch.randint(0, 2**62, (m, 4), dtype=torch.int64, generator=g)
+    xs[:, 3] &= (1 << 58) - 1
+    ys[:, 3] &= (1 << 58) - 1
+    proof = stark.prove(xs.cuda(), ys.cuda(), n_queries=4, seed=3)
+    hash2 = lambda a, b: cref.pedersen_hash_many([a], [b])[0][0]
+    ok, why = S.verify_proof(proof, hash2=hash2)
+    assert ok, why
+    assert len(proof["layer_roots"]) == 16 and len(proof["final_layer"]) == 64
