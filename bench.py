@@ -460,6 +460,7 @@ def extras(torch, lib, _lib, dev, stream):
     trace = stark.pedersen_trace(xs, ys)          # witness generation, outside the timed job
     per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
     torch.cuda.synchronize()
+    out["witness_generation_seconds_2p20_rows"] = timed(lambda: stark.pedersen_trace(xs, ys), 2)
 
     def job():
         t_lde = stark.lde(trace)

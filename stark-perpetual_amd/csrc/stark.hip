@@ -130,46 +130,111 @@ lde_pad_kernel(const uint64_t* __restrict__ coef, uint64_t* __restrict__ out, in
 }
 
 // ---- Pedersen-step AIR --------------------------------------------------------------------------
-// Trace generation: one thread per hash writes 512 rows of (s, px, py, lam) - witness generation
-// with the reference's affine chord rule (math_utils.py:59-68), one inversion per set bit.
+// Trace generation (witness): one thread per hash writes 512 rows of (s, px, py, lambda).  The
+// reference's affine chord rule (math_utils.py:59-68) costs one inversion per set bit; here the
+// 504 partial sums are accumulated projectively (XYZZ), and the two families of inversions the
+// affine rows need - 1/ZZZ of every partial sum, then 1/(px - cx) of every addition row - are each
+// done with ONE divsteps inversion per hash (Montgomery's trick over the rows of that hash).
+// Scratch planes are [row][limb][hash] so that the 64 hashes of a wave touch consecutive dwords.
+__device__ __forceinline__ void tr_store(int32_t* plane, size_t m, int r, size_t h, const fe& v) {
+#pragma unroll
+  for (int l = 0; l < NL; ++l) plane[((size_t)(r * NL + l)) * m + h] = v.l[l];
+}
+__device__ __forceinline__ fe tr_load(const int32_t* plane, size_t m, int r, size_t h) {
+  fe v;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) v.l[l] = plane[((size_t)(r * NL + l)) * m + h];
+  return v;
+}
+
 __global__ void __launch_bounds__(64)
 pedersen_trace_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t m,
                       const aff_packed* __restrict__ bits /* 504 per-bit points */, aff_packed shift,
-                      aff_packed pad, uint64_t* __restrict__ cols /* [4][512 m] plain felts */) {
+                      uint64_t* __restrict__ cols /* [4][512 m] plain felts */,
+                      int32_t* __restrict__ sc /* 5 planes of 512 * 9 * m int32 */) {
   const size_t hsh = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (hsh >= m) return;
   const size_t n = 512 * m;
+  const size_t plane = (size_t)512 * NL * m;
+  int32_t *sX = sc, *sY = sc + plane, *sZZ = sc + 2 * plane, *sZZZ = sc + 3 * plane, *sPre = sc + 4 * plane;
   uint64_t* cs = cols;
   uint64_t* cpx = cols + 4 * n;
   uint64_t* cpy = cols + 8 * n;
   uint64_t* cl = cols + 12 * n;
-  aff acc = ld_aff(&shift);
-  u256 zero;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) zero.w[q] = 0;
+  // pass A: projective partial sums before every row, s column
+  xyzz acc = xyzz_from_aff(ld_aff(&shift));
   for (int block = 0; block < 2; ++block) {
     u256 s = ld_u256((block ? y : x) + 4 * hsh);
     for (int j = 0; j < 256; ++j) {
-      const size_t row = 512 * hsh + 256 * block + j;
-      st_u256(cs + 4 * row, s);
-      st_u256(cpx + 4 * row, fe_pack(fe_from_mont(acc.x)));
-      st_u256(cpy + 4 * row, fe_pack(fe_from_mont(acc.y)));
-      u256 lam_out = zero;
+      const int r = 256 * block + j;
+      st_u256(cs + 4 * (512 * hsh + r), s);
+      tr_store(sX, m, r, hsh, acc.X);
+      tr_store(sY, m, r, hsh, acc.Y);
+      tr_store(sZZ, m, r, hsh, acc.ZZ);
+      tr_store(sZZZ, m, r, hsh, acc.ZZZ);
       if (j < 252) {
-        if (s.w[0] & 1u) {
-          const aff c = ld_aff(bits + 252 * block + j);
-          const fe lam = fe_mul(fe_sub(acc.y, c.y), fe_inv(fe_carry(fe_sub(acc.x, c.x))));
-          const fe x3 = fe_carry(fe_sub(fe_sub(fe_sqr(lam), acc.x), c.x));
-          const fe y3 = fe_carry(fe_sub(fe_mul(lam, fe_sub(acc.x, x3)), acc.y));
-          acc.x = fe_mul(x3, FE_ONE_M);
-          acc.y = fe_mul(y3, FE_ONE_M);
-          lam_out = fe_pack(fe_from_mont(lam));
-        }
+        if (s.w[0] & 1u) acc = xyzz_madd(acc, ld_aff(bits + 252 * block + j));
 #pragma unroll
         for (int q = 0; q < 7; ++q) s.w[q] = (s.w[q] >> 1) | (s.w[q + 1] << 31);
         s.w[7] >>= 1;
       }
-      st_u256(cl + 4 * row, lam_out);
+    }
+  }
+  // pass B: one inversion for all 512 ZZZ; affine px, py (plain columns; Montgomery copies kept)
+  fe run = FE_ONE_M;
+  for (int r = 0; r < 512; ++r) {
+    tr_store(sPre, m, r, hsh, run);
+    run = fe_mul(run, tr_load(sZZZ, m, r, hsh));
+  }
+  fe inv = fe_inv(run);
+  for (int r = 511; r >= 0; --r) {
+    const fe zzz = tr_load(sZZZ, m, r, hsh);
+    const fe izzz = fe_mul(inv, tr_load(sPre, m, r, hsh));
+    inv = fe_mul(inv, zzz);
+    const fe iz = fe_mul(tr_load(sZZ, m, r, hsh), izzz);  // 1/Z
+    const fe px = fe_mul(tr_load(sX, m, r, hsh), fe_sqr(iz));
+    const fe py = fe_mul(tr_load(sY, m, r, hsh), izzz);
+    tr_store(sX, m, r, hsh, px);
+    tr_store(sY, m, r, hsh, py);
+    st_u256(cpx + 4 * (512 * hsh + r), fe_pack(fe_from_mont(px)));
+    st_u256(cpy + 4 * (512 * hsh + r), fe_pack(fe_from_mont(py)));
+  }
+  // pass C: one inversion for the chord denominators of all addition rows
+  run = FE_ONE_M;
+  for (int block = 0; block < 2; ++block) {
+    u256 s = ld_u256((block ? y : x) + 4 * hsh);
+    for (int j = 0; j < 252; ++j) {
+      const int r = 256 * block + j;
+      if (s.w[0] & 1u) {
+        const aff c = ld_aff(bits + 252 * block + j);
+        const fe dx = fe_carry(fe_sub(tr_load(sX, m, r, hsh), c.x));
+        tr_store(sZZ, m, r, hsh, dx);
+        tr_store(sPre, m, r, hsh, run);
+        run = fe_mul(run, dx);
+      }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) s.w[q] = (s.w[q] >> 1) | (s.w[q + 1] << 31);
+      s.w[7] >>= 1;
+    }
+  }
+  inv = fe_inv(run);
+  u256 zero;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) zero.w[q] = 0;
+  for (int block = 1; block >= 0; --block) {
+    const u256 s0 = ld_u256((block ? y : x) + 4 * hsh);
+    for (int j = 255; j >= 0; --j) {
+      const int r = 256 * block + j;
+      u256 lam_out = zero;
+      if (j < 252 && ((s0.w[j >> 5] >> (j & 31)) & 1u)) {
+        const aff c = ld_aff(bits + 252 * block + j);
+        const fe dx = tr_load(sZZ, m, r, hsh);
+        const fe idx = fe_mul(inv, tr_load(sPre, m, r, hsh));
+        inv = fe_mul(inv, dx);
+        const fe lam = fe_mul(fe_sub(tr_load(sY, m, r, hsh), c.y), idx);
+        lam_out = fe_pack(fe_from_mont(lam));
+      }
+      st_u256(cl + 4 * (512 * hsh + r), lam_out);
     }
   }
 }
@@ -241,6 +306,7 @@ struct Tables {
   std::map<std::pair<int, std::vector<uint32_t>>, DeviceBuffer> coset;  // (log_n, shift words) -> shift^c / n
   DeviceBuffer work;   // ping-pong columns for LDE
   DeviceBuffer bits;   // 504 per-bit constant points for trace generation
+  DeviceBuffer trace_scratch;  // projective partial sums / prefix products of the witness generator
   bool bits_ready = false;
 };
 static Tables g_tab;
@@ -251,6 +317,7 @@ void release_stark_state() {
   g_tab.coset.clear();
   g_tab.work.release();
   g_tab.bits.release();
+  g_tab.trace_scratch.release();
   g_tab.bits_ready = false;
 }
 
@@ -468,12 +535,13 @@ int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes,
     SP_HIP(hipMemcpy(g_tab.bits.ptr, h.data(), 504 * sizeof(aff_packed), hipMemcpyHostToDevice));
     g_tab.bits_ready = true;
   }
-  aff_packed shift, pad;
+  aff_packed shift;
   shift.x = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_X))));
   shift.y = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_Y))));
-  pad = shift;
+  SP_HIP(g_tab.trace_scratch.reserve((size_t)5 * 512 * NL * n_hashes * sizeof(int32_t)));
   hipLaunchKernelGGL(pedersen_trace_kernel, dim3((unsigned)((n_hashes + 63) / 64)), dim3(64), 0, st, x, y,
-                     n_hashes, (const aff_packed*)g_tab.bits.ptr, shift, pad, cols);
+                     n_hashes, (const aff_packed*)g_tab.bits.ptr, shift, cols,
+                     (int32_t*)g_tab.trace_scratch.ptr);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }
