@@ -146,6 +146,15 @@ int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes,
  * 4 * 2^log_n felts; periodic_lde: 6 tables of 2048 felts; alphas_host: 11 felts. */
 int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
                     const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream);
+/* EC-ladder AIR (one mimic_ec_mult_air instance = 256 rows, signature.py:176-190): witness columns
+ * m, px, py, qx, qy, la, ld for n_ladders scalar multiplications m * (qx, qy) + SHIFT_POINT
+ * (cols = 7 columns of 256 * n_ladders felts), and its composition column (12 constraints,
+ * periodic_lde: 3 tables of 1024 felts). */
+int sp_ec_ladder_trace_dev(const uint64_t* m, const uint64_t* qx, const uint64_t* qy, size_t n_ladders,
+                           uint64_t* cols, void* stream);
+int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
+                              const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out,
+                              void* stream);
 /* One FRI fold of f on shift * <w_M> (M = 2^log_m) to g on shift^2 * <w_{M/2}>:
  * g(x^2) = (f(x) + f(-x)) / 2 + beta (f(x) - f(-x)) / (2 x). */
 int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uint64_t* beta_host,

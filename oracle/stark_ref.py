@@ -135,9 +135,81 @@ def constraint_values(cur, nxt, per):
     ]
 
 
-def composition_on_coset(trace_lde, per_lde, n, alphas, shift=GEN):
+# ---- the EC-ladder AIR (the ECDSA builtin's building block) --------------------------------------
+# One instance = one mimic_ec_mult_air(m, point, shift_point) call (signature.py:176-190), 256 rows.
+# Columns m, px, py, qx, qy, la, ld.  Row j = 0..250:  b = m - 2 m_next in {0,1};  the doubling
+# point (qx, qy) is doubled on EVERY row by the tangent rule with slope ld (math_utils.py:79-88);
+# if b the partial sum (px, py) takes the chord step with slope la (math_utils.py:59-68), else it
+# is held.  Row 0 starts from the shift point, m = 0 at row 251, rows 251..254 keep doubling with
+# b = 0, row 255 is free (block boundary).  (px, py) at row 251 is m * point + shift_point.
+def ec_ladder_trace(inputs, shift_point=None):
+    """inputs: list of (m, (qx, qy)) with 0 < m < 2^251.  Returns 7 columns of 256 rows each."""
+    shift_point = tuple(shift_point or R.SHIFT_POINT)
+    cols = [[] for _ in range(7)]
+    for m, point in inputs:
+        acc, q = shift_point, tuple(point)
+        for j in range(256):
+            la = ld = 0
+            bit = m & 1 if j < 251 else 0
+            row = [m, acc[0], acc[1], q[0], q[1]]
+            if j < 255:
+                ld = R.div_mod(3 * q[0] * q[0] + R.ALPHA, 2 * q[1], P)
+                if bit:
+                    la = R.div_mod(acc[1] - q[1], acc[0] - q[0], P)
+                    acc = R.ec_add(acc, q)
+                q = R.ec_double(q)
+                m >>= 1
+            for c, v in zip(cols, row + [la, ld]):
+                c.append(v)
+    return cols
+
+
+def ec_ladder_periodic_columns(shift_point=None):
+    """Period-256 selectors: step (rows 0..254), first (row 0), z251 (row 251)."""
+    step = [0 if j == 255 else 1 for j in range(256)]
+    first = [1 if j == 0 else 0 for j in range(256)]
+    z251 = [1 if j == 251 else 0 for j in range(256)]
+    return [step, first, z251]
+
+
+N_EC_LADDER_CONSTRAINTS = 12
+
+
+def ec_ladder_constraint_values(cur, nxt, per, shift_point=None):
+    sx, sy = tuple(shift_point or R.SHIFT_POINT)
+    m, px, py, qx, qy, la, ld = cur
+    m_n, px_n, py_n, qx_n, qy_n, _, _ = nxt
+    step, first, z251 = per
+    b = (m - 2 * m_n) % P
+    nb = (1 - b) % P
+    return [
+        step * b * (b - 1) % P,
+        step * (ld * 2 * qy - 3 * qx * qx - R.ALPHA) % P,
+        step * (qx_n - ld * ld + 2 * qx) % P,
+        step * (qy_n - ld * (qx - qx_n) + qy) % P,
+        step * b * (la * (px - qx) - (py - qy)) % P,
+        step * b * (px_n - la * la + px + qx) % P,
+        step * b * (py_n - la * (px - px_n) + py) % P,
+        step * nb * (px_n - px) % P,
+        step * nb * (py_n - py) % P,
+        first * (px - sx) % P,
+        first * (py - sy) % P,
+        z251 * m % P,
+    ]
+
+
+AIRS = {
+    "pedersen": {"n_cols": 4, "period": 512, "n_constraints": N_CONSTRAINTS,
+                 "periodic": periodic_columns, "constraints": constraint_values},
+    "ec_ladder": {"n_cols": 7, "period": 256, "n_constraints": N_EC_LADDER_CONSTRAINTS,
+                  "periodic": ec_ladder_periodic_columns, "constraints": ec_ladder_constraint_values},
+}
+
+
+def composition_on_coset(trace_lde, per_lde, n, alphas, shift=GEN, air="pedersen"):
     """Random linear combination of the constraints divided by Z_H(x) = x^n - 1, on the LDE coset.
-    trace_lde: 4 columns of 4n values;  per_lde: 6 tables of 4*512 values (index i mod 2048)."""
+    trace_lde: columns of 4n values;  per_lde: tables of 4*period values (index i mod 4*period)."""
+    spec = AIRS[air]
     m = BLOWUP * n
     w = root_of_unity(m.bit_length() - 1)
     out = []
@@ -145,17 +217,18 @@ def composition_on_coset(trace_lde, per_lde, n, alphas, shift=GEN):
     for i in range(m):
         cur = [col[i] for col in trace_lde]
         nxt = [col[(i + BLOWUP) % m] for col in trace_lde]
-        per = [t[i % (BLOWUP * 512)] for t in per_lde]
-        cv = constraint_values(cur, nxt, per)
+        per = [t[i % (BLOWUP * spec["period"])] for t in per_lde]
+        cv = spec["constraints"](cur, nxt, per)
         acc = sum(a * c for a, c in zip(alphas, cv)) % P
         out.append(acc * zinv[i % BLOWUP] % P)
     return out
 
 
-def periodic_lde(n, shift=GEN):
-    """Periodic columns evaluated on the LDE coset: q(x^(n/512)) with x = shift * w_{4n}^i takes
-    4*512 distinct values = the blowup-4 LDE of the 512 column values with shift^(n/512)."""
-    return [lde(col, BLOWUP, pow(shift, n // 512, P)) for col in periodic_columns()]
+def periodic_lde(n, shift=GEN, air="pedersen"):
+    """Periodic columns evaluated on the LDE coset: q(x^(n/period)) with x = shift * w_{4n}^i takes
+    4*period distinct values = the blowup-4 LDE of the column values with shift^(n/period)."""
+    spec = AIRS[air]
+    return [lde(col, BLOWUP, pow(shift, n // spec["period"], P)) for col in spec["periodic"]()]
 
 
 # ---- FRI ---------------------------------------------------------------------------------------
@@ -215,20 +288,21 @@ def _root_from_path(leaf, index, path, hash2):
     return node
 
 
-def verify_proof(proof, hash2=R.pedersen_hash, final_log=6):
+def verify_proof(proof, hash2=R.pedersen_hash, final_log=6, air=None):
     """Checks a proof produced by the GPU prover: Merkle openings, the AIR relation between the
     opened trace rows and the composition column at every queried point, FRI fold consistency down
     to the final layer, and the degree bound of the final layer.  Returns (ok, reason)."""
     n, seed, shift = proof["n"], proof["seed"], proof["shift"]
+    spec = AIRS[air or proof.get("air", "pedersen")]
     m = BLOWUP * n
     log_m = m.bit_length() - 1
     root_t, roots, final = proof["trace_root"], proof["layer_roots"], proof["final_layer"]
     n_layers = log_m - final_log
     if len(roots) != n_layers or len(final) != 1 << final_log:
         return False, "shape"
-    alphas = [transcript_challenge("alpha", seed, root_t, k) for k in range(N_CONSTRAINTS)]
+    alphas = [transcript_challenge("alpha", seed, root_t, k) for k in range(spec["n_constraints"])]
     betas = [transcript_challenge("beta", seed, roots[k], k + 1) for k in range(n_layers)]
-    per = periodic_lde(n, shift)
+    per = periodic_lde(n, shift, air or proof.get("air", "pedersen"))
     w = root_of_unity(log_m)
     zinv = [pow((pow(shift, n, P) * pow(w, n * k, P) - 1) % P, -1, P) for k in range(BLOWUP)]
     # final layer: degree < 3n / 2^n_layers on the domain shift^(2^n_layers) * <w_64>
@@ -254,8 +328,8 @@ def verify_proof(proof, hash2=R.pedersen_hash, final_log=6):
         # composition at the two layer-0 positions must follow from the trace openings
         for side, pos in enumerate((j, j + m // 2)):
             cur, nxt = q["trace"][2 * side]["values"], q["trace"][2 * side + 1]["values"]
-            pv = [tab[pos % (BLOWUP * 512)] for tab in per]
-            cv = constraint_values(cur, nxt, pv)
+            pv = [tab[pos % (BLOWUP * spec["period"])] for tab in per]
+            cv = spec["constraints"](cur, nxt, pv)
             expect = sum(a * c for a, c in zip(alphas, cv)) % P * zinv[pos % BLOWUP] % P
             if q["layers"][0][side]["value"] != expect:
                 return False, "composition value"

@@ -239,6 +239,185 @@ pedersen_trace_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
   }
 }
 
+// ---- EC-ladder AIR (the ECDSA builtin's building block, signature.py:176-190) --------------------
+// Columns m, px, py, qx, qy, la, ld; 256 rows per mimic_ec_mult_air instance (oracle/stark_ref.py
+// ec_ladder_trace).  Witness generation, one thread per ladder: the doubling chain in Jacobian
+// coordinates, the partial sums in XYZZ, and four batched inversions per ladder (1/Z of the
+// doubled points, 1/(2 qy) for the tangent slopes, 1/ZZZ of the partial sums, 1/(px - qx) for the
+// chord slopes).  Eight scratch planes [row][limb][ladder].
+__global__ void __launch_bounds__(64)
+ec_ladder_trace_kernel(const uint64_t* __restrict__ pm, const uint64_t* __restrict__ pqx,
+                       const uint64_t* __restrict__ pqy, size_t K, aff_packed shift,
+                       uint64_t* __restrict__ cols /* [7][256 K] plain */, int32_t* __restrict__ sc) {
+  const size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= K) return;
+  const size_t n = 256 * K;
+  const size_t plane = (size_t)256 * NL * K;
+  int32_t *qX = sc, *qY = sc + plane, *qZ = sc + 2 * plane, *pX = sc + 3 * plane, *pY = sc + 4 * plane,
+          *pZZ = sc + 5 * plane, *pZZZ = sc + 6 * plane, *pre = sc + 7 * plane;
+  uint64_t *cm = cols, *cpx = cols + 4 * n, *cpy = cols + 8 * n, *cqx = cols + 12 * n, *cqy = cols + 16 * n,
+           *cla = cols + 20 * n, *cld = cols + 24 * n;
+  const size_t row0 = 256 * h;
+  const u256 m0 = ld_u256(pm + 4 * h);
+  u256 zero;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) zero.w[q] = 0;
+  // m column
+  {
+    u256 s = m0;
+    for (int j = 0; j < 256; ++j) {
+      st_u256(cm + 4 * (row0 + j), s);
+      if (j < 255) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) s.w[q] = (s.w[q] >> 1) | (s.w[q + 1] << 31);
+        s.w[7] >>= 1;
+      }
+    }
+  }
+  // phase 1: doubling chain, Jacobian -> affine with one inversion
+  jac Q;
+  Q.X = fe_to_mont(fe_unpack(ld_u256(pqx + 4 * h)));
+  Q.Y = fe_to_mont(fe_unpack(ld_u256(pqy + 4 * h)));
+  Q.Z = FE_ONE_M;
+  fe run = FE_ONE_M;
+  for (int j = 0; j < 256; ++j) {
+    tr_store(qX, K, j, h, Q.X);
+    tr_store(qY, K, j, h, Q.Y);
+    tr_store(qZ, K, j, h, Q.Z);
+    tr_store(pre, K, j, h, run);
+    run = fe_mul(run, Q.Z);
+    if (j < 255) Q = jac_dbl(Q, FE_ONE_M);
+  }
+  fe inv = fe_inv(run);
+  for (int j = 255; j >= 0; --j) {
+    const fe z = tr_load(qZ, K, j, h);
+    const fe iz = fe_mul(inv, tr_load(pre, K, j, h));
+    inv = fe_mul(inv, z);
+    const fe iz2 = fe_sqr(iz);
+    const fe ax = fe_mul(tr_load(qX, K, j, h), iz2);
+    const fe ay = fe_mul(tr_load(qY, K, j, h), fe_mul(iz2, iz));
+    tr_store(qX, K, j, h, ax);
+    tr_store(qY, K, j, h, ay);
+    st_u256(cqx + 4 * (row0 + j), fe_pack(fe_from_mont(ax)));
+    st_u256(cqy + 4 * (row0 + j), fe_pack(fe_from_mont(ay)));
+  }
+  // phase 2: tangent slopes ld = (3 qx^2 + 1) / (2 qy), rows 0..254
+  run = FE_ONE_M;
+  for (int j = 0; j < 255; ++j) {
+    tr_store(pre, K, j, h, run);
+    run = fe_mul(run, fe_carry(fe_dbl(tr_load(qY, K, j, h))));
+  }
+  inv = fe_inv(run);
+  st_u256(cld + 4 * (row0 + 255), zero);
+  for (int j = 254; j >= 0; --j) {
+    const fe d = fe_carry(fe_dbl(tr_load(qY, K, j, h)));
+    const fe id = fe_mul(inv, tr_load(pre, K, j, h));
+    inv = fe_mul(inv, d);
+    const fe xx = fe_sqr(tr_load(qX, K, j, h));
+    const fe num = fe_carry(fe_add(fe_carry(fe_add(fe_dbl(xx), xx)), FE_ONE_M));
+    st_u256(cld + 4 * (row0 + j), fe_pack(fe_from_mont(fe_mul(num, id))));
+  }
+  // phase 3: partial sums in XYZZ, then affine with one inversion
+  xyzz acc = xyzz_from_aff(ld_aff(&shift));
+  for (int j = 0; j < 256; ++j) {
+    tr_store(pX, K, j, h, acc.X);
+    tr_store(pY, K, j, h, acc.Y);
+    tr_store(pZZ, K, j, h, acc.ZZ);
+    tr_store(pZZZ, K, j, h, acc.ZZZ);
+    if (j < 251 && ((m0.w[j >> 5] >> (j & 31)) & 1u)) {
+      aff q;
+      q.x = tr_load(qX, K, j, h);
+      q.y = tr_load(qY, K, j, h);
+      acc = xyzz_madd(acc, q);
+    }
+  }
+  run = FE_ONE_M;
+  for (int j = 0; j < 256; ++j) {
+    tr_store(pre, K, j, h, run);
+    run = fe_mul(run, tr_load(pZZZ, K, j, h));
+  }
+  inv = fe_inv(run);
+  for (int j = 255; j >= 0; --j) {
+    const fe zzz = tr_load(pZZZ, K, j, h);
+    const fe izzz = fe_mul(inv, tr_load(pre, K, j, h));
+    inv = fe_mul(inv, zzz);
+    const fe iz = fe_mul(tr_load(pZZ, K, j, h), izzz);
+    const fe ax = fe_mul(tr_load(pX, K, j, h), fe_sqr(iz));
+    const fe ay = fe_mul(tr_load(pY, K, j, h), izzz);
+    tr_store(pX, K, j, h, ax);
+    tr_store(pY, K, j, h, ay);
+    st_u256(cpx + 4 * (row0 + j), fe_pack(fe_from_mont(ax)));
+    st_u256(cpy + 4 * (row0 + j), fe_pack(fe_from_mont(ay)));
+  }
+  // phase 4: chord slopes la = (py - qy) / (px - qx) on the addition rows
+  run = FE_ONE_M;
+  for (int j = 0; j < 251; ++j) {
+    if ((m0.w[j >> 5] >> (j & 31)) & 1u) {
+      const fe dx = fe_carry(fe_sub(tr_load(pX, K, j, h), tr_load(qX, K, j, h)));
+      tr_store(pZZ, K, j, h, dx);
+      tr_store(pre, K, j, h, run);
+      run = fe_mul(run, dx);
+    }
+  }
+  inv = fe_inv(run);
+  for (int j = 255; j >= 0; --j) {
+    u256 out = zero;
+    if (j < 251 && ((m0.w[j >> 5] >> (j & 31)) & 1u)) {
+      const fe dx = tr_load(pZZ, K, j, h);
+      const fe idx = fe_mul(inv, tr_load(pre, K, j, h));
+      inv = fe_mul(inv, dx);
+      const fe lam = fe_mul(fe_sub(tr_load(pY, K, j, h), tr_load(qY, K, j, h)), idx);
+      out = fe_pack(fe_from_mont(lam));
+    }
+    st_u256(cla + 4 * (row0 + j), out);
+  }
+}
+
+struct EcAirParams {
+  fe alpha[12];
+  fe zinv[4];
+  fe shift_x, shift_y;
+};
+
+__global__ void __launch_bounds__(256)
+air_eval_ec_ladder_kernel(const uint64_t* __restrict__ trace /* [7][M] plain */,
+                          const uint64_t* __restrict__ per /* [3][1024] plain */, size_t M, EcAirParams prm,
+                          uint64_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const size_t in = (i + 4) & (M - 1);
+  auto col = [&](int c, size_t r) { return fe_to_mont(ld_fe_packed(trace + 4 * ((size_t)c * M + r))); };
+  auto pcol = [&](int c) { return fe_to_mont(ld_fe_packed(per + 4 * ((size_t)c * 1024 + (i & 1023)))); };
+  const fe m = col(0, i), px = col(1, i), py = col(2, i), qx = col(3, i), qy = col(4, i), la = col(5, i),
+           ld = col(6, i);
+  const fe m_n = col(0, in), px_n = col(1, in), py_n = col(2, in), qx_n = col(3, in), qy_n = col(4, in);
+  const fe step = pcol(0), first = pcol(1), z251 = pcol(2);
+  const fe b = fe_carry(fe_sub(m, fe_dbl(m_n)));
+  const fe nb = fe_carry(fe_sub(FE_ONE_M, b));
+  fe c[9];
+  c[0] = fe_mul(b, fe_carry(fe_sub(b, FE_ONE_M)));
+  // doubling: ld 2 qy - 3 qx^2 - 1 ; qx' - ld^2 + 2 qx ; qy' - ld (qx - qx') + qy
+  const fe qxx = fe_sqr(qx);
+  c[1] = fe_carry(fe_sub(fe_sub(fe_mul(ld, fe_carry(fe_dbl(qy))), fe_carry(fe_add(fe_dbl(qxx), qxx))), FE_ONE_M));
+  c[2] = fe_carry(fe_add(fe_sub(qx_n, fe_sqr(ld)), fe_dbl(qx)));
+  c[3] = fe_carry(fe_add(fe_sub(qy_n, fe_mul(ld, fe_sub(qx, qx_n))), qy));
+  // addition (gated by b): la (px - qx) - (py - qy) ; px' - la^2 + px + qx ; py' - la (px - px') + py
+  c[4] = fe_mul(b, fe_carry(fe_sub(fe_mul(la, fe_sub(px, qx)), fe_sub(py, qy))));
+  c[5] = fe_mul(b, fe_carry(fe_add(fe_sub(px_n, fe_sqr(la)), fe_add(px, qx))));
+  c[6] = fe_mul(b, fe_carry(fe_add(fe_sub(py_n, fe_mul(la, fe_sub(px, px_n))), py)));
+  c[7] = fe_mul(nb, fe_carry(fe_sub(px_n, px)));
+  c[8] = fe_mul(nb, fe_carry(fe_sub(py_n, py)));
+  fe acc_step = fe_mul(prm.alpha[0], c[0]);
+#pragma unroll
+  for (int k = 1; k < 9; ++k) acc_step = fe_weak_reduce(fe_add(acc_step, fe_mul(prm.alpha[k], c[k])));
+  fe acc = fe_mul(step, acc_step);
+  const fe firsts = fe_mul_add_mul(prm.alpha[9], fe_carry(fe_sub(px, prm.shift_x)), prm.alpha[10],
+                                   fe_carry(fe_sub(py, prm.shift_y)));
+  acc = fe_weak_reduce(fe_add(acc, fe_mul(first, firsts)));
+  acc = fe_weak_reduce(fe_add(acc, fe_mul(prm.alpha[11], fe_mul(z251, m))));
+  st_u256(out + 4 * i, fe_pack(fe_from_mont(fe_mul(acc, prm.zinv[i & 3]))));
+}
+
 struct AirParams {
   fe alpha[11];  // Montgomery
   fe zinv[4];    // 1 / (x^n - 1) for i mod 4, Montgomery
@@ -573,6 +752,50 @@ int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, uns
   prm.shift_y = fe_to_mont(fe_unpack(PT_SHIFT_Y));
   hipLaunchKernelGGL(air_eval_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      trace_lde, periodic_lde, M, prm, out);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_ec_ladder_trace_dev(const uint64_t* m, const uint64_t* qx, const uint64_t* qy, size_t n_ladders,
+                           uint64_t* cols, void* stream) {
+  SP_REQUIRE_READY();
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  aff_packed shift;
+  shift.x = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_X))));
+  shift.y = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_Y))));
+  SP_HIP(g_tab.trace_scratch.reserve((size_t)8 * 256 * NL * n_ladders * sizeof(int32_t)));
+  hipLaunchKernelGGL(ec_ladder_trace_kernel, dim3((unsigned)((n_ladders + 63) / 64)), dim3(64), 0,
+                     (hipStream_t)stream, m, qx, qy, n_ladders, shift, cols, (int32_t*)g_tab.trace_scratch.ptr);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
+                              const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out,
+                              void* stream) {
+  SP_REQUIRE_READY();
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  const size_t n = (size_t)1 << log_n, M = 4 * n;
+  EcAirParams prm;
+  for (int k = 0; k < 12; ++k) {
+    u256 a;
+    std::memcpy(a.w, alphas_host + 4 * k, 32);
+    prm.alpha[k] = fe_to_mont(fe_unpack(a));
+  }
+  u256 sh;
+  std::memcpy(sh.w, shift_host, 32);
+  fe sn = fe_to_mont(fe_unpack(sh));
+  for (unsigned i = 0; i < log_n; ++i) sn = fe_sqr(sn);
+  const fe w4 = h_root_of_unity(2);
+  fe wk = FE_ONE_M;
+  for (int k = 0; k < 4; ++k) {
+    prm.zinv[k] = fe_inv(fe_carry(fe_sub(fe_mul(sn, wk), FE_ONE_M)));
+    wk = fe_mul(wk, w4);
+  }
+  prm.shift_x = fe_to_mont(fe_unpack(PT_SHIFT_X));
+  prm.shift_y = fe_to_mont(fe_unpack(PT_SHIFT_Y));
+  hipLaunchKernelGGL(air_eval_ec_ladder_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, trace_lde, periodic_lde, M, prm, out);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }

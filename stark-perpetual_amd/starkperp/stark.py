@@ -91,22 +91,52 @@ def periodic_columns():
     return [cx, cy, step, mid, end, z252]
 
 
-def periodic_lde(n, shift=FIELD_GEN, device="cuda"):
-    """[6, 2048, 4]: the periodic columns on the LDE coset (values repeat with period 4 * 512)."""
+def ec_ladder_periodic_columns():
+    """Period-256 selectors of the EC-ladder AIR: step (rows 0..254), first (row 0), z251."""
+    return [[0 if j == 255 else 1 for j in range(256)], [1 if j == 0 else 0 for j in range(256)],
+            [1 if j == 251 else 0 for j in range(256)]]
+
+
+N_EC_LADDER_CONSTRAINTS = 12
+AIRS = {
+    "pedersen": {"n_cols": 4, "period": 512, "n_constraints": N_CONSTRAINTS, "periodic": periodic_columns,
+                 "eval": "sp_air_eval_dev"},
+    "ec_ladder": {"n_cols": 7, "period": 256, "n_constraints": N_EC_LADDER_CONSTRAINTS,
+                  "periodic": ec_ladder_periodic_columns, "eval": "sp_air_eval_ec_ladder_dev"},
+}
+
+
+def periodic_lde(n, shift=FIELD_GEN, device="cuda", air="pedersen"):
+    """[k, 4 * period, 4]: the periodic columns on the LDE coset (they repeat with period 4 * period)."""
     torch = _torch()
-    cols = torch.stack([felts_to_tensor(c, device) for c in periodic_columns()])
-    return lde(cols, BLOWUP_LOG, pow(shift, n // 512, FIELD_PRIME))
+    spec = AIRS[air]
+    cols = torch.stack([felts_to_tensor(c, device) for c in spec["periodic"]()])
+    return lde(cols, BLOWUP_LOG, pow(shift, n // spec["period"], FIELD_PRIME))
 
 
-def air_eval(trace_lde, per_lde, n, alphas, shift=FIELD_GEN):
+def air_eval(trace_lde, per_lde, n, alphas, shift=FIELD_GEN, air="pedersen"):
     torch = _torch()
     lib = _lib.ensure_init()
-    assert len(alphas) == N_CONSTRAINTS and trace_lde.shape[1] == 4 * n
+    spec = AIRS[air]
+    assert len(alphas) == spec["n_constraints"] and trace_lde.shape[0] == spec["n_cols"]
+    assert trace_lde.shape[1] == 4 * n
     out = torch.empty((4 * n, 4), dtype=torch.int64, device=trace_lde.device)
-    _lib.check(lib.sp_air_eval_dev(trace_lde.data_ptr(), per_lde.data_ptr(), n.bit_length() - 1,
-                                   pack_felts(alphas), pack_felts([shift]), out.data_ptr(), _stream()),
-               "sp_air_eval_dev")
+    _lib.check(getattr(lib, spec["eval"])(trace_lde.data_ptr(), per_lde.data_ptr(), n.bit_length() - 1,
+                                          pack_felts(alphas), pack_felts([shift]), out.data_ptr(), _stream()),
+               spec["eval"])
     return out
+
+
+def ec_ladder_trace(ms, qxs, qys):
+    """ms, qxs, qys: [k, 4] device tensors (scalars 0 < m < 2^251, affine base points) ->
+    [7, 256 k, 4] witness of k mimic_ec_mult_air ladders (m, px, py, qx, qy, la, ld)."""
+    torch = _torch()
+    lib = _lib.ensure_init()
+    k = ms.shape[0]
+    cols = torch.empty((7, 256 * k, 4), dtype=torch.int64, device=ms.device)
+    _lib.check(lib.sp_ec_ladder_trace_dev(ms.data_ptr(), qxs.data_ptr(), qys.data_ptr(), k, cols.data_ptr(),
+                                          _stream()), "sp_ec_ladder_trace_dev")
+    return cols
 
 
 def fri_fold(layer, beta, shift):
@@ -192,19 +222,31 @@ def _gather_felts(t, indices):
 
 
 def prove(xs, ys, n_queries: int = 8, seed: int = 0, final_log: int = 6, shift: int = FIELD_GEN):
-    """Proof that the trace of the hashes (xs[i], ys[i]) satisfies the Pedersen-step AIR:
-    commitments to the trace LDE, the composition column and every FRI layer, the final layer in
+    """Proof that the trace of the hashes (xs[i], ys[i]) satisfies the Pedersen-step AIR."""
+    return prove_trace(pedersen_trace(xs, ys), "pedersen", n_queries, seed, final_log, shift)
+
+
+def prove_ec_ladders(ms, qxs, qys, n_queries: int = 8, seed: int = 0, final_log: int = 6,
+                     shift: int = FIELD_GEN):
+    """Proof that k scalar multiplications m * Q + SHIFT_POINT were carried out step by step as
+    mimic_ec_mult_air does (the EC-ladder AIR)."""
+    return prove_trace(ec_ladder_trace(ms, qxs, qys), "ec_ladder", n_queries, seed, final_log, shift)
+
+
+def prove_trace(trace, air: str, n_queries: int = 8, seed: int = 0, final_log: int = 6,
+                shift: int = FIELD_GEN):
+    """Commitments to the trace LDE, the composition column and every FRI layer, the final layer in
     the clear, and for each query the openings a verifier needs (oracle/stark_ref.verify_proof)."""
     P = FIELD_PRIME
-    n = 512 * xs.shape[0]
+    spec = AIRS[air]
+    n = trace.shape[1]
     M = n << BLOWUP_LOG
-    trace = pedersen_trace(xs, ys)
     trace_lde = lde(trace)
     lv_trace = commit_rows(trace_lde)
     root_t = root_of(lv_trace)
-    alphas = [transcript_challenge("alpha", seed, root_t, k) for k in range(N_CONSTRAINTS)]
-    per = periodic_lde(n, shift, xs.device)
-    comp = air_eval(trace_lde, per, n, alphas, shift)
+    alphas = [transcript_challenge("alpha", seed, root_t, k) for k in range(spec["n_constraints"])]
+    per = periodic_lde(n, shift, trace.device, air)
+    comp = air_eval(trace_lde, per, n, alphas, shift, air)
     layers, level_bufs, roots = [comp], [], []
     s = shift
     while True:
@@ -225,7 +267,7 @@ def prove(xs, ys, n_queries: int = 8, seed: int = 0, final_log: int = 6, shift: 
         entry = {"index": j, "trace": [], "layers": []}
         for pos in (j, j + M // 2):
             for row in (pos, (pos + (1 << BLOWUP_LOG)) % M):
-                vals = [tensor_to_felts(trace_lde[c][row : row + 1])[0] for c in range(4)]
+                vals = [tensor_to_felts(trace_lde[c][row : row + 1])[0] for c in range(spec["n_cols"])]
                 entry["trace"].append({"row": row, "values": vals,
                                        "path": _gather_felts(lv_trace, _path_indices(M, row))})
         jk = j
@@ -238,5 +280,5 @@ def prove(xs, ys, n_queries: int = 8, seed: int = 0, final_log: int = 6, shift: 
                              "path": _gather_felts(lv, _path_indices(mk, pos))})
             entry["layers"].append(pair)
         queries.append(entry)
-    return {"n": n, "seed": seed, "shift": shift, "trace_root": root_t, "layer_roots": roots,
+    return {"n": n, "air": air, "seed": seed, "shift": shift, "trace_root": root_t, "layer_roots": roots,
             "final_layer": final, "queries": queries}

@@ -176,3 +176,41 @@ def test_prove_then_verify_full_size(stark):
     ok, why = S.verify_proof(proof, hash2=hash2)
     assert ok, why
     assert len(proof["layer_roots"]) == 16 and len(proof["final_layer"]) == 64
+
+
+def test_ec_ladder_air_matches_oracle_and_proves(stark):
+    """EC-ladder AIR (mimic_ec_mult_air as a trace): GPU witness and composition == oracle;
+    the ladder outputs are the reference's mimic_ec_mult_air results; prove -> verify round trip."""
+    import torch
+    rng = random.Random(33)
+    inputs = []
+    for _ in range(4):
+        q = R.ec_mult(rng.randrange(1, R.EC_ORDER), tuple(R.EC_GEN))
+        inputs.append((rng.randrange(1, 2**251), q))
+    inputs[1] = (2**251 - 1, tuple(R.EC_GEN))
+    inputs[2] = (1, inputs[2][1])
+    ms = stark.felts_to_tensor([m for m, _ in inputs])
+    qxs = stark.felts_to_tensor([q[0] for _, q in inputs])
+    qys = stark.felts_to_tensor([q[1] for _, q in inputs])
+    trace = stark.ec_ladder_trace(ms, qxs, qys)
+    exp = S.ec_ladder_trace(inputs)
+    for g, e in zip(trace, exp):
+        assert stark.tensor_to_felts(g) == e
+    for k, (m, q) in enumerate(inputs):
+        assert (exp[1][256 * k + 251], exp[2][256 * k + 251]) == R.mimic_ec_mult_air(m, q, R.SHIFT_POINT)
+    n = 1024
+    per = stark.periodic_lde(n, air="ec_ladder")
+    exp_per = S.periodic_lde(n, air="ec_ladder")
+    for g, e in zip(per, exp_per):
+        assert stark.tensor_to_felts(g) == e
+    alphas = [rng.randrange(P) for _ in range(S.N_EC_LADDER_CONSTRAINTS)]
+    trace_lde = stark.lde(trace)
+    comp = stark.air_eval(trace_lde, per, n, alphas, air="ec_ladder")
+    exp_comp = S.composition_on_coset([S.lde(c) for c in exp], exp_per, n, alphas, air="ec_ladder")
+    assert stark.tensor_to_felts(comp) == exp_comp
+    assert S.poly_degree_bound_check(exp_comp, S.GEN, 3 * n - 1)
+    proof = stark.prove_ec_ladders(ms, qxs, qys, n_queries=2, seed=5)
+    ok, why = S.verify_proof(proof)
+    assert ok, why
+    proof["queries"][0]["trace"][1]["values"][6] ^= 1
+    assert not S.verify_proof(proof)[0]

@@ -93,3 +93,29 @@ def test_commit_rows_small():
     leaves = [R.pedersen_hash(a, b) for a, b in zip(*cols)]
     assert S.commit_rows(cols) == R.merkle_root(leaves)
     assert S.commit_rows([[1, 2, 3, 4]]) == R.merkle_root([1, 2, 3, 4])
+
+
+def test_ec_ladder_air_trace_and_degree():
+    rng = random.Random(8)
+    q = R.ec_mult(rng.randrange(1, R.EC_ORDER), tuple(R.EC_GEN))
+    m = rng.randrange(1, 2**251)
+    inputs = [(m, q), (2**251 - 1, tuple(R.EC_GEN))]
+    cols = S.ec_ladder_trace(inputs)
+    n = len(cols[0])
+    assert n == 512
+    assert (cols[1][251], cols[2][251]) == R.mimic_ec_mult_air(m, q, R.SHIFT_POINT)
+    assert (cols[1][256 + 251], cols[2][256 + 251]) == R.mimic_ec_mult_air(2**251 - 1, R.EC_GEN, R.SHIFT_POINT)
+    per = S.ec_ladder_periodic_columns()
+    for i in range(n):
+        cur = [c[i] for c in cols]
+        nxt = [c[(i + 1) % n] for c in cols]
+        vals = S.ec_ladder_constraint_values(cur, nxt, [t[i % 256] for t in per])
+        assert all(v == 0 for v in vals), (i, vals)
+    alphas = [rng.randrange(P) for _ in range(S.N_EC_LADDER_CONSTRAINTS)]
+    per_lde = S.periodic_lde(n, air="ec_ladder")
+    comp = S.composition_on_coset([S.lde(c) for c in cols], per_lde, n, alphas, air="ec_ladder")
+    assert S.poly_degree_bound_check(comp, S.GEN, 3 * n - 1)
+    bad = [list(c) for c in cols]
+    bad[6][10] = (bad[6][10] + 1) % P
+    comp_bad = S.composition_on_coset([S.lde(c) for c in bad], per_lde, n, alphas, air="ec_ladder")
+    assert not S.poly_degree_bound_check(comp_bad, S.GEN, 3 * n - 1)
