@@ -271,7 +271,7 @@ def main():
                 "launches": int(k_launches.value),
                 "avg_launch_us": avg_launch_s * 1e6,
                 "timing": "HIP events around every launch inside the timed region",
-                "note": "integer-ALU bound kernel (DESIGN.md): ~2.9e3 v_mad_i64_i32 per window add; "
+                "note": "integer-ALU bound kernel (DESIGN.md): 39e3 VALU instructions per hash at the VALU issue limit; "
                         "HBM fraction is reported because the contract asks for it",
             },
         }

@@ -351,7 +351,7 @@ SP_HD fe fe_inv_fermat(const fe& a) {
 // Same structure as the constant-time modular inverse used for secp256k1 with 30-bit limbs, here
 // with 29-bit limbs: 21 rounds of 29 branch-free divsteps on the low limb build a 2x2 transition
 // matrix that is then applied to (f, g) exactly and to (d, e) modulo p.  21 * 29 = 609 >= 590
-// divsteps suffice for 256-bit operands (half-delta variant).  ~15k VALU instructions instead of
+// divsteps suffice for 256-bit operands (half-delta variant).  ~19k VALU instructions instead of
 // the ~40k of the Fermat chain above; identical for every lane, so no divergence.
 struct trans2x2 {
   int32_t u, v, q, r;

@@ -13,7 +13,7 @@
 //   scratch int32[9][n] x 3          : X, ZZ and prefix products, limb-major so that a wave's
 //                                      64 lanes touch 64 consecutive dwords
 // Algorithmic bytes per hash: 96 (two felts in, one out).  The kernel is VALU bound
-// (~3.3e3 v_mad_i64_i32 per window addition), not HBM bound - see DESIGN.md.
+// (~1.75e3 VALU instructions per window addition, 39e3 per hash), not HBM bound - see DESIGN.md.
 #include <cstdlib>
 #include <map>
 #include <vector>
@@ -85,7 +85,7 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
   }
   const size_t per = (size_t)1 << wbits;
   // The first entry initialises the accumulator; entries i+1 and i+2 are in flight (two 64-byte
-  // gathers) while entry i is added, which hides the random-HBM latency behind ~3.5k instructions.
+  // gathers) while entry i is added, which hides the random-HBM latency behind ~3.5e3 instructions of arithmetic.
   const int total = 2 * nwin;
   auto next_index = [&](int g) -> const aff_packed* {  // consumes the next window of x, then of y
     const uint32_t v = (g < nwin) ? pop_window(sx, wbits) : pop_window(sy, wbits);
