@@ -154,52 +154,50 @@ def main():
         return run_airfri(args, torch, dist, lib, _lib, dev, rank, world)
     n_leaves = 1 << HEIGHT
     n_streams = max(1, args.streams)
-    log_b = max(0, min(6, int(args.trees_per_call).bit_length() - 1))
-    B = 1 << log_b  # independent rebuilds advanced in lockstep by one sp_merkle_forest_dev call
+    B = max(1, min(64, int(args.trees_per_call)))  # independent rebuilds advanced in lockstep per call
 
-    def forest_felts(lt):
-        return sum(1 << (HEIGHT + lt - k) for k in range(HEIGHT + 1))
+    def forest_felts(nb):
+        return nb * (2 * n_leaves - 1)
 
-    leaves = seeded_felts(torch, n_leaves << log_b, 1000 + rank, dev)  # distinct leaves for every tree
+    leaves = seeded_felts(torch, n_leaves * B, 1000 + rank, dev)  # distinct leaves for every tree
 
     def plan(k):
-        """K steps (trees) as lockstep calls of <= B trees: greedy powers of two."""
-        out = []
-        while k > 0:
-            lt = min(log_b, k.bit_length() - 1)
-            out.append(lt)
-            k -= 1 << lt
-        return out
+        """K steps (trees) as lockstep calls of <= B trees each, spread evenly over at least as many
+        calls as there are streams (so that the latency-bound tops of the forests overlap)."""
+        if k <= 0:
+            return []
+        calls = max((k + B - 1) // B, min(n_streams, k))
+        base, rem = divmod(k, calls)
+        return [base + (1 if i < rem else 0) for i in range(calls)]
 
-    sizes = sorted(set([log_b] + plan(args.warmup) + plan(args.steps)))
+    sizes = sorted(set([B] + plan(args.warmup) + plan(args.steps)))
     slots = []
     for si in range(n_streams):
         bufs = {}
-        for lt in sizes:  # one forest buffer per call size; tree t always gets the same seeded leaves
-            lv = torch.zeros((forest_felts(lt), 4), dtype=torch.int64, device=dev)
-            lv[: n_leaves << lt] = leaves[: n_leaves << lt]
-            bufs[lt] = lv
+        for nb in sizes:  # one forest buffer per call size; tree t always gets the same seeded leaves
+            lv = torch.zeros((forest_felts(nb), 4), dtype=torch.int64, device=dev)
+            lv[: n_leaves * nb] = leaves[: n_leaves * nb]
+            bufs[nb] = lv
         slots.append({
             "levels": bufs,
             "gathered": torch.zeros((max(world, 1) * B, 4), dtype=torch.int64, device=dev),
             "top": torch.zeros((2 * max(world, 1) * B - B, 4), dtype=torch.int64, device=dev),
             "stream": torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream(device=dev),
         })
-    levels = slots[0]["levels"][log_b]
+    levels = slots[0]["levels"][B]
     stream = torch.cuda.current_stream().cuda_stream
     call_counter = [0]
 
-    def issue(lt):
-        """One lockstep call: 2^lt complete 2^16-leaf rebuilds (+ the cross-rank combine)."""
+    def issue(nb):
+        """One lockstep call: nb complete 2^16-leaf rebuilds (+ the cross-rank combine)."""
         sl = slots[call_counter[0] % n_streams]
         call_counter[0] += 1
-        nb = 1 << lt
         with torch.cuda.stream(sl["stream"]):
             h = sl["stream"].cuda_stream
-            buf = sl["levels"][lt]
-            _lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), lt, HEIGHT, None, h), "forest")
+            buf = sl["levels"][nb]
+            _lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), nb, HEIGHT, None, h), "forest")
             if world > 1:
-                combine_forest_dev(lib, dist, buf[buf.shape[0] - nb :], sl["gathered"], sl["top"], lt, h)
+                combine_forest_dev(lib, dist, buf[buf.shape[0] - nb :], sl["gathered"], sl["top"], nb, h)
 
     def fence():
         torch.cuda.synchronize()
@@ -208,16 +206,16 @@ def main():
         torch.cuda.synchronize()
 
     for sl in slots:  # size every stream's scratch before the timed region
-        issue(log_b)
-    for lt in plan(args.warmup):
-        issue(lt)
+        issue(B)
+    for nb in plan(args.warmup):
+        issue(nb)
     fence()
     timed_plan = plan(args.steps)
     launches_per_call = HEIGHT + 8
     _lib.check(lib.sp_profile_begin(len(timed_plan) * launches_per_call), "profile_begin")
     t0 = time.perf_counter()
-    for lt in timed_plan:
-        issue(lt)
+    for nb in timed_plan:
+        issue(nb)
     fence()
     elapsed = time.perf_counter() - t0
     k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
@@ -286,7 +284,7 @@ def main():
             # the sample doubles as one more parity check of the timed tree
             gpu_l1 = _lib.unpack_felts(
                 (ctypes.c_uint64 * (4 * len(cpu_out))).from_buffer_copy(
-                    levels[(n_leaves << log_b) : (n_leaves << log_b) + len(cpu_out)].cpu().numpy().astype("<i8").tobytes()),
+                    levels[n_leaves * B : n_leaves * B + len(cpu_out)].cpu().numpy().astype("<i8").tobytes()),
                 len(cpu_out))
             base["matches_gpu"] = gpu_l1 == cpu_out
             result["cpu_baseline"] = base

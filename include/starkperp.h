@@ -101,10 +101,10 @@ int sp_merkle_root(const uint64_t* leaves, unsigned height, uint64_t* root, uint
 /* Device version: `levels` is a device buffer of (2^(height+1) - 1) felts whose first 2^height
  * entries hold the leaves; the upper levels are written behind them, the root last. */
 int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void* stream);
-/* 2^log_trees independent trees of the same height in lockstep (one launch pair per level for all
- * of them).  Leaves of tree t at felts [t 2^height, (t+1) 2^height); the buffer is level-major with
- * sum_{k=0..height} 2^(log_trees + height - k) felts and ends with the 2^log_trees roots. */
-int sp_merkle_forest_dev(uint64_t* levels, unsigned log_trees, unsigned height, uint8_t* status,
+/* n_trees independent trees (any count) of the same height in lockstep: one launch pair per level
+ * for all of them.  Leaves of tree t at felts [t 2^height, (t+1) 2^height); the buffer is level-major
+ * with n_trees (2^(height+1) - 1) felts and ends with the n_trees roots. */
+int sp_merkle_forest_dev(uint64_t* levels, size_t n_trees, unsigned height, uint8_t* status,
                          void* stream);
 /* Sparse multi-update: root of the tree of the given height (<= 64) that holds new_leaves[i] at
  * keys[i] (strictly increasing) and `empty_leaf` everywhere else - the induced-subtree walk of

@@ -557,19 +557,20 @@ int sp_pedersen_chain_right(const uint64_t* elems, size_t n_elems, uint64_t* out
   return SP_OK;
 }
 
-// Forest of 2^log_trees independent trees of the given height, built in lockstep: the leaves of
-// all trees are concatenated (tree t owns leaves [t 2^height, (t+1) 2^height)), so level k of the
-// forest is one contiguous array of 2^(log_trees + height - k) nodes and ONE launch pair per level
-// serves every tree.  Stops after `height` levels: the last level holds the 2^log_trees roots.
-// Buffer: sum_{k=0..height} 2^(log_trees + height - k) felts, level-major, leaves first.
-int sp_merkle_forest_dev(uint64_t* levels, unsigned log_trees, unsigned height, uint8_t* status,
+// Forest of n_trees independent trees (any count) of the given height, built in lockstep: the
+// leaves of all trees are concatenated (tree t owns leaves [t 2^height, (t+1) 2^height)), so level k
+// of the forest is one contiguous array of n_trees 2^(height - k) nodes and ONE launch pair per
+// level serves every tree.  Stops after `height` levels: the last level holds the n_trees roots.
+// Buffer: n_trees (2^(height+1) - 1) felts, level-major, leaves first.
+int sp_merkle_forest_dev(uint64_t* levels, size_t n_trees, unsigned height, uint8_t* status,
                          void* stream) {
   SP_REQUIRE_READY();
-  if (height + log_trees > 40) { set_error("forest too large"); return SP_ERR_BAD_ARGUMENT; }
+  if (n_trees == 0) return SP_OK;
+  if (height > 40 || (n_trees >> (40 - height)) != 0) { set_error("forest too large"); return SP_ERR_BAD_ARGUMENT; }
   Context& c = ctx();
   std::lock_guard<std::mutex> lk(c.mu);
   hipStream_t st = (hipStream_t)stream;
-  const size_t n0 = (size_t)1 << (height + log_trees);
+  const size_t n0 = n_trees << height;
   Scratch s;
   int rc = get_scratch(n0 / 2 + 1, s, st);
   if (rc != SP_OK) return rc;
@@ -587,7 +588,7 @@ int sp_merkle_forest_dev(uint64_t* levels, unsigned log_trees, unsigned height, 
 }
 
 int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void* stream) {
-  return sp_merkle_forest_dev(levels, 0, height, status, stream);
+  return sp_merkle_forest_dev(levels, 1, height, status, stream);
 }
 
 int sp_merkle_root(const uint64_t* leaves, unsigned height, uint64_t* root, uint64_t* levels_out,

@@ -40,7 +40,7 @@ _SIGNATURES = {
     "sp_merkle_root": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p]),
     "sp_merkle_build_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]),
-    "sp_merkle_forest_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p,
+    "sp_merkle_forest_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
                                             ctypes.c_void_p]),
     "sp_merkle_sparse_root": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                              ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,

@@ -145,25 +145,25 @@ def merkle_root(leaves):
 
 
 def merkle_roots_many(trees):
-    """Roots of 2^k independent trees of equal power-of-two size, built in lockstep
+    """Roots of any number of independent trees of equal power-of-two size, built in lockstep
     (sp_merkle_forest_dev: one launch pair per level for all trees)."""
     import torch  # device staging for the forest buffer
     count = len(trees)
-    assert count >= 1 and count & (count - 1) == 0
+    assert count >= 1
     n = len(trees[0])
     assert n >= 1 and n & (n - 1) == 0 and all(len(t) == n for t in trees)
-    height, log_trees = n.bit_length() - 1, count.bit_length() - 1
+    height = n.bit_length() - 1
     flat = [v for t in trees for v in t]
     for v in flat:
         assert 0 <= v < FIELD_PRIME
     lib = _lib.ensure_init()
-    total = sum(1 << (height + log_trees - k) for k in range(height + 1))
+    total = count * (2 * n - 1)
     import numpy as np
     raw = b"".join(int(v).to_bytes(32, "little") for v in flat)
     buf = torch.zeros((total, 4), dtype=torch.int64, device="cuda")
     buf[: len(flat)] = torch.from_numpy(np.frombuffer(raw, dtype="<i8").reshape(len(flat), 4).copy()).cuda()
     st = new_bytes(1)
-    _lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), log_trees, height, st,
+    _lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), count, height, st,
                                         torch.cuda.current_stream().cuda_stream), "sp_merkle_forest_dev")
     torch.cuda.synchronize()
     if st[0]:

@@ -85,16 +85,15 @@ def combine_forest_subroots(dist, torch, local_roots: Sequence[int], hash_many, 
     return [combine_subroots(leaves[t * world : (t + 1) * world], hash_many) for t in range(nb)]
 
 
-def combine_forest_dev(lib, dist, roots, gathered, top, log_trees: int, stream):
+def combine_forest_dev(lib, dist, roots, gathered, top, nb: int, stream):
     """Device-resident version used by bench.py.  roots: [nb, 4] view of this rank's sub-roots;
     gathered: >= [world * nb, 4]; top: >= [nb * (2 * world - 1), 4].  One all_gather (RCCL) of
-    world * nb * 32 bytes, then the nb top trees as one lockstep forest of height log2(world)."""
+    world * nb * 32 bytes, then the nb top trees (any nb) as one lockstep forest of height log2(world)."""
     from . import _lib
-    nb = 1 << log_trees
     world = dist.get_world_size()
     g = gathered[: world * nb]
     dist.all_gather_into_tensor(g, roots)
     top[: world * nb] = g.reshape(world, nb, 4).transpose(0, 1).reshape(world * nb, 4)
-    _lib.check(lib.sp_merkle_forest_dev(top.data_ptr(), log_trees, world.bit_length() - 1, None, stream),
+    _lib.check(lib.sp_merkle_forest_dev(top.data_ptr(), nb, world.bit_length() - 1, None, stream),
                "sp_merkle_forest_dev")
     return top[nb * (2 * world - 1) - nb : nb * (2 * world - 1)]

@@ -106,8 +106,7 @@ def test_combine_forest_dev_with_fake_collective():
 
     lib = _lib.ensure_init()
     for world in (2, 4):
-        for log_trees in (0, 2):
-            nb = 1 << log_trees
+        for nb in (1, 3, 4):
             rng = random.Random(world * 10 + nb)
             per_rank = [[rng.randrange(P) for _ in range(nb)] for _ in range(world)]  # [rank][tree]
 
@@ -124,7 +123,7 @@ def test_combine_forest_dev_with_fake_collective():
             roots = stark.felts_to_tensor(per_rank[0])
             gathered = torch.zeros((world * nb, 4), dtype=torch.int64, device="cuda")
             top = torch.zeros((nb * (2 * world - 1), 4), dtype=torch.int64, device="cuda")
-            out = combine_forest_dev(lib, FakeDist, roots, gathered, top, log_trees,
+            out = combine_forest_dev(lib, FakeDist, roots, gathered, top, nb,
                                      torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             got = stark.tensor_to_felts(out)

@@ -15,7 +15,7 @@ for lt in (0, 2, 4, 5, 6):
     lv = torch.zeros((total, 4), dtype=torch.int64, device="cuda")
     t = torch.randint(-(2**63), 2**63 - 1, (n0, 4), dtype=torch.int64, generator=g); t[:, 3] &= (1 << 58) - 1
     lv[:n0] = t.cuda()
-    def run(): _lib.check(lib.sp_merkle_forest_dev(lv.data_ptr(), lt, H, None, st), "forest")
+    def run(): _lib.check(lib.sp_merkle_forest_dev(lv.data_ptr(), 1 << lt, H, None, st), "forest")
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
