@@ -147,3 +147,60 @@ def hash_position_updates(updates: Sequence[Tuple[int, Position, Position]]):
     for i, hnew in zip(changed, new_h):
         out[i] = (updates[i][0], prev[i], hnew)
     return out
+
+
+# ---- the per-batch state-root update ------------------------------------------------------------
+def squash_updates(accesses: Sequence[Tuple[int, object, object]]):
+    """squash_dict semantics (state/state.cairo:67-96): a chronological list of
+    (key, prev_value, new_value) accesses -> one (key, first_prev, last_new) per key, sorted by key;
+    every access must continue from the previous value of its key."""
+    first, last = {}, {}
+    for key, prev, new in accesses:
+        if key in last:
+            assert last[key] == prev, "inconsistent dict access for key %d" % key
+        else:
+            first[key] = prev
+        last[key] = new
+    return [(k, first[k], last[k]) for k in sorted(first)]
+
+
+class SharedState:
+    """The two roots of services/perpetual/cairo/state/state.cairo:99-107 with their sparse trees
+    (leaf of the positions tree = position_hash, empty leaf = hash of the empty position; leaf of
+    the orders tree = fulfilled amount, empty leaf 0)."""
+
+    EMPTY_POSITION: Position = (0, 0, ())
+
+    def __init__(self, positions_tree_height: int = 64, orders_tree_height: int = 64, hash_many=None,
+                 position_hashes=None):
+        self._position_hashes = position_hashes or position_hashes_many
+        empty_leaf = self._position_hashes([self.EMPTY_POSITION])[0]
+        self.positions = SparseMerkleTree(positions_tree_height, empty_leaf, hash_many)
+        self.orders = SparseMerkleTree(orders_tree_height, 0, hash_many)
+
+    @property
+    def positions_root(self) -> int:
+        return self.positions.root
+
+    @property
+    def orders_root(self) -> int:
+        return self.orders.root
+
+    def apply_state_updates(self, position_accesses, order_accesses):
+        """shared_state_apply_state_updates (state/state.cairo:135-186): squash, hash the previous
+        and new positions (hash_position_updates), check the previous leaves against the tree,
+        merkle-multi-update both trees.  Returns ((old_pos_root, new_pos_root), (old_ord, new_ord))."""
+        pos = squash_updates(position_accesses)
+        prev_h = self._position_hashes([p for _, p, _ in pos])
+        changed = [i for i, (_, p, q) in enumerate(pos) if p != q]
+        new_h = list(prev_h)
+        for i, hv in zip(changed, self._position_hashes([pos[i][2] for i in changed])):
+            new_h[i] = hv
+        for (key, _, _), hv in zip(pos, prev_h):
+            assert self.positions.get(key) == hv, "previous position does not match the tree"
+        pos_roots = self.positions.update({k: hv for (k, _, _), hv in zip(pos, new_h)})
+        orders = squash_updates(order_accesses)
+        for key, prev, _ in orders:
+            assert self.orders.get(key) == prev, "previous order state does not match the tree"
+        ord_roots = self.orders.update({k: new for k, _, new in orders})
+        return pos_roots, ord_roots

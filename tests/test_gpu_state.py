@@ -129,3 +129,16 @@ def test_combine_forest_dev_with_fake_collective():
             got = stark.tensor_to_felts(out)
             exp = [R.merkle_root([per_rank[r][t] for r in range(world)]) for t in range(nb)]
             assert got == exp, (world, nb)
+
+
+def test_shared_state_on_gpu_matches_oracle_twin():
+    from starkperp.state import SharedState
+    ph = lambda ps: [R.position_hash(p[0], p[1], list(p[2])) for p in ps]
+    oracle_hash_many = lambda a, b: [R.pedersen_hash(x, y) for x, y in zip(a, b)]
+    gpu, ref = SharedState(64, 64), SharedState(64, 64, hash_many=oracle_hash_many, position_hashes=ph)
+    assert gpu.positions_root == ref.positions_root and gpu.orders_root == ref.orders_root
+    empty = (0, 0, ())
+    poss = wl.positions(6, seed=9)
+    accesses = [(1000 + 77 * i, empty, tuple([p[0], p[1], tuple(p[2])])) for i, p in enumerate(poss)]
+    orders = [(2**63 + i, 0, 5 * i + 1) for i in range(5)]
+    assert gpu.apply_state_updates(accesses, orders) == ref.apply_state_updates(accesses, orders)

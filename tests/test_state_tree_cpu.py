@@ -41,3 +41,30 @@ def test_height_64_two_far_keys():
     mods = {0: 9, 2**64 - 1: 7}
     assert tree.update(mods)[1] == R.merkle_multi_update_sparse(64, mods)
     assert tree.get(2**64 - 1) == 7 and tree.get(12345) == 0
+
+
+def test_shared_state_updates_with_oracle_hash():
+    """SharedState bookkeeping (squash, prev/new position hashing, dual-tree update) with the oracle
+    hash plugged in, against a from-scratch recomputation."""
+    import pytest
+    from starkperp.state import SharedState, squash_updates
+    assert squash_updates([(5, "a", "b"), (2, "x", "y"), (5, "b", "c")]) == [(2, "x", "y"), (5, "a", "c")]
+    with pytest.raises(AssertionError):
+        squash_updates([(5, "a", "b"), (5, "zzz", "c")])
+    ph = lambda ps: [R.position_hash(p[0], p[1], list(p[2])) for p in ps]
+    st = SharedState(8, 6, hash_many=oracle_hash_many, position_hashes=ph)
+    empty = (0, 0, ())
+    assert st.positions_root == R.empty_subtree_roots(8, R.position_hash(0, 0, []))[8]
+    p1 = (123, 50, ((7, 1, -2),))
+    p2 = (123, 40, ((7, 1, 3),))
+    q1 = (456, -9, ())
+    (old_p, new_p), (old_o, new_o) = st.apply_state_updates(
+        [(3, empty, p1), (200, empty, q1), (3, p1, p2)], [(9, 0, 10), (9, 10, 25), (1, 0, 4)])
+    leaves = {3: R.position_hash(p2[0], p2[1], list(p2[2])), 200: R.position_hash(q1[0], q1[1], [])}
+    assert new_p == R.merkle_multi_update_sparse(8, leaves, R.position_hash(0, 0, []))
+    assert new_o == R.merkle_multi_update_sparse(6, {9: 25, 1: 4}) and old_o == R.empty_subtree_roots(6)[6]
+    # a second batch continues from the stored state; a stale previous value is rejected
+    st.apply_state_updates([(200, q1, q1)], [(1, 4, 6)])
+    assert st.orders_root == R.merkle_multi_update_sparse(6, {9: 25, 1: 6})
+    with pytest.raises(AssertionError):
+        st.apply_state_updates([(3, p1, p1)], [])
