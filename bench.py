@@ -124,6 +124,11 @@ def main():
                     help="merkle = BASELINE.json configs[1] (default, the headline line); airfri = one "
                          "2^20-row AIR+FRI commit job per GPU per step (configs[3]; with N GPUs the "
                          "N * 2^20-row trace of configs[4] as disjoint row ranges, roots combined over RCCL)")
+    ap.add_argument("--window-bits", type=int, default=26,
+                    help="table window width: 26 = 120 GB of the 288 GB HBM as tables (10 windows per "
+                         "operand instead of 12, +12 %% on this workload, ~5 s to build, outside the timed "
+                         "region); 0 = the library default 21 = 4.5 GiB.  If the wide tables cannot be "
+                         "allocated the bench falls back to the library default and says so in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -149,7 +154,13 @@ def main():
     from starkperp import _lib
     from starkperp.distributed import combine_forest_dev
 
-    lib = _lib.ensure_init(local_rank)
+    try:
+        lib = _lib.ensure_init(local_rank, args.window_bits or None)
+    except _lib.StarkPerpError as e:
+        if not args.window_bits:
+            raise
+        sys.stderr.write("bench: %d-bit tables unavailable (%s); using the library default\n" % (args.window_bits, e))
+        lib = _lib.ensure_init(local_rank, None)
     if args.workload == "airfri":
         return run_airfri(args, torch, dist, lib, _lib, dev, rank, world)
     n_leaves = 1 << HEIGHT
