@@ -96,6 +96,26 @@ def cpu_baseline_c(leaf_ints, gpu_root):
             "root_matches_gpu": levels[-1][0] == gpu_root}
 
 
+def valu_issue(bulk_hashes_per_sec, window_bits):
+    """The roofline that actually bounds the hash kernels: wave64 VALU
+    instructions issued per second against 1024 SIMDs x one instruction per 4 cycles.  Instruction
+    counts per hash are the SQ_INSTS_VALU measurements in profiles/r01_valu_issue.json; None when
+    there is no measurement for this window width."""
+    try:
+        m = json.load(open(os.path.join(ROOT, "profiles", "r01_valu_issue.json")))
+        w = m["window_bits"][str(window_bits)]
+    except Exception:
+        return None
+    per_hash = w["accumulate_instr_per_hash"] + w["finish_instr_per_hash"]
+    achieved = bulk_hashes_per_sec * per_hash / 64.0
+    peak = m["simds"] * m["nominal_clock_ghz"] * 1e9 / m["cycles_per_wave64_valu_instr"]
+    return {"bound": "valu_issue", "workload": "2^22 independent hashes (bulk_pedersen_hashes_per_sec)",
+            "instr_per_hash": per_hash, "achieved": achieved, "peak": peak, "unit": "wave64 VALU instr/s",
+            "frac": achieved / peak,
+            "note": "peak at the nominal 2.4 GHz; the chip runs this kernel at about 1.94 GHz "
+                    "(GRBM_GUI_ACTIVE), where the measured issue interval is 4.2 cycles per SIMD"}
+
+
 def pmc_traffic_per_launch():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py: separate --pmc FETCH_SIZE and
@@ -416,6 +436,7 @@ def extras(torch, lib, _lib, dev, stream):
     out["bulk_pedersen_hashes_per_sec"] = n / s
     out["bulk_pedersen_batch"] = n
     del x, y, o
+    out["valu_issue"] = valu_issue(n / s, int(lib.sp_window_bits()))
 
     # BASELINE.json configs[2]: 4096 limit orders - message hashes, ECDSA verify, orders-tree update
     import random as _random

@@ -214,6 +214,51 @@ def sqrt_mod(n, p=FIELD_PRIME):
 
 
 # --------------------------------------------------------------------------------------------
+# Where the constants come from: nothing_up_my_sleeve_gen.py:50-91 (digits of pi)
+# --------------------------------------------------------------------------------------------
+def pi_digits(n_digits):
+    """The first n_digits decimal digits of pi as a string ("3141...", truncated, no rounding);
+    stands in for math_utils.pi_as_string (:28-33, mpmath), whose caller asks for 100 spare digits
+    and reads only the leading ones.  Machin: pi = 16 atan(1/5) - 4 atan(1/239), integers only."""
+    guard = 10**15
+    scale = 10 ** (n_digits - 1) * guard
+
+    def atan_inv(q):
+        total = term = scale // q
+        k, sign = 3, -1
+        while term:
+            term //= q * q
+            total += sign * (term // k)
+            k, sign = k + 2, -sign
+        return total
+
+    return str((16 * atan_inv(5) - 4 * atan_inv(239)) // guard)
+
+
+def generate_constant_points(n_points=6):
+    """nothing_up_my_sleeve_gen.py:50-91: beta = first 76 digits of pi + 379; base point i takes
+    its x from the i-th block of 76 digits (incremented until on the curve, y = the smaller root);
+    points 1, 2 (shift, generator) are kept as they are, point i > 2 is expanded into its 248
+    (i odd) or 4 (i even) successive doublings.  Returns (beta, table)."""
+    digits = pi_digits(76 * (1 + n_points) + 100)
+    beta = int(digits[:76]) + 379
+    table, i = [], 0
+    while i < n_points:
+        i += 1
+        x = int(digits[76 * i : 76 * (i + 1)])
+        while not is_quad_residue(x**3 + ALPHA * x + beta, FIELD_PRIME):
+            x += 1
+        pt = (x % FIELD_PRIME, sqrt_mod(x**3 + ALPHA * x + beta, FIELD_PRIME))
+        if i <= 2:
+            table.append(pt)
+            continue
+        for _ in range(248 if i % 2 == 1 else 4):
+            table.append(pt)
+            pt = ec_double(pt, ALPHA, FIELD_PRIME)
+    return beta, table
+
+
+# --------------------------------------------------------------------------------------------
 # ECDSA: signature.py:79-260
 # --------------------------------------------------------------------------------------------
 class InvalidPublicKeyError(Exception):

@@ -92,3 +92,30 @@ def sqrt_mod(n: int, p: int) -> int:
         t = t * c % p
         m = i
     return min(root, p - root)
+
+
+def pi_as_string(digits: int) -> str:
+    """math_utils.py:28-33: pi as decimal digits without the point ("314...").  The reference prints
+    mpmath's pi at `digits` significant digits; here: Machin's formula in integers with guard
+    digits, rounded to nearest at `digits` significant digits, trailing zeros dropped as mpmath's
+    str() does.  mpmath rounds through a binary intermediate, so its LAST digit or two can differ
+    from the correctly rounded decimal; the one caller (nothing_up_my_sleeve_gen.py:57) asks for
+    100 spare digits for exactly that reason and reads only the leading ones."""
+    assert digits >= 2
+    guard = 12
+    scale = 10 ** (digits - 1 + guard)
+
+    def arctan_inverse(q):
+        total = term = scale // q
+        q2, k, sign = q * q, 3, -1
+        while term:
+            term //= q2
+            total += sign * (term // k)
+            k, sign = k + 2, -sign
+        return total
+
+    pi_scaled = 16 * arctan_inverse(5) - 4 * arctan_inverse(239)
+    rounded = (pi_scaled + 10**guard // 2) // 10**guard  # `digits` significant digits
+    text = str(rounded)
+    fraction = text[1:].rstrip("0") or "0"
+    return "3" + fraction

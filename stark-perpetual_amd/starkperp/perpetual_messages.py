@@ -6,12 +6,26 @@ depth-d, width-n chains (sp_pedersen_chains_dev shape)."""
 from typing import Callable, Sequence
 
 from . import batch
+from .keccak import keccak256
 from .signature import pedersen_hash
 
 LIMIT_ORDER_WITH_FEES = 3
 TRANSFER = 4
 CONDITIONAL_TRANSFER = 5
 WITHDRAWAL_TO_ADDRESS = 7
+
+
+def build_condition(fact_registry_address: str, fact: bytes) -> int:
+    """Condition felt of a conditional transfer (perpetual_messages.py:15-21): Keccak-256 over the
+    packed (address, bytes32) pair, cut to its 250 low bits.  web3's solidityKeccak is replaced by
+    the host Keccak in starkperp.keccak; the address is 20 bytes of hex with or without "0x"."""
+    digits = fact_registry_address[2:] if fact_registry_address[:2] in ("0x", "0X") else fact_registry_address
+    address = bytes.fromhex(digits)
+    if len(address) != 20:
+        raise ValueError("fact registry address must be 20 bytes, got %d" % len(address))
+    if len(fact) != 32:
+        raise ValueError("fact must be 32 bytes, got %d" % len(fact))
+    return int.from_bytes(keccak256(address + bytes(fact)), "big") & (2**250 - 1)
 
 
 def _limit_order_words(asset_id_synthetic, asset_id_collateral, is_buying_synthetic, asset_id_fee,
@@ -34,6 +48,15 @@ def _transfer_words(kind, sender_position_id, receiver_position_id, src_fee_posi
     word0 = ((sender_position_id * 2**64 + receiver_position_id) * 2**64 + src_fee_position_id) * 2**32 + nonce
     word1 = (((kind * 2**64 + amount) * 2**64 + max_amount_fee) * 2**32 + expiration_timestamp) * 2**81
     return word0, word1
+
+
+def _withdrawal_word(position_id, nonce, amount, expiration_timestamp):
+    word = WITHDRAWAL_TO_ADDRESS
+    word = word * 2**64 + position_id
+    word = word * 2**32 + nonce
+    word = word * 2**64 + amount
+    word = word * 2**32 + expiration_timestamp
+    return word * 2**49
 
 
 def _fold(hash_function, words):
@@ -139,13 +162,8 @@ def get_withdrawal_to_address_msg_without_bounds(asset_id_collateral, position_i
                                                  expiration_timestamp, amount,
                                                  hash_function: Callable[..., int] = pedersen_hash) -> int:
     """perpetual_messages.py:192-209."""
-    word = WITHDRAWAL_TO_ADDRESS
-    word = word * 2**64 + position_id
-    word = word * 2**32 + nonce
-    word = word * 2**64 + amount
-    word = word * 2**32 + expiration_timestamp
-    word = word * 2**49
-    return _fold(hash_function, [asset_id_collateral, int(eth_address, 16), word])
+    return _fold(hash_function, [asset_id_collateral, int(eth_address, 16),
+                                 _withdrawal_word(position_id, nonce, amount, expiration_timestamp)])
 
 
 def get_withdrawal_to_address_msg(asset_id_collateral, position_id, eth_address, nonce,
@@ -208,3 +226,28 @@ def price_msgs_many(prices: Sequence[Sequence[int]]):
     xs = [(asset_pair << 40) + oracle for oracle, asset_pair, _, _ in prices]
     ys = [(price << 32) + ts for _, _, ts, price in prices]
     return batch.pedersen_hash_many(xs, ys)
+
+
+def withdrawal_to_address_msgs_many(withdrawals: Sequence[Sequence]):
+    """Many withdrawals to an address (6-tuples in get_withdrawal_to_address_msg argument order,
+    eth_address a hex string or an int): depth-3 chains."""
+    words = []
+    for asset_id_collateral, position_id, eth_address, nonce, expiration, amount in withdrawals:
+        address = int(eth_address, 16) if isinstance(eth_address, str) else int(eth_address)
+        words.append([asset_id_collateral, address, _withdrawal_word(position_id, nonce, amount, expiration)])
+    return batch.pedersen_chains_many(words)
+
+
+def verify_price_signatures_many(prices: Sequence[Sequence[int]], signatures: Sequence[Sequence[int]],
+                                 signer_keys: Sequence[int]):
+    """Oracle price quorum check (oracle/oracle_price.cairo:96-108): one message hash and one
+    signature verification per signed price, both batched.  prices[i] = (oracle_name, asset_pair,
+    timestamp, price), signatures[i] = (r, s), signer_keys[i] = the oracle's x-only Stark key.
+    Returns one bool per signed price (False for anything the reference's verify would reject or
+    assert on)."""
+    if not (len(prices) == len(signatures) == len(signer_keys)):
+        raise ValueError("prices, signatures and signer_keys must have the same length")
+    messages = price_msgs_many(prices)
+    codes = batch.verify_codes(messages, [r for r, _ in signatures], [s for _, s in signatures],
+                               list(signer_keys))
+    return [c == 1 for c in codes]

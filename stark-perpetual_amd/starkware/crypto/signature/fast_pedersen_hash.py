@@ -2,6 +2,9 @@
 `pedersen_hash(x, y) -> int` and the bytes32 variant `pedersen_hash_func`."""
 from starkperp.signature import pedersen_hash as _pedersen_hash
 
+LOW_PART_BITS = 248  # fast_pedersen_hash.py:17-18 (the 248 + 4 bit split of each element)
+LOW_PART_MASK = 2**248 - 1
+
 
 def pedersen_hash(x: int, y: int) -> int:
     return _pedersen_hash(x, y)

@@ -181,6 +181,17 @@ def test_messages(sig):
     assert spm.conditional_transfer_msgs_many(c) == [R.get_conditional_transfer_msg(*a) for a in c]
     pr = [(0x4D616B6572, 0x42544355534400000000000000000000 + i, 0x5F590C1E, 0xAC9F3163AD52B000) for i in range(3)]
     assert spm.price_msgs_many(pr) == [R.get_price_msg(*a) for a in pr]
+    wd = [(5 + i, 6, "0x%040x" % (0xabc + i), 7, 8, 9) for i in range(3)]
+    assert spm.withdrawal_to_address_msgs_many(wd) == [R.get_withdrawal_to_address_msg(*a) for a in wd]
+    assert spm.withdrawal_to_address_msgs_many([(5, 6, 0xabc, 7, 8, 9)]) == [
+        R.get_withdrawal_to_address_msg(5, 6, "0xabc", 7, 8, 9)]
+    # oracle price quorum: one hash + one verification per signed price (oracle_price.cairo:96-108)
+    keys = [R.private_to_stark_key(1000 + i) for i in range(3)]
+    zs = [R.get_price_msg(*a) for a in pr]
+    sigs = [R.sign(z % 2**251, 1000 + i) if z < 2**251 else (1, 1) for i, z in enumerate(zs)]
+    want = [z < 2**251 for z in zs]
+    assert spm.verify_price_signatures_many(pr, sigs, keys) == want
+    assert spm.verify_price_signatures_many(pr, sigs[1:] + sigs[:1], keys) == [False] * 3
     # the hash_function injection seam still works
     assert pm.get_price_msg(1, 2, 3, 4, hash_function=lambda a, b: a + b) == (2 << 40) + 1 + (4 << 32) + 3
 

@@ -1,0 +1,74 @@
+"""Host-side pieces of the message layer that need no GPU: Keccak-256 (for build_condition,
+reference perpetual_messages.py:15-21) and the word packers, checked with the oracle's Pedersen
+hash injected through the `hash_function=` seam."""
+import hashlib
+import json
+import os
+import random
+
+from oracle import ref_py as R
+from starkperp import keccak
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_keccak256_published_vectors():
+    assert keccak.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert keccak.keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+
+
+def test_sponge_matches_hashlib_sha3_for_every_block_boundary():
+    rng = random.Random(5)
+    for n in list(range(0, 140)) + [271, 272, 273, 1000]:
+        m = bytes(rng.randrange(256) for _ in range(n))
+        assert keccak.sponge256(m, 0x06) == hashlib.sha3_256(m).digest(), n
+
+
+def test_build_condition_is_the_masked_keccak_of_the_packed_pair():
+    from starkperp import perpetual_messages as pm
+    address = "0x" + "12" * 20
+    fact = bytes(range(32))
+    want = int.from_bytes(keccak.keccak256(bytes.fromhex("12" * 20) + fact), "big") % 2**250
+    assert pm.build_condition(address, fact) == want
+    assert pm.build_condition(address[2:], fact) == want
+    assert 0 <= want < R.FIELD_PRIME
+    for bad_address, bad_fact in [("0x1234", fact), (address, b"short")]:
+        try:
+            pm.build_condition(bad_address, bad_fact)
+        except ValueError:
+            continue
+        raise AssertionError("accepted a malformed condition input")
+
+
+def test_scalar_builders_with_the_oracle_hash_match_the_reference_kats():
+    """The four precomputed message files of the reference (perpetual_messages_test.py), through
+    our word packers with the oracle hash injected; no GPU involved."""
+    from starkperp import perpetual_messages as pm
+    m = json.load(open(os.path.join(GOLD, "reference_kats.json")))["perpetual_messages"]
+    H = R.pedersen_hash
+    for exp, d in m["limit_order"].items():
+        assert hex(pm.get_limit_order_msg(
+            d["assetIdSynthetic"], d["assetIdCollateral"], d["isBuyingSynthetic"], d["assetIdFee"],
+            d["amountSynthetic"], d["amountCollateral"], d["amountFee"], d["nonce"], d["positionId"],
+            d["expirationTimestamp"], hash_function=H)) == exp
+    for exp, d in m["withdrawal_to_address"].items():
+        assert hex(pm.get_withdrawal_to_address_msg(
+            d["assetIdCollateral"], d["positionId"], d["ethAddress"], d["nonce"],
+            d["expirationTimestamp"], d["amount"], hash_function=H)) == exp
+
+
+def test_pi_as_string_leading_digits():
+    from starkperp.math_utils import pi_as_string
+    for d in (2, 10, 77, 632):  # 632 = 76 * 7 + 100, the reference's request (nothing_up_my_sleeve_gen.py:57)
+        ours = pi_as_string(d)
+        assert ours[: max(1, d - 2)] == R.pi_digits(d)[: max(1, d - 2)]
+    try:
+        import mpmath
+    except ImportError:
+        return
+    saved = mpmath.mp.dps
+    try:
+        mpmath.mp.dps = 632
+        assert pi_as_string(632)[:600] == ("3" + str(mpmath.mp.pi)[2:])[:600]
+    finally:
+        mpmath.mp.dps = saved

@@ -31,6 +31,19 @@ def test_params_and_table_digest():
         assert R.CONSTANT_POINTS[int(i)] == [h(x), h(y)]
 
 
+def test_constants_rederived_from_the_digits_of_pi():
+    """nothing_up_my_sleeve_gen.py:50-91 restated: beta and all 506 points follow from pi alone and
+    equal the table whose digest the reference's pedersen_params.json gave."""
+    import hashlib
+    beta, table = R.generate_constant_points(6)
+    assert beta == R.BETA
+    m = hashlib.sha256()
+    for x, y in table:
+        m.update(x.to_bytes(32, "big") + y.to_bytes(32, "big"))
+    assert m.hexdigest() == load("params_digest.json")["constant_points_sha256"]
+    assert R.pi_digits(40) == "3141592653589793238462643383279502884197"
+
+
 def test_reference_hash_and_key_kats():
     k = load("reference_kats.json")
     for case in k["hash_test"].values():
