@@ -149,6 +149,9 @@ def main():
                          "operand instead of 12, +12 %% on this workload, ~5 s to build, outside the timed "
                          "region); 0 = the library default 21 = 4.5 GiB.  If the wide tables cannot be "
                          "allocated the bench falls back to the library default and says so in config")
+    ap.add_argument("--log-rows", type=int, default=20,
+                    help="airfri workload: log2 of the trace rows per GPU (20 = configs[3]; 24 = the whole "
+                         "configs[4] trace on ONE GPU, 14 GiB of columns and trees)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -334,16 +337,19 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
     rank) and combined into 17 job-level roots by hashing the log2(N) top levels on every rank."""
     import random
     from starkperp import stark
-    m = 2048
+    if not 10 <= args.log_rows <= 24:
+        raise SystemExit("--log-rows must be in 10..24")
+    m = 1 << (args.log_rows - 9)  # 512 trace rows per hash
+    log_lde = args.log_rows + 2
     P = stark.FIELD_PRIME
     xs, ys = seeded_felts(torch, m, 11 + 100 * rank, dev), seeded_felts(torch, m, 12 + 100 * rank, dev)
     rng = random.Random(13)
     alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
-    betas = [rng.randrange(P) for _ in range(16)]
+    betas = [rng.randrange(P) for _ in range(log_lde - 6)]
     trace = stark.pedersen_trace(xs, ys)  # witness generation is input preparation
     per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
     stream = torch.cuda.current_stream().cuda_stream
-    n_roots = 17
+    n_roots = 2 + (log_lde - 7)  # trace, composition, every FRI layer above 64 points
     roots_dev = torch.zeros((n_roots, 4), dtype=torch.int64, device=dev)
     gathered = torch.zeros((max(world, 1) * n_roots, 4), dtype=torch.int64, device=dev)
     tops = torch.zeros((n_roots, 2 * max(world, 1) - 1, 4), dtype=torch.int64, device=dev)
@@ -388,15 +394,17 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        hashes = 4 * (1 << 22) + (1 << 22) + sum((1 << k) for k in range(7, 22))
+        # trace rows: 3 chain hashes + 1 tree node per LDE row; then one tree per committed column
+        hashes = 4 * (1 << log_lde) + (1 << log_lde) + sum((1 << k) for k in range(7, log_lde))
         print(json.dumps({
             "metric": "air_fri_commits_per_sec", "value": world * args.steps / elapsed, "unit": "commits/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32x9 (29-bit limbs) mod p", "data": "synthetic",
-            "config": {"workload": "2^20-row Pedersen-step trace per GPU: LDE x4 -> commit -> AIR -> commit -> "
-                                   "16 FRI folds with 15 layer commits (BASELINE.json configs[3]; N GPUs = "
-                                   "configs[4] as N disjoint row ranges)",
+            "config": {"workload": "2^%d-row Pedersen-step trace per GPU: LDE x4 -> commit -> AIR -> commit -> "
+                                   "%d FRI folds with %d layer commits (BASELINE.json configs[3] at 2^20; N GPUs "
+                                   "= configs[4] as N disjoint row ranges; --log-rows 24 = configs[4] on one "
+                                   "GPU)" % (args.log_rows, log_lde - 6, log_lde - 7),
                        "rows_per_gpu": 512 * m, "pedersen_hashes_per_job": hashes,
                        "combine": "none" if world == 1 else "all_gather of 17 roots per rank + top hashes"},
             "roofline": None, "cpu_baseline": None,
@@ -486,7 +494,7 @@ def extras(torch, lib, _lib, dev, stream):
     rng = random.Random(13)
     P = stark.FIELD_PRIME
     alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
-    betas = [rng.randrange(P) for _ in range(16)]
+    betas = [rng.randrange(P) for _ in range(log_lde - 6)]
     trace = stark.pedersen_trace(xs, ys)          # witness generation, outside the timed job
     per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
     torch.cuda.synchronize()

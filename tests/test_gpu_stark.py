@@ -52,6 +52,44 @@ def test_ntt_roundtrip_and_linearity_large(stark):
         assert ev[i] == sum(v * pow(x, k, P) for k, v in coeffs.items()) % P
 
 
+def test_ntt_and_lde_at_the_maximum_size(stark):
+    """log_n = 26 (the C-ABI limit; 2^24 trace rows x blowup 4 = BASELINE.json configs[4] on one GPU):
+    round trip on random data, and a sparse polynomial checked against its definition both through
+    the plain NTT and through the coset LDE 2^24 -> 2^26."""
+    import torch
+    log_n = 26
+    n = 1 << log_n
+    g = torch.Generator().manual_seed(9)
+    a = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, generator=g)
+    a[:, 3] &= (1 << 58) - 1
+    a = a.cuda()
+    fa = stark.ntt(a)
+    assert torch.equal(stark.ntt(fa, inverse=True), a)
+    del a, fa
+    coeffs = {0: 5, 1: 7, 12345: 11, (1 << 24) - 1: 13}
+
+    def sparse(size):
+        t = torch.zeros((size, 4), dtype=torch.int64, device="cuda")
+        for k, v in coeffs.items():
+            t[k, 0] = v
+        return t
+
+    def f(x):
+        return sum(v * pow(x, k, P) for k, v in coeffs.items()) % P
+
+    ev = stark.ntt(sparse(n))
+    w = S.root_of_unity(log_n)
+    spots = [0, 1, 2, 777, n // 2, n - 1, 0x2345678]
+    got = stark.tensor_to_felts(ev[spots])
+    assert got == [f(pow(w, i, P)) for i in spots]
+    del ev
+    on_trace_domain = stark.ntt(sparse(1 << 24))  # f on <w_{2^24}>, degree < 2^24
+    ext = stark.lde(on_trace_domain.unsqueeze(0))[0]
+    assert ext.shape[0] == n
+    got = stark.tensor_to_felts(ext[spots])
+    assert got == [f(stark.FIELD_GEN * pow(w, i, P) % P) for i in spots]
+
+
 def test_lde_matches_oracle(stark):
     import torch
     rng = random.Random(3)
