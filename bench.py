@@ -131,9 +131,9 @@ def pmc_traffic_per_launch():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--trees-per-call", type=int, default=32,
+    ap.add_argument("--trees-per-call", type=int, default=64,
                     help="independent 2^16-leaf rebuilds advanced in lockstep by one library call "
                          "(sp_merkle_forest_dev: one launch pair per level serves all of them; the upper "
                          "levels of a single rebuild are latency-bound and leave most of the chip idle); "
@@ -144,6 +144,9 @@ def main():
                     help="merkle = BASELINE.json configs[1] (default, the headline line); airfri = one "
                          "2^20-row AIR+FRI commit job per GPU per step (configs[3]; with N GPUs the "
                          "N * 2^20-row trace of configs[4] as disjoint row ranges, roots combined over RCCL)")
+    ap.add_argument("--plan", default="",
+                    help="comma-separated call sizes (trees per lockstep call, issued round-robin over the "
+                         "streams) for the TIMED steps; must sum to --steps.  Default: see plan()")
     ap.add_argument("--window-bits", type=int, default=26,
                     help="table window width: 26 = 120 GB of the 288 GB HBM as tables (10 windows per "
                          "operand instead of 12, +12 %% on this workload, ~5 s to build, outside the timed "
@@ -193,18 +196,26 @@ def main():
     def forest_felts(nb):
         return nb * (2 * n_leaves - 1)
 
-    leaves = seeded_felts(torch, n_leaves * B, 1000 + rank, dev)  # distinct leaves for every tree
-
     def plan(k):
-        """K steps (trees) as lockstep calls of <= B trees each, spread evenly over at least as many
-        calls as there are streams (so that the latency-bound tops of the forests overlap)."""
+        """K steps (trees) as the fewest lockstep calls of <= B trees each, evenly sized.  Measured
+        (tools/plan_sweep*.sh): the larger the forest the better - one call of 64 beats two of 32 on
+        two streams (6.5 vs 6.1 x 10^8 hashes/s), and two calls of 64 on two streams overlap their
+        latency-bound tops (7.5 x 10^8)."""
         if k <= 0:
             return []
-        calls = max((k + B - 1) // B, min(n_streams, k))
+        calls = (k + B - 1) // B
         base, rem = divmod(k, calls)
         return [base + (1 if i < rem else 0) for i in range(calls)]
 
-    sizes = sorted(set([B] + plan(args.warmup) + plan(args.steps)))
+    if args.plan:
+        timed_plan = [int(v) for v in args.plan.split(",")]
+        if sum(timed_plan) != args.steps or min(timed_plan) < 1 or max(timed_plan) > 64:
+            raise SystemExit("--plan must be positive call sizes <= 64 summing to --steps")
+    else:
+        timed_plan = plan(args.steps)
+    sizes = sorted(set([B] + plan(args.warmup) + timed_plan))
+    max_b = sizes[-1]
+    leaves = seeded_felts(torch, n_leaves * max_b, 1000 + rank, dev)  # distinct leaves for every tree
     slots = []
     for si in range(n_streams):
         bufs = {}
@@ -214,8 +225,8 @@ def main():
             bufs[nb] = lv
         slots.append({
             "levels": bufs,
-            "gathered": torch.zeros((max(world, 1) * B, 4), dtype=torch.int64, device=dev),
-            "top": torch.zeros((2 * max(world, 1) * B - B, 4), dtype=torch.int64, device=dev),
+            "gathered": torch.zeros((max(world, 1) * max_b, 4), dtype=torch.int64, device=dev),
+            "top": torch.zeros((2 * max(world, 1) * max_b - max_b, 4), dtype=torch.int64, device=dev),
             "stream": torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream(device=dev),
         })
     levels = slots[0]["levels"][B]
@@ -240,11 +251,10 @@ def main():
         torch.cuda.synchronize()
 
     for sl in slots:  # size every stream's scratch before the timed region
-        issue(B)
+        issue(max_b)
     for nb in plan(args.warmup):
         issue(nb)
     fence()
-    timed_plan = plan(args.steps)
     launches_per_call = HEIGHT + 8
     _lib.check(lib.sp_profile_begin(len(timed_plan) * launches_per_call), "profile_begin")
     t0 = time.perf_counter()
@@ -287,6 +297,7 @@ def main():
                 "hashes_per_step": hashes_per_step,
                 "trees_per_call": B,
                 "streams": n_streams,
+                "timed_calls": timed_plan,
                 "window_bits": int(lib.sp_window_bits()),
                 "table_mib": lib.sp_table_bytes() / 2**20,
                 "combine": "none" if world == 1 else "all_gather of %d sub-roots (RCCL) + %d top hashes" % (
@@ -303,8 +314,9 @@ def main():
                 "launches": int(k_launches.value),
                 "avg_launch_us": avg_launch_s * 1e6,
                 "timing": "HIP events around every launch inside the timed region",
-                "note": "integer-ALU bound kernel (DESIGN.md): 39e3 VALU instructions per hash at the VALU issue limit; "
-                        "HBM fraction is reported because the contract asks for it",
+                "note": "integer-ALU bound kernel (DESIGN.md section 4): 33-39e3 VALU instructions per hash at the "
+                        "VALU issue limit (extra.valu_issue has that roofline); the HBM fraction is reported "
+                        "because the contract asks for it",
             },
         }
         if world == 1 and not args.no_extras:
@@ -494,7 +506,7 @@ def extras(torch, lib, _lib, dev, stream):
     rng = random.Random(13)
     P = stark.FIELD_PRIME
     alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
-    betas = [rng.randrange(P) for _ in range(log_lde - 6)]
+    betas = [rng.randrange(P) for _ in range(16)]
     trace = stark.pedersen_trace(xs, ys)          # witness generation, outside the timed job
     per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
     torch.cuda.synchronize()
