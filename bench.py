@@ -191,7 +191,7 @@ def main():
         return run_airfri(args, torch, dist, lib, _lib, dev, rank, world)
     n_leaves = 1 << HEIGHT
     n_streams = max(1, args.streams)
-    B = max(1, min(64, int(args.trees_per_call)))  # independent rebuilds advanced in lockstep per call
+    B = max(1, min(1024, int(args.trees_per_call)))  # independent rebuilds advanced in lockstep per call
 
     def forest_felts(nb):
         return nb * (2 * n_leaves - 1)
@@ -209,8 +209,8 @@ def main():
 
     if args.plan:
         timed_plan = [int(v) for v in args.plan.split(",")]
-        if sum(timed_plan) != args.steps or min(timed_plan) < 1 or max(timed_plan) > 64:
-            raise SystemExit("--plan must be positive call sizes <= 64 summing to --steps")
+        if sum(timed_plan) != args.steps or min(timed_plan) < 1 or max(timed_plan) > 1024:
+            raise SystemExit("--plan must be positive call sizes <= 1024 summing to --steps")
     else:
         timed_plan = plan(args.steps)
     sizes = sorted(set([B] + plan(args.warmup) + timed_plan))
