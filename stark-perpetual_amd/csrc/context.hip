@@ -198,7 +198,7 @@ using namespace sp;
 extern "C" {
 
 int sp_init(int device, int window_bits) {
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  ctx_lock lk(g_ctx.mu);
   int rc = init_locked(device, window_bits);
   if (rc != SP_OK && !g_ctx.ready) {
     if (g_ctx.ped) (void)hipFree(g_ctx.ped);
@@ -209,7 +209,7 @@ int sp_init(int device, int window_bits) {
 }
 
 void sp_shutdown(void) {
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  ctx_lock lk(g_ctx.mu);
   (void)hipDeviceSynchronize();
   sp::release_pedersen_state();
   sp::release_merkle_state();

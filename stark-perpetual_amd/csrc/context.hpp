@@ -46,8 +46,11 @@ struct Context {
   size_t table_bytes = 0;
   DeviceBuffer io;             // staging for host-pointer entry points
   DeviceBuffer io2;
-  std::mutex mu;
+  // Recursive: host-pointer entry points hold it across the staging copies AND the nested _dev
+  // call, so two host threads can never interleave on the shared staging buffers.
+  std::recursive_mutex mu;
 };
+using ctx_lock = std::lock_guard<std::recursive_mutex>;
 
 Context& ctx();
 void set_error(const std::string& s);
@@ -59,14 +62,29 @@ int hip_fail(hipError_t e, const char* what);
     if (e__ != hipSuccess) return hip_fail(e__, #call); \
   } while (0)
 
+// HIP's current device is per host thread: a thread other than the one that called sp_init would
+// otherwise launch on device 0.  Binds the library's device for the duration of an entry point and
+// puts the caller's own choice back afterwards.
+struct DeviceScope {
+  int previous = -1;
+  bool switched = false;
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&previous) == hipSuccess && previous != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(previous);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 #define SP_REQUIRE_READY()                                                        \
-  do {                                                                            \
-    if (!ctx().ready) {                                                           \
-      set_error("libstarkperp is not initialised (sp_init failed or not called; " \
-                "there is no CPU fallback)");                                     \
-      return SP_ERR_NOT_INITIALISED;                                              \
-    }                                                                             \
-  } while (0)
+  if (!ctx().ready) {                                                             \
+    set_error("libstarkperp is not initialised (sp_init failed or not called; "   \
+              "there is no CPU fallback)");                                       \
+    return SP_ERR_NOT_INITIALISED;                                                \
+  }                                                                               \
+  sp::DeviceScope sp_device_scope__(ctx().device)
 
 // ---- device helpers shared by the kernels ----
 __device__ __forceinline__ u256 ld_u256(const uint64_t* p) {

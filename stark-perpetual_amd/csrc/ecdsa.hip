@@ -328,7 +328,7 @@ int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* 
                           const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   const uint64_t* host[5] = {z, r, s, qx, qy};
   uint64_t* dev[5];
   char* extra;
@@ -346,7 +346,7 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
+  ctx_lock lk(c.mu);
   const uint64_t* host[3] = {z, d, k};
   uint64_t* dev[3];
   char* extra;
@@ -371,7 +371,7 @@ int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* 
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
+  ctx_lock lk(c.mu);
   const uint64_t* host[1] = {d};
   uint64_t* dev[1];
   char* extra;

@@ -58,7 +58,7 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
     if (height < 64 && (keys[i] >> height) != 0) { set_error("key out of range for height"); return SP_ERR_BAD_ARGUMENT; }
   }
   Context& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
+  ctx_lock lk(c.mu);
   // ---- host bookkeeping: induced subtree (merkle_tree.py:18-26) ----
   std::vector<uint64_t> idx(keys, keys + n);
   std::vector<int2> src;                 // all levels, concatenated

@@ -362,7 +362,7 @@ extern "C" {
 int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status,
                           size_t n, void* stream) {
   SP_REQUIRE_READY();
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   Scratch s;
   int rc = get_scratch(n, s, (hipStream_t)stream);
   if (rc != SP_OK) return rc;
@@ -373,7 +373,7 @@ int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
+  ctx_lock lk(c.mu);
   const size_t fb = n * 32;
   SP_HIP(c.io.reserve(3 * fb + n + 64));
   uint64_t* dx = (uint64_t*)c.io.ptr;
@@ -395,7 +395,7 @@ int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8
 
 int sp_profile_begin(size_t max_launches) {
   SP_REQUIRE_READY();
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   while (g_prof.ev.size() < 2 * max_launches) {
     hipEvent_t e;
     SP_HIP(hipEventCreate(&e));
@@ -409,7 +409,7 @@ int sp_profile_begin(size_t max_launches) {
 
 int sp_profile_end(double* total_ms, uint64_t* launches, uint64_t* units) {
   SP_REQUIRE_READY();
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   g_prof.enabled = false;
   double ms = 0;
   uint64_t u = 0;
@@ -431,7 +431,7 @@ int sp_pedersen_point_batch(const uint64_t* x, const uint64_t* y, uint64_t* ox, 
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
+  ctx_lock lk(c.mu);
   const size_t fb = n * 32;
   SP_HIP(c.io.reserve(4 * fb + n + 64));
   char* b = (char*)c.io.ptr;
@@ -457,7 +457,7 @@ int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, ui
   if (depth < 1) { set_error("chain depth must be >= 1"); return SP_ERR_BAD_ARGUMENT; }
   if (width == 0) return SP_OK;
   Context& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
+  ctx_lock lk(c.mu);
   hipStream_t st = (hipStream_t)stream;
   Scratch s;
   int rc = get_scratch(width, s, st);
@@ -484,14 +484,11 @@ int sp_pedersen_chains(const uint64_t* elems, size_t width, size_t depth, uint64
   if (depth < 1) { set_error("chain depth must be >= 1"); return SP_ERR_BAD_ARGUMENT; }
   if (width == 0) return SP_OK;
   Context& c = ctx();
-  uint64_t *d_el, *d_out;
-  {
-    std::lock_guard<std::mutex> lk(c.mu);
-    SP_HIP(c.io.reserve((width * depth + width) * 32 + 64));
-    d_el = (uint64_t*)c.io.ptr;
-    d_out = d_el + 4 * width * depth;
-    SP_HIP(hipMemcpy(d_el, elems, width * depth * 32, hipMemcpyHostToDevice));
-  }
+  ctx_lock lk(c.mu);  // held across the nested _dev call: the staging buffer is shared
+  SP_HIP(c.io.reserve((width * depth + width) * 32 + 64));
+  uint64_t* d_el = (uint64_t*)c.io.ptr;
+  uint64_t* d_out = d_el + 4 * width * depth;
+  SP_HIP(hipMemcpy(d_el, elems, width * depth * 32, hipMemcpyHostToDevice));
   uint8_t st8 = 0;
   int rc = sp_pedersen_chains_dev(d_el, width, depth, d_out, &st8, 0);
   if (rc != SP_OK) return rc;
@@ -505,14 +502,11 @@ int sp_pedersen_chain(const uint64_t* elems, size_t n_elems, uint64_t* out, uint
   SP_REQUIRE_READY();
   if (n_elems < 1) { set_error("chain needs at least one element"); return SP_ERR_BAD_ARGUMENT; }
   Context& c = ctx();
-  uint64_t *d_el, *d_out;
-  {
-    std::lock_guard<std::mutex> lk(c.mu);
-    SP_HIP(c.io.reserve(n_elems * 32 + 64));
-    d_el = (uint64_t*)c.io.ptr;
-    d_out = (uint64_t*)((char*)c.io.ptr + n_elems * 32);
-    SP_HIP(hipMemcpy(d_el, elems, n_elems * 32, hipMemcpyHostToDevice));
-  }
+  ctx_lock lk(c.mu);
+  SP_HIP(c.io.reserve(n_elems * 32 + 64));
+  uint64_t* d_el = (uint64_t*)c.io.ptr;
+  uint64_t* d_out = (uint64_t*)((char*)c.io.ptr + n_elems * 32);
+  SP_HIP(hipMemcpy(d_el, elems, n_elems * 32, hipMemcpyHostToDevice));
   uint8_t st8 = 0;
   int rc = sp_pedersen_chains_dev(d_el, 1, n_elems, d_out, &st8, 0);
   if (rc != SP_OK) return rc;
@@ -529,7 +523,7 @@ int sp_pedersen_chain_right(const uint64_t* elems, size_t n_elems, uint64_t* out
   SP_REQUIRE_READY();
   if (n_elems < 1) { set_error("chain needs at least one element"); return SP_ERR_BAD_ARGUMENT; }
   Context& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
+  ctx_lock lk(c.mu);
   SP_HIP(c.io.reserve((n_elems + 2) * 32 + 64));
   uint64_t* d_el = (uint64_t*)c.io.ptr;
   uint64_t* d_a = d_el + 4 * n_elems;
@@ -568,7 +562,7 @@ int sp_merkle_forest_dev(uint64_t* levels, size_t n_trees, unsigned height, uint
   if (n_trees == 0) return SP_OK;
   if (height > 40 || (n_trees >> (40 - height)) != 0) { set_error("forest too large"); return SP_ERR_BAD_ARGUMENT; }
   Context& c = ctx();
-  std::lock_guard<std::mutex> lk(c.mu);
+  ctx_lock lk(c.mu);
   hipStream_t st = (hipStream_t)stream;
   const size_t n0 = n_trees << height;
   Scratch s;
@@ -598,13 +592,10 @@ int sp_merkle_root(const uint64_t* leaves, unsigned height, uint64_t* root, uint
   Context& c = ctx();
   const size_t n0 = (size_t)1 << height;
   const size_t total = 2 * n0 - 1;
-  uint64_t* d;
-  {
-    std::lock_guard<std::mutex> lk(c.mu);
-    SP_HIP(c.io.reserve(total * 32));
-    d = (uint64_t*)c.io.ptr;
-    SP_HIP(hipMemcpy(d, leaves, n0 * 32, hipMemcpyHostToDevice));
-  }
+  ctx_lock lk(c.mu);
+  SP_HIP(c.io.reserve(total * 32));
+  uint64_t* d = (uint64_t*)c.io.ptr;
+  SP_HIP(hipMemcpy(d, leaves, n0 * 32, hipMemcpyHostToDevice));
   uint8_t st8 = 0;
   int rc = sp_merkle_build_dev(d, height, &st8, 0);
   if (rc != SP_OK) return rc;

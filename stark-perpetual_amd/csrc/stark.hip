@@ -616,7 +616,7 @@ extern "C" {
 int sp_ntt_dev(const uint64_t* in, uint64_t* out, unsigned log_n, int inverse, void* stream) {
   SP_REQUIRE_READY();
   if (log_n > 26) { set_error("log_n too large"); return SP_ERR_BAD_ARGUMENT; }
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   hipStream_t st = (hipStream_t)stream;
   const size_t n = (size_t)1 << log_n;
   SP_HIP(g_tab.work.reserve(n * 32));
@@ -639,7 +639,7 @@ int sp_lde_dev(const uint64_t* in, uint64_t* out, unsigned ncols, unsigned log_n
                const uint64_t* shift_host, void* stream) {
   SP_REQUIRE_READY();
   if (log_n + log_blowup > 26) { set_error("LDE size too large"); return SP_ERR_BAD_ARGUMENT; }
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   hipStream_t st = (hipStream_t)stream;
   const size_t n = (size_t)1 << log_n, m = n << log_blowup;
   u256 sh;
@@ -676,7 +676,7 @@ int sp_lde_dev(const uint64_t* in, uint64_t* out, unsigned ncols, unsigned log_n
 int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes, uint64_t* cols,
                           void* stream) {
   SP_REQUIRE_READY();
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   hipStream_t st = (hipStream_t)stream;
   if (!g_tab.bits_ready) {
     // per-bit points = window value 2^b of the w-bit window tables minus the offsets is awkward;
@@ -728,7 +728,7 @@ int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes,
 int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
                     const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream) {
   SP_REQUIRE_READY();
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   const size_t n = (size_t)1 << log_n, M = 4 * n;
   AirParams prm;
   for (int k = 0; k < 11; ++k) {
@@ -759,7 +759,7 @@ int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, uns
 int sp_ec_ladder_trace_dev(const uint64_t* m, const uint64_t* qx, const uint64_t* qy, size_t n_ladders,
                            uint64_t* cols, void* stream) {
   SP_REQUIRE_READY();
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   aff_packed shift;
   shift.x = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_X))));
   shift.y = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_Y))));
@@ -774,7 +774,7 @@ int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodi
                               const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out,
                               void* stream) {
   SP_REQUIRE_READY();
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   const size_t n = (size_t)1 << log_n, M = 4 * n;
   EcAirParams prm;
   for (int k = 0; k < 12; ++k) {
@@ -804,7 +804,7 @@ int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uin
                     const uint64_t* shift_host, void* stream) {
   SP_REQUIRE_READY();
   if (log_m < 1 || log_m > 26) { set_error("bad layer size"); return SP_ERR_BAD_ARGUMENT; }
-  std::lock_guard<std::mutex> lk(ctx().mu);
+  ctx_lock lk(ctx().mu);
   hipStream_t st = (hipStream_t)stream;
   const uint64_t* tw;
   int rc = get_twiddles((int)log_m, 1, &tw, st);
