@@ -20,6 +20,8 @@
 //   pre-assert violations       -> SP_VERIFY_ASSERT_* codes (signature.py:219,225-227,241)
 // All other assertion sites of the reference ladders (partial sum meeting the doubled point) need
 // a discrete-log relation between the shift point and G or Q (DESIGN.md "failure set").
+#include <map>
+
 #include "context.hpp"
 #include "curve_consts.hpp"
 
@@ -282,9 +284,14 @@ ecdsa_sign_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ 
 
 using namespace sp;
 
-static sp::DeviceBuffer g_verify_tab;
+// Per-stream, like the Pedersen scratch: verifications in flight on different streams (or issued by
+// different host threads) never share a window table.
+static std::map<hipStream_t, sp::DeviceBuffer> g_verify_tab;
 namespace sp {
-void release_ecdsa_state() { g_verify_tab.release(); }
+void release_ecdsa_state() {
+  for (auto& kv : g_verify_tab) kv.second.release();
+  g_verify_tab.clear();
+}
 }
 static inline unsigned nblocks(size_t n, unsigned tpb) { return (unsigned)((n + tpb - 1) / tpb); }
 
@@ -296,10 +303,12 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
+  ctx_lock lk(c.mu);
   // per-signature table of the eight odd multiples of the key: 8 x 27 limbs, limb-major
-  SP_HIP(g_verify_tab.reserve(n * 8 * 27 * sizeof(int32_t)));
+  DeviceBuffer& tab = g_verify_tab[(hipStream_t)stream];
+  SP_HIP(tab.reserve(n * 8 * 27 * sizeof(int32_t)));
   hipLaunchKernelGGL(ecdsa_verify_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z, r,
-                     s, qx, qy, result, n, c.gen, c.wbits, c.nwin, (int32_t*)g_verify_tab.ptr);
+                     s, qx, qy, result, n, c.gen, c.wbits, c.nwin, (int32_t*)tab.ptr);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }

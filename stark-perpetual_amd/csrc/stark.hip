@@ -483,9 +483,12 @@ fri_fold_kernel(const uint64_t* __restrict__ f, uint64_t* __restrict__ g, int lo
 struct Tables {
   std::map<std::pair<int, int>, DeviceBuffer> twiddle;        // (log_n, inverse) -> N/2 powers
   std::map<std::pair<int, std::vector<uint32_t>>, DeviceBuffer> coset;  // (log_n, shift words) -> shift^c / n
-  DeviceBuffer work;   // ping-pong columns for LDE
+  // Work buffers are per stream (like the Pedersen scratch): calls in flight on different streams
+  // or from different host threads never share one.  The twiddle / coset / bits tables are
+  // immutable once built (their builders synchronise before publishing them).
+  std::map<hipStream_t, DeviceBuffer> work;           // coefficient column of the NTT / LDE
+  std::map<hipStream_t, DeviceBuffer> trace_scratch;  // partial sums / prefix products of the witness generators
   DeviceBuffer bits;   // 504 per-bit constant points for trace generation
-  DeviceBuffer trace_scratch;  // projective partial sums / prefix products of the witness generator
   bool bits_ready = false;
 };
 static Tables g_tab;
@@ -494,9 +497,11 @@ void release_stark_state() {
   for (auto& kv : g_tab.coset) kv.second.release();
   g_tab.twiddle.clear();
   g_tab.coset.clear();
-  g_tab.work.release();
+  for (auto& kv : g_tab.work) kv.second.release();
+  for (auto& kv : g_tab.trace_scratch) kv.second.release();
+  g_tab.work.clear();
+  g_tab.trace_scratch.clear();
   g_tab.bits.release();
-  g_tab.trace_scratch.release();
   g_tab.bits_ready = false;
 }
 
@@ -619,8 +624,9 @@ int sp_ntt_dev(const uint64_t* in, uint64_t* out, unsigned log_n, int inverse, v
   ctx_lock lk(ctx().mu);
   hipStream_t st = (hipStream_t)stream;
   const size_t n = (size_t)1 << log_n;
-  SP_HIP(g_tab.work.reserve(n * 32));
-  uint64_t* tmp = (uint64_t*)g_tab.work.ptr;
+  DeviceBuffer& work = g_tab.work[st];
+  SP_HIP(work.reserve(n * 32));
+  uint64_t* tmp = (uint64_t*)work.ptr;
   // natural -> natural: DIF into tmp (bit-reversed), then permute
   fe scale = FE_ONE_M;
   if (inverse) {
@@ -657,8 +663,9 @@ int sp_lde_dev(const uint64_t* in, uint64_t* out, unsigned ncols, unsigned log_n
     it = g_tab.coset.emplace(key, buf).first;
   }
   const uint64_t* G = (const uint64_t*)it->second.ptr;
-  SP_HIP(g_tab.work.reserve(n * 32));
-  uint64_t* coef = (uint64_t*)g_tab.work.ptr;
+  DeviceBuffer& work = g_tab.work[st];
+  SP_HIP(work.reserve(n * 32));
+  uint64_t* coef = (uint64_t*)work.ptr;
   for (unsigned c = 0; c < ncols; ++c) {
     const uint64_t* src = in + 4 * (size_t)c * n;
     uint64_t* dst = out + 4 * (size_t)c * m;
@@ -717,10 +724,10 @@ int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes,
   aff_packed shift;
   shift.x = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_X))));
   shift.y = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_Y))));
-  SP_HIP(g_tab.trace_scratch.reserve((size_t)5 * 512 * NL * n_hashes * sizeof(int32_t)));
+  DeviceBuffer& scratch = g_tab.trace_scratch[st];
+  SP_HIP(scratch.reserve((size_t)5 * 512 * NL * n_hashes * sizeof(int32_t)));
   hipLaunchKernelGGL(pedersen_trace_kernel, dim3((unsigned)((n_hashes + 63) / 64)), dim3(64), 0, st, x, y,
-                     n_hashes, (const aff_packed*)g_tab.bits.ptr, shift, cols,
-                     (int32_t*)g_tab.trace_scratch.ptr);
+                     n_hashes, (const aff_packed*)g_tab.bits.ptr, shift, cols, (int32_t*)scratch.ptr);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }
@@ -763,9 +770,10 @@ int sp_ec_ladder_trace_dev(const uint64_t* m, const uint64_t* qx, const uint64_t
   aff_packed shift;
   shift.x = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_X))));
   shift.y = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_Y))));
-  SP_HIP(g_tab.trace_scratch.reserve((size_t)8 * 256 * NL * n_ladders * sizeof(int32_t)));
+  DeviceBuffer& scratch = g_tab.trace_scratch[(hipStream_t)stream];
+  SP_HIP(scratch.reserve((size_t)8 * 256 * NL * n_ladders * sizeof(int32_t)));
   hipLaunchKernelGGL(ec_ladder_trace_kernel, dim3((unsigned)((n_ladders + 63) / 64)), dim3(64), 0,
-                     (hipStream_t)stream, m, qx, qy, n_ladders, shift, cols, (int32_t*)g_tab.trace_scratch.ptr);
+                     (hipStream_t)stream, m, qx, qy, n_ladders, shift, cols, (int32_t*)scratch.ptr);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }
