@@ -17,6 +17,14 @@
  *     text).  Data-dependent outcomes are reported per item in a uint8_t status array.
  *   - There is no CPU fallback: without a visible gfx950 device sp_init fails and every compute
  *     entry point returns SP_ERR_NOT_INITIALISED.
+ *   - Ownership: the library never keeps a caller pointer after a host-pointer call returns; a _dev
+ *     call's buffers must stay valid until the work enqueued on its stream has completed.
+ *   - Threading: every entry point may be called from any host thread.  One recursive lock
+ *     serialises the host-side bookkeeping (and, for host-pointer calls, the whole staged
+ *     round trip through the shared staging buffers); scratch, window tables of the verifier and
+ *     NTT work columns are per stream, so _dev calls on different streams overlap on the device.
+ *     Each entry point binds the device given to sp_init for its duration and restores the calling
+ *     thread's current HIP device on return.
  */
 #ifndef STARKPERP_H
 #define STARKPERP_H
