@@ -68,59 +68,38 @@ __device__ __noinline__ fe double_x(const fe& xa, const fe& ya) {
   return fe_carry(fe_sub(fe_sqr(lam), fe_dbl(xa)));
 }
 
-__global__ void __launch_bounds__(128)
-ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr,
-                    const uint64_t* __restrict__ ps, const uint64_t* __restrict__ pqx,
-                    const uint64_t* __restrict__ pqy, uint8_t* __restrict__ result, size_t n,
-                    const aff_packed* __restrict__ gen, int wbits, int nwin, int32_t* __restrict__ tab) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+// ---- the three stages of a verification, shared by the ladder kernel and the key-table kernel ----
+struct verify_scalars {
+  u256 r;       // the signature's r (plain)
+  u256 u1, u2;  // z w, r w mod N (plain)
+  bool z_zero;  // msg_hash == 0: reference returns False (signature.py:181 via :252) AFTER the key checks
+};
+constexpr uint8_t VERIFY_CONTINUE = 0xff;
+
+// Pre-asserts of signature.py:219-227 in the reference's order; on success fills u1, u2.
+__device__ __forceinline__ uint8_t verify_prepare(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr,
+                                                  const uint64_t* __restrict__ ps, size_t e,
+                                                  verify_scalars& v) {
   const u256 z = ld_u256(pz + 4 * e), r = ld_u256(pr + 4 * e), s = ld_u256(ps + 4 * e);
-  // signature.py:219
-  if (u256_is_zero(s) || !u256_lt(s, U256_N)) { result[e] = SP_VERIFY_ASSERT_S; return; }
-  const fe s_m = montn_of(s);
-  const fe w_m = fn_inv(s_m);
-  const fe w_c = fn_from_mont(w_m);  // canonical limbs
-  const u256 w = fe_pack(w_c);
-  // signature.py:225-227
-  if (u256_is_zero(r) || !u256_lt(r, U256_2P251)) { result[e] = SP_VERIFY_ASSERT_R; return; }
-  if (u256_is_zero(w) || !u256_lt(w, U256_2P251)) { result[e] = SP_VERIFY_ASSERT_W; return; }
-  if (!u256_lt(z, U256_2P251)) { result[e] = SP_VERIFY_ASSERT_MSG; return; }
+  if (u256_is_zero(s) || !u256_lt(s, U256_N)) return SP_VERIFY_ASSERT_S;  // :219
+  const fe w_m = fn_inv(montn_of(s));
+  const u256 w = fe_pack(fn_from_mont(w_m));
+  if (u256_is_zero(r) || !u256_lt(r, U256_2P251)) return SP_VERIFY_ASSERT_R;  // :225
+  if (u256_is_zero(w) || !u256_lt(w, U256_2P251)) return SP_VERIFY_ASSERT_W;  // :226
+  if (!u256_lt(z, U256_2P251)) return SP_VERIFY_ASSERT_MSG;                   // :227
+  v.r = r;
+  v.z_zero = u256_is_zero(z);
+  v.u1 = fe_pack(fn_from_mont(fn_mul(montn_of(z), w_m)));
+  v.u2 = fe_pack(fn_from_mont(fn_mul(montn_of(r), w_m)));
+  return VERIFY_CONTINUE;
+}
 
-  const bool has_y = pqy != nullptr;
-  const fe qx = mont_of(reduce_mod_p(ld_u256(pqx + 4 * e)));
-  const fe beta = mont_of(CURVE_BETA);
-  // c = x^3 + x + beta
-  const fe rhs = fe_carry(fe_add(fe_add(fe_mul(fe_sqr(qx), qx), qx), beta));
-  fe c, a_coef;
-  aff base;
-  fe qy = FE_ONE_M;
-  if (has_y) {
-    qy = mont_of(reduce_mod_p(ld_u256(pqy + 4 * e)));
-    if (!fe_eq(fe_sqr(qy), rhs)) { result[e] = SP_VERIFY_ASSERT_CURVE; return; }  // signature.py:241
-    c = FE_ONE_M;
-    a_coef = FE_ONE_M;
-    base.x = qx;
-    base.y = qy;
-  } else {
-    c = rhs;
-    if (fe_is_zero(c) || !fe_is_qr(c)) { result[e] = SP_VERIFY_FALSE; return; }  // signature.py:232-235
-    a_coef = fe_sqr(c);
-    base.x = fe_mul(c, qx);
-    base.y = a_coef;
-  }
-  if (u256_is_zero(z)) { result[e] = SP_VERIFY_FALSE; return; }  // signature.py:181 via :252
-
-  const u256 u1 = fe_pack(fn_from_mont(fn_mul(montn_of(z), w_m)));
-  const u256 u2 = fe_pack(fn_from_mont(fn_mul(montn_of(r), w_m)));
-
-  // B' = u2 * base on y^2 = x^3 + a_coef x + ...  Fixed signed window, w = 4, regular recoding:
-  // for odd k the digits d_i = 2 e_i - 15 (all odd, |d_i| <= 15) are read straight off the 4-bit
-  // windows e_i of E = (k - 1)/2 + 2^255, and the top digit is always +1 - every lane does the
-  // same 252 doublings + 63 additions (no divergent branch; the binary ladder paid a mixed
-  // addition on every bit because some lane always needed one).  Even k uses N - k and flips y.
-  // The eight odd multiples (2j+1)*base live in a per-signature table in HBM, limb-major.
-  const bool flip = (u2.w[0] & 1u) == 0;
+// Regular signed recoding shared by the window ladder and the comb: for odd k,
+//   k = sum_{j<256} (2 E_j - 1) 2^j   with   E = (k - 1)/2 + 2^255,
+// so every 4-bit window of E is an odd digit 2e - 15 and every comb column has no zero row.
+// Even scalars use N - k (odd) and the caller negates the result (`flip`).
+__device__ __forceinline__ u256 recode_odd(const u256& u2, bool& flip) {
+  flip = (u2.w[0] & 1u) == 0;
   u256 k = u2;
   if (flip) {
     uint64_t borrow = 0;
@@ -135,6 +114,19 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
 #pragma unroll
   for (int i = 0; i < 7; ++i) E.w[i] = (k.w[i] >> 1) | (k.w[i + 1] << 31);
   E.w[7] = (k.w[7] >> 1) | 0x80000000u;
+  return E;
+}
+
+// B' = u2 * base on y^2 = x^3 + a_coef x + ...  Fixed signed window, w = 4, regular recoding:
+// the digits d_i = 2 e_i - 15 (all odd, |d_i| <= 15) are read straight off the 4-bit windows e_i
+// of E, and the top digit is always +1 - every lane does the same 252 doublings + 63 additions
+// (no divergent branch; the binary ladder paid a mixed addition on every bit because some lane
+// always needed one).  The eight odd multiples (2j+1)*base live in a per-signature table in HBM,
+// limb-major (entry * 27 + limb) * n + e.
+__device__ __forceinline__ jac ladder_mul(const u256& u2, const aff& base, const fe& a_coef,
+                                          int32_t* __restrict__ tab, size_t n, size_t e) {
+  bool flip;
+  u256 E = recode_odd(u2, flip);
   auto tab_at = [&](int entry, int limb) -> int32_t* { return tab + ((size_t)(entry * 27 + limb) * n + e); };
   auto tab_store = [&](int entry, const jac& P) {
 #pragma unroll
@@ -182,12 +174,18 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
     B = jac_add(B, T);
   }
   if (flip) B.Y = fe_neg(B.Y);
-  const xyzz A = gen_mul(u1, gen, wbits, nwin);
+  return B;
+}
 
+// Acceptance test for A = u1 G (XYZZ, real curve) and B = u2 Q (Jacobian; on the real curve for a
+// point key, c = 1, or on the c-twisted model for an x-only key): r == x(A + B), resp.
+// r in { x(A + B), x(A - B) } as one polynomial identity.
+__device__ __forceinline__ uint8_t verify_finish(const xyzz& A, const jac& B, const fe& c, bool has_y,
+                                                 const u256& r) {
   // one inversion for 1/ZZZ_A, 1/Z_B, 1/c
   const fe zc = fe_mul(B.Z, c);
   const fe D = fe_mul(A.ZZZ, zc);
-  if (fe_is_zero(D)) { result[e] = SP_VERIFY_FALSE; return; }  // degenerate (unreachable) guard
+  if (fe_is_zero(D)) return SP_VERIFY_FALSE;  // degenerate (unreachable) guard
   const fe I = fe_inv(D);
   const fe izzz = fe_mul(I, zc);
   const fe Iz3 = fe_mul(I, A.ZZZ);
@@ -218,7 +216,53 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
       ok = fe_eq(fe_sqr(E), rhs2);
     }
   }
-  result[e] = ok ? SP_VERIFY_TRUE : SP_VERIFY_FALSE;
+  return ok ? SP_VERIFY_TRUE : SP_VERIFY_FALSE;
+}
+
+// Public-key stage: the curve model the multiples of Q live on.  Point key: the curve itself
+// (c = a = 1), off-curve -> SP_VERIFY_ASSERT_CURVE (signature.py:241).  X-only key: with
+// c = x^3 + x + beta the multiples of (x, sqrt c) are rational points of
+// y'^2 = x'^3 + c^2 x' + beta c^3 (x' = c x, y' = c^2 b); base = (c x, c^2);
+// c a non-residue -> SP_VERIFY_FALSE (InvalidPublicKeyError, signature.py:232-235).
+__device__ __forceinline__ uint8_t key_model(const uint64_t* __restrict__ pqx, const uint64_t* __restrict__ pqy,
+                                             size_t e, aff& base, fe& c, fe& a_coef) {
+  const fe qx = mont_of(reduce_mod_p(ld_u256(pqx + 4 * e)));
+  const fe rhs = fe_carry(fe_add(fe_add(fe_mul(fe_sqr(qx), qx), qx), mont_of(CURVE_BETA)));
+  if (pqy != nullptr) {
+    const fe qy = mont_of(reduce_mod_p(ld_u256(pqy + 4 * e)));
+    if (!fe_eq(fe_sqr(qy), rhs)) return SP_VERIFY_ASSERT_CURVE;
+    c = FE_ONE_M;
+    a_coef = FE_ONE_M;
+    base.x = qx;
+    base.y = qy;
+  } else {
+    c = rhs;
+    if (fe_is_zero(c) || !fe_is_qr(c)) return SP_VERIFY_FALSE;
+    a_coef = fe_sqr(c);
+    base.x = fe_mul(c, qx);
+    base.y = a_coef;
+  }
+  return VERIFY_CONTINUE;
+}
+
+__global__ void __launch_bounds__(128)
+ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr,
+                    const uint64_t* __restrict__ ps, const uint64_t* __restrict__ pqx,
+                    const uint64_t* __restrict__ pqy, uint8_t* __restrict__ result, size_t n,
+                    const aff_packed* __restrict__ gen, int wbits, int nwin, int32_t* __restrict__ tab) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  verify_scalars v;
+  uint8_t code = verify_prepare(pz, pr, ps, e, v);
+  if (code != VERIFY_CONTINUE) { result[e] = code; return; }
+  aff base;
+  fe c, a_coef;
+  code = key_model(pqx, pqy, e, base, c, a_coef);
+  if (code != VERIFY_CONTINUE) { result[e] = code; return; }
+  if (v.z_zero) { result[e] = SP_VERIFY_FALSE; return; }
+  const jac B = ladder_mul(v.u2, base, a_coef, tab, n, e);
+  const xyzz A = gen_mul(v.u1, gen, wbits, nwin);
+  result[e] = verify_finish(A, B, c, pqy != nullptr, v.r);
 }
 
 // (qx, qy) = d * G
