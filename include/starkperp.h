@@ -41,6 +41,7 @@ extern "C" {
 #define SP_ERR_HIP (-2)
 #define SP_ERR_BAD_ARGUMENT (-3)
 #define SP_ERR_TABLE_BUILD (-4)
+#define SP_ERR_CACHE_FULL (-5) /* sp_ecdsa_register_keys: no free key-table slot */
 
 /* per-item status of sp_pedersen_* (signature.py:300-318) */
 #define SP_HASH_OK 0
@@ -128,6 +129,26 @@ int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* 
 int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                               const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n,
                               void* stream);
+/* Key tables - the same verify() for public keys that are seen again (an exchange's accounts):
+ * a registered key owns a 128-entry signed comb table (8 KiB) in HBM that replaces the 252 doublings
+ * + 63 additions of the per-signature ladder by 31 doublings + 32 mixed additions.  Results are
+ * identical to sp_ecdsa_verify_batch for every input (same pre-asserts, same False cases).
+ *   sp_ecdsa_register_keys  host pointers; qy == NULL registers x-only keys; equal keys share a
+ *                           slot; slots[i] receives the slot of key i; invalid keys get a slot too
+ *                           (their verifications return False / SP_VERIFY_ASSERT_CURVE as before);
+ *                           SP_ERR_CACHE_FULL when no slot is free (capacity: 2^17 keys = 1 GiB, or
+ *                           STARKPERP_KEY_CACHE_SLOTS), in which case nothing is registered.
+ *   sp_ecdsa_verify_keyed_dev  device pointers; slots[i] names the key of signature i.
+ *   sp_ecdsa_verify_batch_keyed  host pointers: registers what is new, then verifies.
+ * sp_ecdsa_verify_batch itself switches to the tables when at most 40 % of a batch's signatures bring
+ * a key that is not registered yet (STARKPERP_VERIFY_KEYED=0 / 1 forces the ladder / the tables). */
+int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uint32_t* slots);
+int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64_t* s,
+                              const uint32_t* slots, uint8_t* result, size_t n, void* stream);
+int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint64_t* s,
+                                const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n);
+int sp_ecdsa_key_cache_info(size_t* capacity, size_t* used);
+int sp_ecdsa_key_cache_reset(void);
 /* One signing attempt per item with caller-supplied nonce k (host RFC 6979, signature.py:117-134):
  * the body of the loop at signature.py:146-173. */
 int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r,

@@ -20,7 +20,12 @@
 //   pre-assert violations       -> SP_VERIFY_ASSERT_* codes (signature.py:219,225-227,241)
 // All other assertion sites of the reference ladders (partial sum meeting the doubled point) need
 // a discrete-log relation between the shift point and G or Q (DESIGN.md "failure set").
+#include <array>
+#include <cstdlib>
+#include <cstring>
 #include <map>
+#include <unordered_map>
+#include <vector>
 
 #include "context.hpp"
 #include "curve_consts.hpp"
@@ -265,6 +270,233 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
   result[e] = verify_finish(A, B, c, pqy != nullptr, v.r);
 }
 
+// =================================================================================================
+// Key tables: verification against a public key that has been seen before.
+//
+// The ladder above spends 252 doublings + 63 additions per signature on u2 * Q because Q is new to
+// it every time.  Exchange traffic is not like that: the same accounts sign again and again
+// (BASELINE.json configs[2]: 4096 orders from 1024 keys).  With 288 GB of HBM a signed comb table per
+// key is cheap - 128 affine points, 8 KiB - and turns u2 * Q into 31 doublings + 32 mixed additions:
+//   rows     Q_i = 2^(32 i) Q, i = 0..7          (the 256 signed bits of the recoding, 8 rows x 32 columns)
+//   entries  T[v] = Q_7 + sum_{i<7} (2 v_i - 1) Q_i,  v = 0..127   (row 7 carries the column's sign)
+//   column c of E = (k-1)/2 + 2^255: bit c of word i is row i; sign = row 7, index = rows 0..6
+//   (complemented when the sign is negative);  acc = 2 acc +- T[index], from column 31 down to 0.
+// Tables live on the same curve model as the ladder's base point (the curve itself for a point key,
+// the c-twisted model for an x-only key), so verify_finish is shared.  Unlike the window ladder, a
+// chosen u2 CAN make a comb addition meet its own operand (k = N - 2|t| for a table multiple t), so
+// the column addition detects Z3 == 0 and takes the doubling / infinity branch explicitly.
+constexpr int COMB_ENTRIES = 128;
+constexpr int COMB_ROW_POINTS = 15;  // Q_0, 2Q_0, Q_1, 2Q_1, ..., Q_6, 2Q_6, Q_7
+constexpr uint8_t KEY_EMPTY = 0, KEY_XONLY = 1, KEY_POINT = 2, KEY_INVALID_X = 3, KEY_OFF_CURVE = 4;
+
+__device__ __forceinline__ void st_aff(aff_packed* dst, const fe& x_m, const fe& y_m) {
+  uint4* q = reinterpret_cast<uint4*>(dst);
+  const u256 x = fe_pack(fe_canon(x_m)), y = fe_pack(fe_canon(y_m));
+  q[0] = make_uint4(x.w[0], x.w[1], x.w[2], x.w[3]);
+  q[1] = make_uint4(x.w[4], x.w[5], x.w[6], x.w[7]);
+  q[2] = make_uint4(y.w[0], y.w[1], y.w[2], y.w[3]);
+  q[3] = make_uint4(y.w[4], y.w[5], y.w[6], y.w[7]);
+}
+
+// Stage 1, one thread per NEW key: validity, curve model, the 15 row points (224 doublings, one
+// shared inversion).  `work` holds 15 x (X, Y, Z, prefix) limb planes per key, key-minor.
+__global__ void __launch_bounds__(64)
+key_rows_kernel(const uint64_t* __restrict__ pqx, const uint64_t* __restrict__ pqy,
+                const uint8_t* __restrict__ has_y, const uint32_t* __restrict__ slot_of, size_t n_new,
+                uint64_t* __restrict__ key_c, uint8_t* __restrict__ key_flag,
+                aff_packed* __restrict__ rows, int32_t* __restrict__ work) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_new) return;
+  const uint32_t slot = slot_of[e];
+  aff base;
+  fe c, a_coef;
+  const bool point_key = has_y[e] != 0;
+  const uint8_t code = key_model(pqx, point_key ? pqy : nullptr, e, base, c, a_coef);
+  if (code != VERIFY_CONTINUE) {
+    key_flag[slot] = point_key ? KEY_OFF_CURVE : KEY_INVALID_X;
+    return;
+  }
+  st_u256(key_c + 4 * (size_t)slot, fe_pack(fe_canon(c)));
+  auto plane = [&](int point, int limb) -> int32_t* { return work + ((size_t)(point * 36 + limb) * n_new + e); };
+  jac P;
+  P.X = base.x; P.Y = base.y; P.Z = FE_ONE_M;
+  fe run = FE_ONE_M;
+  auto emit = [&](int point) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      *plane(point, l) = P.X.l[l];
+      *plane(point, 9 + l) = P.Y.l[l];
+      *plane(point, 18 + l) = P.Z.l[l];
+      *plane(point, 27 + l) = run.l[l];
+    }
+    run = fe_mul(run, P.Z);
+  };
+  for (int i = 0; i < 8; ++i) {
+    emit(2 * i);
+    if (i == 7) break;
+    P = jac_dbl(P, a_coef);
+    emit(2 * i + 1);
+    for (int j = 1; j < 32; ++j) P = jac_dbl(P, a_coef);
+  }
+  fe inv = fe_inv(run);
+  for (int point = COMB_ROW_POINTS - 1; point >= 0; --point) {
+    fe X, Y, Z, pre;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      X.l[l] = *plane(point, l);
+      Y.l[l] = *plane(point, 9 + l);
+      Z.l[l] = *plane(point, 18 + l);
+      pre.l[l] = *plane(point, 27 + l);
+    }
+    const fe zinv = fe_mul(inv, pre);
+    inv = fe_mul(inv, Z);
+    const fe zi2 = fe_sqr(zinv);
+    st_aff(rows + e * COMB_ROW_POINTS + point, fe_mul(X, zi2), fe_mul(Y, fe_mul(zi2, zinv)));
+  }
+  key_flag[slot] = point_key ? KEY_POINT : KEY_XONLY;
+}
+
+// Stage 2, four threads per new key: thread t owns the 32 entries whose rows 5, 6 have the signs
+// given by t, walks rows 0..4 in Gray-code order (one mixed addition of +-2 Q_i per entry), then
+// converts its 32 projective entries to affine with one shared inversion.
+__global__ void __launch_bounds__(64)
+key_table_kernel(const aff_packed* __restrict__ rows, const uint32_t* __restrict__ slot_of, size_t n_new,
+                 const uint8_t* __restrict__ key_flag, aff_packed* __restrict__ key_tab,
+                 int32_t* __restrict__ work) {
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e = gt >> 2;
+  const int t = (int)(gt & 3);
+  if (e >= n_new) return;
+  const uint32_t slot = slot_of[e];
+  const uint8_t flag = key_flag[slot];
+  if (flag != KEY_XONLY && flag != KEY_POINT) return;
+  const size_t lanes = 4 * n_new;
+  auto plane = [&](int entry, int limb) -> int32_t* { return work + ((size_t)(entry * 45 + limb) * lanes + gt); };
+  auto row_point = [&](int point, bool negative) {
+    aff q = ld_aff(rows + e * COMB_ROW_POINTS + point);
+    if (negative) q.y = fe_neg(q.y);
+    return q;
+  };
+  // entry (t << 5) | 0: Q_7 +- Q_6 +- Q_5 - Q_4 - Q_3 - Q_2 - Q_1 - Q_0
+  xyzz acc = xyzz_mmadd(row_point(14, false), row_point(12, (t & 2) == 0));
+  acc = xyzz_madd(acc, row_point(10, (t & 1) == 0));
+  for (int i = 4; i >= 0; --i) acc = xyzz_madd(acc, row_point(2 * i, true));
+  fe run = FE_ONE_M;
+  uint32_t gray = 0;
+  for (int g = 0; g < 32; ++g) {
+    if (g > 0) {
+      const int bit = __ffs(g) - 1;  // the row whose sign flips between Gray codes g-1 and g
+      gray ^= 1u << bit;
+      acc = xyzz_madd(acc, row_point(2 * bit + 1, ((gray >> bit) & 1u) == 0));  // 0 -> 1 adds +2 Q_i
+    }
+    const int entry = (int)gray;  // position inside this thread's block of 32
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      *plane(entry, l) = acc.X.l[l];
+      *plane(entry, 9 + l) = acc.Y.l[l];
+      *plane(entry, 18 + l) = acc.ZZ.l[l];
+      *plane(entry, 27 + l) = acc.ZZZ.l[l];
+      *plane(g, 36 + l) = run.l[l];  // prefix products are indexed by visiting order
+    }
+    run = fe_mul(run, acc.ZZZ);
+  }
+  fe inv = fe_inv(run);
+  gray = 0;
+  for (int g = 1; g < 32; ++g) gray ^= 1u << (__ffs(g) - 1);  // Gray code of 31
+  for (int g = 31; g >= 0; --g) {
+    const int entry = (int)gray;
+    fe X, Y, ZZ, ZZZ, pre;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      X.l[l] = *plane(entry, l);
+      Y.l[l] = *plane(entry, 9 + l);
+      ZZ.l[l] = *plane(entry, 18 + l);
+      ZZZ.l[l] = *plane(entry, 27 + l);
+      pre.l[l] = *plane(g, 36 + l);
+    }
+    const fe izzz = fe_mul(inv, pre);
+    inv = fe_mul(inv, ZZZ);
+    st_aff(key_tab + (size_t)slot * COMB_ENTRIES + ((t << 5) | entry),
+           fe_mul(X, fe_sqr(fe_mul(ZZ, izzz))), fe_mul(Y, izzz));
+    if (g > 0) gray ^= 1u << (__ffs(g) - 1);
+  }
+}
+
+// acc + q with the exceptional cases resolved (acc == infinity, acc == q, acc == -q).
+__device__ __forceinline__ jac jac_madd_complete(const jac& p, const aff& q, const fe& a_coef) {
+  jac r = jac_madd(p, q);
+  if (fe_is_zero(r.Z)) {  // Z3 = 2 Z1 H: p is infinity or the x-coordinates agree
+    jac qj;
+    qj.X = q.x; qj.Y = q.y; qj.Z = FE_ONE_M;
+    if (fe_is_zero(p.Z)) {
+      r = qj;
+    } else {
+      const fe z2 = fe_sqr(p.Z);
+      if (fe_eq(fe_mul(fe_mul(q.y, p.Z), z2), p.Y)) {
+        r = jac_dbl(qj, a_coef);
+      } else {
+        r.X = FE_ONE_M; r.Y = FE_ONE_M; r.Z = FE_ZERO;
+      }
+    }
+  }
+  return r;
+}
+
+__device__ __forceinline__ jac comb_mul(const u256& u2, const aff_packed* __restrict__ tab, const fe& a_coef) {
+  bool flip;
+  const u256 E = recode_odd(u2, flip);
+  auto column = [&](int col, bool& negative) -> const aff_packed* {
+    uint32_t idx = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) idx |= ((E.w[i] >> col) & 1u) << i;
+    negative = ((E.w[7] >> col) & 1u) == 0;
+    if (negative) idx ^= 127u;
+    return tab + idx;
+  };
+  bool neg;
+  aff q = ld_aff(column(31, neg));  // bit 255 of E is always set: the top column is +T
+  jac B;
+  B.X = q.x; B.Y = q.y; B.Z = FE_ONE_M;
+  aff nxt = ld_aff(column(30, neg));
+  for (int col = 30; col >= 0; --col) {
+    q = nxt;
+    if (neg) q.y = fe_neg(q.y);
+    if (col > 0) nxt = ld_aff(column(col - 1, neg));
+    B = jac_dbl(B, a_coef);
+    B = jac_madd_complete(B, q, a_coef);
+  }
+  if (flip) B.Y = fe_neg(B.Y);
+  return B;
+}
+
+__global__ void __launch_bounds__(128)
+ecdsa_verify_keyed_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr,
+                          const uint64_t* __restrict__ ps, const uint32_t* __restrict__ slots,
+                          uint8_t* __restrict__ result, size_t n, const aff_packed* __restrict__ gen,
+                          int wbits, int nwin, const aff_packed* __restrict__ key_tab,
+                          const uint64_t* __restrict__ key_c, const uint8_t* __restrict__ key_flag,
+                          uint32_t n_slots) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  verify_scalars v;
+  const uint8_t code = verify_prepare(pz, pr, ps, e, v);
+  if (code != VERIFY_CONTINUE) { result[e] = code; return; }
+  const uint32_t slot = slots[e];
+  const uint8_t flag = slot < n_slots ? key_flag[slot] : KEY_EMPTY;
+  if (flag == KEY_OFF_CURVE) { result[e] = SP_VERIFY_ASSERT_CURVE; return; }  // signature.py:241
+  if (flag != KEY_XONLY && flag != KEY_POINT) { result[e] = SP_VERIFY_FALSE; return; }  // :232-235
+  if (v.z_zero) { result[e] = SP_VERIFY_FALSE; return; }
+  const bool has_y = flag == KEY_POINT;
+  fe c = FE_ONE_M, a_coef = FE_ONE_M;
+  if (!has_y) {
+    c = fe_unpack(ld_u256(key_c + 4 * (size_t)slot));
+    a_coef = fe_sqr(c);
+  }
+  const jac B = comb_mul(v.u2, key_tab + (size_t)slot * COMB_ENTRIES, a_coef);
+  const xyzz A = gen_mul(v.u1, gen, wbits, nwin);
+  result[e] = verify_finish(A, B, c, has_y, v.r);
+}
+
 // (qx, qy) = d * G
 __global__ void __launch_bounds__(128)
 public_key_kernel(const uint64_t* __restrict__ pd, uint64_t* __restrict__ ox, uint64_t* __restrict__ oy,
@@ -331,10 +563,43 @@ using namespace sp;
 // Per-stream, like the Pedersen scratch: verifications in flight on different streams (or issued by
 // different host threads) never share a window table.
 static std::map<hipStream_t, sp::DeviceBuffer> g_verify_tab;
+// Key-table cache (see "Key tables" above): slot -> 128-entry comb table, curve-model constant c and
+// a flag, all in HBM; the host keeps the (qx, qy | x-only) -> slot map.
+struct KeyId {
+  std::array<uint64_t, 8> w;
+  bool operator==(const KeyId& o) const { return w == o.w; }
+};
+struct KeyIdHash {
+  size_t operator()(const KeyId& k) const {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+    for (uint64_t v : k.w) h = (h ^ v) * 0xff51afd7ed558ccdull + (h >> 29);
+    return (size_t)h;
+  }
+};
+struct KeyCache {
+  sp::DeviceBuffer tab, c, flag, stage;
+  size_t capacity = 0, used = 0;
+  std::unordered_map<KeyId, uint32_t, KeyIdHash> slot_of;
+};
+static KeyCache g_keys;
+static KeyId key_id(const uint64_t* qx, const uint64_t* qy) {
+  KeyId k;
+  for (int i = 0; i < 4; ++i) {
+    k.w[i] = qx[i];
+    k.w[4 + i] = qy ? qy[i] : ~(uint64_t)0;  // no curve point has y = 2^256 - 1: marks an x-only key
+  }
+  return k;
+}
 namespace sp {
 void release_ecdsa_state() {
   for (auto& kv : g_verify_tab) kv.second.release();
   g_verify_tab.clear();
+  g_keys.tab.release();
+  g_keys.c.release();
+  g_keys.flag.release();
+  g_keys.stage.release();
+  g_keys.capacity = g_keys.used = 0;
+  g_keys.slot_of.clear();
 }
 }
 static inline unsigned nblocks(size_t n, unsigned tpb) { return (unsigned)((n + tpb - 1) / tpb); }
@@ -377,11 +642,178 @@ static int stage_in(const uint64_t* const* host, int count, size_t n, uint64_t**
   return SP_OK;
 }
 
+static int key_cache_ready() {
+  if (g_keys.capacity) return SP_OK;
+  size_t cap = (size_t)1 << 17;  // 128 Ki keys = 1 GiB of tables
+  if (const char* env = getenv("STARKPERP_KEY_CACHE_SLOTS")) {
+    const long long v = atoll(env);
+    if (v > 0) cap = (size_t)v;
+  }
+  SP_HIP(g_keys.tab.reserve(cap * COMB_ENTRIES * sizeof(aff_packed)));
+  SP_HIP(g_keys.c.reserve(cap * 32));
+  SP_HIP(g_keys.flag.reserve(cap));
+  SP_HIP(hipMemset(g_keys.flag.ptr, 0, cap));
+  g_keys.capacity = cap;
+  g_keys.used = 0;
+  return SP_OK;
+}
+
+// Builds the tables of keys [first, first + count) of the `fresh` list (host arrays), synchronously.
+static int build_key_tables(const std::vector<uint64_t>& qx, const std::vector<uint64_t>& qy,
+                            const std::vector<uint8_t>& has_y, const std::vector<uint32_t>& slots) {
+  const size_t m = slots.size();
+  if (m == 0) return SP_OK;
+  const size_t chunk_max = (size_t)1 << 15;  // bounds the scratch: 92 KiB of work planes per key
+  for (size_t first = 0; first < m; first += chunk_max) {
+    const size_t cnt = m - first < chunk_max ? m - first : chunk_max;
+    const size_t fb = cnt * 32;
+    const size_t rows_b = cnt * COMB_ROW_POINTS * sizeof(aff_packed);
+    const size_t work1 = cnt * COMB_ROW_POINTS * 36 * sizeof(int32_t);
+    const size_t work2 = cnt * 4 * 32 * 45 * sizeof(int32_t);
+    const size_t work_b = work1 > work2 ? work1 : work2;
+    SP_HIP(g_keys.stage.reserve(2 * fb + cnt + cnt * 4 + rows_b + work_b + 1024));
+    char* b = (char*)g_keys.stage.ptr;
+    aff_packed* d_rows = (aff_packed*)b;                       // 64-byte aligned first
+    int32_t* d_work = (int32_t*)(b + rows_b);
+    uint64_t* d_qx = (uint64_t*)(b + rows_b + work_b);
+    uint64_t* d_qy = (uint64_t*)(b + rows_b + work_b + fb);
+    uint32_t* d_slot = (uint32_t*)(b + rows_b + work_b + 2 * fb);
+    uint8_t* d_hasy = (uint8_t*)(b + rows_b + work_b + 2 * fb + cnt * 4);
+    SP_HIP(hipMemcpy(d_qx, qx.data() + 4 * first, fb, hipMemcpyHostToDevice));
+    SP_HIP(hipMemcpy(d_qy, qy.data() + 4 * first, fb, hipMemcpyHostToDevice));
+    SP_HIP(hipMemcpy(d_slot, slots.data() + first, cnt * 4, hipMemcpyHostToDevice));
+    SP_HIP(hipMemcpy(d_hasy, has_y.data() + first, cnt, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(key_rows_kernel, dim3(nblocks(cnt, 64)), dim3(64), 0, 0, d_qx, d_qy, d_hasy, d_slot,
+                       cnt, (uint64_t*)g_keys.c.ptr, (uint8_t*)g_keys.flag.ptr, d_rows, d_work);
+    hipLaunchKernelGGL(key_table_kernel, dim3(nblocks(4 * cnt, 64)), dim3(64), 0, 0, d_rows, d_slot, cnt,
+                       (const uint8_t*)g_keys.flag.ptr, (aff_packed*)g_keys.tab.ptr, d_work);
+    SP_HIP(hipGetLastError());
+    SP_HIP(hipDeviceSynchronize());
+  }
+  return SP_OK;
+}
+
+int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uint32_t* slots) {
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  ctx_lock lk(ctx().mu);
+  int rc = key_cache_ready();
+  if (rc != SP_OK) return rc;
+  std::vector<uint64_t> fx, fy;
+  std::vector<uint8_t> fh;
+  std::vector<uint32_t> fs;
+  std::vector<KeyId> added;
+  for (size_t i = 0; i < n; ++i) {
+    const KeyId id = key_id(qx + 4 * i, qy ? qy + 4 * i : nullptr);
+    auto it = g_keys.slot_of.find(id);
+    if (it == g_keys.slot_of.end()) {
+      if (g_keys.used == g_keys.capacity) {
+        for (const KeyId& k : added) g_keys.slot_of.erase(k);  // roll this call back
+        g_keys.used -= added.size();
+        set_error("key-table cache is full (" + std::to_string(g_keys.capacity) +
+                  " slots; STARKPERP_KEY_CACHE_SLOTS, sp_ecdsa_key_cache_reset)");
+        return SP_ERR_CACHE_FULL;
+      }
+      const uint32_t slot = (uint32_t)g_keys.used++;
+      it = g_keys.slot_of.emplace(id, slot).first;
+      added.push_back(id);
+      fx.insert(fx.end(), qx + 4 * i, qx + 4 * i + 4);
+      if (qy) fy.insert(fy.end(), qy + 4 * i, qy + 4 * i + 4);
+      else fy.insert(fy.end(), 4, 0);
+      fh.push_back(qy ? 1 : 0);
+      fs.push_back(slot);
+    }
+    slots[i] = it->second;
+  }
+  rc = build_key_tables(fx, fy, fh, fs);
+  if (rc != SP_OK) {  // leave no slot behind whose table was never built
+    for (const KeyId& k : added) g_keys.slot_of.erase(k);
+    g_keys.used -= added.size();
+  }
+  return rc;
+}
+
+int sp_ecdsa_key_cache_info(size_t* capacity, size_t* used) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  if (capacity) *capacity = g_keys.capacity;
+  if (used) *used = g_keys.used;
+  return SP_OK;
+}
+
+int sp_ecdsa_key_cache_reset(void) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  SP_HIP(hipDeviceSynchronize());
+  g_keys.slot_of.clear();
+  g_keys.used = 0;
+  if (g_keys.capacity) SP_HIP(hipMemset(g_keys.flag.ptr, 0, g_keys.capacity));
+  return SP_OK;
+}
+
+int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64_t* s,
+                              const uint32_t* slots, uint8_t* result, size_t n, void* stream) {
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  Context& c = ctx();
+  ctx_lock lk(c.mu);
+  if (g_keys.capacity == 0) { set_error("no key has been registered"); return SP_ERR_BAD_ARGUMENT; }
+  hipLaunchKernelGGL(ecdsa_verify_keyed_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z,
+                     r, s, slots, result, n, c.gen, c.wbits, c.nwin, (const aff_packed*)g_keys.tab.ptr,
+                     (const uint64_t*)g_keys.c.ptr, (const uint8_t*)g_keys.flag.ptr, (uint32_t)g_keys.used);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+// Policy of the host-pointer entry point.  A new key costs about 1.25 ladder verifications to
+// tabulate and a tabulated verification about 0.25, so the tables pay off when fewer than ~60 % of the
+// batch's signatures bring a key that is not cached yet; the threshold used is 40 %.
+// STARKPERP_VERIFY_KEYED=0 / 1 forces the ladder / the tables.
+static bool use_key_tables(const uint64_t* qx, const uint64_t* qy, size_t n) {
+  static const char* mode = getenv("STARKPERP_VERIFY_KEYED");
+  if (mode && mode[0] == '0') return false;
+  if (key_cache_ready() != SP_OK) return false;
+  std::unordered_map<KeyId, int, KeyIdHash> fresh;
+  for (size_t i = 0; i < n; ++i) {
+    const KeyId id = key_id(qx + 4 * i, qy ? qy + 4 * i : nullptr);
+    if (g_keys.slot_of.find(id) == g_keys.slot_of.end()) fresh.emplace(id, 0);
+  }
+  if (g_keys.used + fresh.size() > g_keys.capacity) return false;
+  if (mode && mode[0] == '1') return true;
+  return fresh.size() * 5 <= n * 2;
+}
+
+// Host-pointer verification through the key tables: registers the keys it has not seen, then runs
+// the comb kernel.
+int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint64_t* s,
+                                const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  ctx_lock lk(ctx().mu);
+  std::vector<uint32_t> slots(n);
+  int rc = sp_ecdsa_register_keys(qx, qy, n, slots.data());
+  if (rc != SP_OK) return rc;
+  const uint64_t* host[3] = {z, r, s};
+  uint64_t* dev[3];
+  char* extra;
+  rc = stage_in(host, 3, n, dev, n * 4 + n, &extra);
+  if (rc != SP_OK) return rc;
+  uint32_t* d_slots = (uint32_t*)extra;
+  uint8_t* d_res = (uint8_t*)(extra + n * 4);
+  SP_HIP(hipMemcpy(d_slots, slots.data(), n * 4, hipMemcpyHostToDevice));
+  rc = sp_ecdsa_verify_keyed_dev(dev[0], dev[1], dev[2], d_slots, d_res, n, 0);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipDeviceSynchronize());
+  SP_HIP(hipMemcpy(result, d_res, n, hipMemcpyDeviceToHost));
+  return SP_OK;
+}
+
 int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                           const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   ctx_lock lk(ctx().mu);
+  if (use_key_tables(qx, qy, n)) return sp_ecdsa_verify_batch_keyed(z, r, s, qx, qy, result, n);
   const uint64_t* host[5] = {z, r, s, qx, qy};
   uint64_t* dev[5];
   char* extra;

@@ -60,6 +60,11 @@ _SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p]),
     "sp_ecdsa_verify_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
     "sp_ecdsa_verify_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "sp_ecdsa_register_keys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "sp_ecdsa_verify_keyed_dev": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "sp_ecdsa_verify_batch_keyed": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
+    "sp_ecdsa_key_cache_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_ecdsa_key_cache_reset": (ctypes.c_int, []),
     "sp_ecdsa_sign_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
     "sp_public_key_batch": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t]),
 }

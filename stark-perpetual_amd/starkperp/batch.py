@@ -197,13 +197,9 @@ SIGN_OK, SIGN_RETRY, SIGN_BAD_INPUT = 0, 1, 2
 _TWO251 = 2**251
 
 
-def verify_codes(msg_hashes, rs, ss, public_keys):
-    """Raw per-item result codes of sp_ecdsa_verify_batch (include/starkperp.h SP_VERIFY_*).
-    public_keys: all ints (x-only, signature.py:229-238) or all (x, y) pairs."""
+def _verify_inputs(msg_hashes, rs, ss, public_keys):
     n = len(msg_hashes)
     assert len(rs) == len(ss) == len(public_keys) == n
-    if n == 0:
-        return []
     xonly = isinstance(public_keys[0], int)
     assert all(isinstance(q, int) == xonly for q in public_keys), "mix of x-only and point keys"
     if xonly:
@@ -217,11 +213,66 @@ def verify_codes(msg_hashes, rs, ss, public_keys):
     z = [clamp(int(v), 2**256 - 1) for v in msg_hashes]
     r = [clamp(int(v), 0) for v in rs]
     s = [clamp(int(v), 0) for v in ss]
+    return pack_felts(z), pack_felts(r), pack_felts(s), pack_felts(qx), qy
+
+
+def verify_codes(msg_hashes, rs, ss, public_keys, key_tables=None):
+    """Raw per-item result codes of sp_ecdsa_verify_batch (include/starkperp.h SP_VERIFY_*).
+    public_keys: all ints (x-only, signature.py:229-238) or all (x, y) pairs.
+    key_tables: None = the library's policy (per-key comb tables when most keys of the batch are
+    already registered), True = always through the tables, False = always the per-signature
+    ladder.  The result is the same either way."""
+    n = len(msg_hashes)
+    if n == 0:
+        return []
+    z, r, s, qx, qy = _verify_inputs(msg_hashes, rs, ss, public_keys)
     lib = _lib.ensure_init()
     res = new_bytes(n)
-    _lib.check(lib.sp_ecdsa_verify_batch(pack_felts(z), pack_felts(r), pack_felts(s), pack_felts(qx),
-                                         qy, res, n), "sp_ecdsa_verify_batch")
+    if key_tables is None:
+        _lib.check(lib.sp_ecdsa_verify_batch(z, r, s, qx, qy, res, n), "sp_ecdsa_verify_batch")
+    elif key_tables:
+        _lib.check(lib.sp_ecdsa_verify_batch_keyed(z, r, s, qx, qy, res, n), "sp_ecdsa_verify_batch_keyed")
+    else:  # stage by hand so that the policy of the host entry point is bypassed
+        import ctypes
+        import torch
+        dev = [torch.frombuffer(bytearray(bytes(b)), dtype=torch.int64).cuda() if b is not None else None
+               for b in (z, r, s, qx, qy)]
+        out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.sp_ecdsa_verify_batch_dev(dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(),
+                                                 dev[3].data_ptr(), dev[4].data_ptr() if dev[4] is not None else None,
+                                                 out.data_ptr(), n, torch.cuda.current_stream().cuda_stream),
+                   "sp_ecdsa_verify_batch_dev")
+        torch.cuda.synchronize()
+        return out.cpu().tolist()
     return list(bytes(res)[:n])
+
+
+def register_keys(public_keys):
+    """Registers public keys (all ints = x-only, or all (x, y) pairs) in the library's key-table
+    cache; returns one slot index per key (equal keys share a slot)."""
+    import ctypes
+    n = len(public_keys)
+    if n == 0:
+        return []
+    xonly = isinstance(public_keys[0], int)
+    assert all(isinstance(q, int) == xonly for q in public_keys), "mix of x-only and point keys"
+    qx = pack_felts([int(q if xonly else q[0]) % FIELD_PRIME for q in public_keys])
+    qy = None if xonly else pack_felts([int(q[1]) % FIELD_PRIME for q in public_keys])
+    slots = (ctypes.c_uint32 * n)()
+    _lib.check(_lib.ensure_init().sp_ecdsa_register_keys(qx, qy, n, slots), "sp_ecdsa_register_keys")
+    return list(slots)
+
+
+def key_cache_info():
+    import ctypes
+    cap, used = ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.check(_lib.ensure_init().sp_ecdsa_key_cache_info(ctypes.byref(cap), ctypes.byref(used)),
+               "sp_ecdsa_key_cache_info")
+    return cap.value, used.value
+
+
+def key_cache_reset():
+    _lib.check(_lib.ensure_init().sp_ecdsa_key_cache_reset(), "sp_ecdsa_key_cache_reset")
 
 
 def raise_for_verify_code(code, msg_hash, r, s):

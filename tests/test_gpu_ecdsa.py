@@ -264,46 +264,16 @@ def test_verify_crafted_scalars_differential(batch):
     u1*G = +-u2*Q.  Verdicts must equal the oracle's (C oracle for point keys, Python restatement
     for x-only keys)."""
     import random
+    import workloads as wl
     from oracle import cref
     rng = random.Random(77)
     d = rng.randrange(1, N)
     q = R.private_key_to_ec_point_on_stark_curve(d)
-    u2_targets = [1, 2, 3, 15, 16, 17, 31, 32, 33, N - 1, N - 2, N - 3, 2**251, 2**251 - 1, 2**251 + 1,
-                  (N - 1) // 2, (N + 1) // 2, int("f" * 62, 16) % N, int("1" * 62, 16), int("8" * 62, 16) % N]
-    u2_targets += [N - 2 * t for t in range(1, 16, 2)] + [2 * t for t in range(1, 16, 2)]
-    u2_targets += [1 << k for k in (4, 21, 26, 63, 126, 250)] + [(1 << k) - 1 for k in (21, 26, 252)]
-    u1_targets = [1, 2, 2**21 - 1, 2**21, 2**26, 2**42 - 1, 2**251, N - 1, N - 2, rng.randrange(N)]
-    cases = []
-    for u2 in u2_targets:
-        u2 %= N
-        if u2 == 0:
-            continue
-        # (i) a VALID signature with this u2: pick u1, let R = u1 G + u2 Q, r = x(R), s = r / u2, z = u1 s
-        u2q = R.ec_mult(u2, q)
-        for u1 in u1_targets + [rng.randrange(1, N) for _ in range(200)]:
-            a = R.ec_mult(u1, tuple(R.EC_GEN))
-            if a[0] == u2q[0]:
-                continue
-            r = R.ec_add(a, u2q)[0]
-            if not 1 <= r < 2**251:
-                continue
-            s = r * pow(u2, -1, N) % N
-            z = u1 * s % N
-            if s and z < 2**251 and 1 <= pow(s, -1, N) < 2**251:
-                cases.append((z, r, s))
-                break
-        # (ii) the same scalars with an r that does not match, and u1 G = +-u2 Q
-        for u1 in (rng.randrange(1, N), u2 * d % N, (N - u2 * d) % N):
-            for _ in range(200):
-                s = rng.randrange(1, N)
-                r, z = u2 * s % N, u1 * s % N
-                if 1 <= r < 2**251 and z < 2**251 and 1 <= pow(s, -1, N) < 2**251:
-                    cases.append((z, r, s))
-                    break
+    cases = wl.crafted_verify_cases(d, q, rng)
     assert len(cases) > 150
     zs, rs, ss = (list(v) for v in zip(*cases))
     want = cref.verify_codes(zs, rs, ss, [q] * len(cases))
-    assert sum(1 for c in want if c == 1) >= len(u2_targets) - 4  # the crafted valid ones verify
+    assert sum(1 for c in want if c == 1) >= 40  # the crafted valid ones verify
     assert batch.verify_codes(zs, rs, ss, [q] * len(cases)) == want
     # genuinely valid signatures for the doubling corner: u1 G == u2 Q and r == x(2 u1 G)
     valid = []

@@ -1,0 +1,160 @@
+"""Key-table (signed comb) ECDSA verification, csrc/ecdsa.hip "Key tables": must agree with the
+per-signature ladder and with the oracle on every input - golden verdicts of the reference
+(tests/golden/g4_verify.json), crafted corner scalars, random batches with repeated keys."""
+import json
+import os
+import random
+
+import pytest
+
+import workloads as wl
+from oracle import cref
+from oracle import ref_py as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+P, N = R.FIELD_PRIME, R.EC_ORDER
+
+
+def h(s):
+    return int(s, 16)
+
+
+@pytest.fixture(scope="module")
+def batch():
+    from starkperp import batch
+    return batch
+
+
+def _expected_code(c):
+    return {"true": 1, "false": 0}.get(c["expect"])
+
+
+def test_golden_verdicts_through_the_tables(batch):
+    cases = json.load(open(os.path.join(GOLD, "g4_verify.json")))["cases"]
+    for point_keys in (False, True):
+        sel = [c for c in cases if isinstance(c["key"], list) == point_keys]
+        assert sel
+        keys = [tuple(h(v) for v in c["key"]) if point_keys else h(c["key"]) for c in sel]
+        args = ([h(c["z"]) for c in sel], [h(c["r"]) for c in sel], [h(c["s"]) for c in sel], keys)
+        tables = batch.verify_codes(*args, key_tables=True)
+        ladder = batch.verify_codes(*args, key_tables=False)
+        assert tables == ladder
+        for c, code in zip(sel, tables):
+            want = _expected_code(c)
+            if want is None:
+                assert code >= 2, c["label"]
+            else:
+                assert code == want, c["label"]
+        # a second pass finds every key registered already
+        assert batch.verify_codes(*args, key_tables=True) == tables
+
+
+def test_no_scalar_meets_its_own_table_entry():
+    """Why the comb needs no exceptional-case branch for honest tables (the kernel keeps a guard
+    anyway): the last column adds a = +-t_v to 2m with 2m + a = k, and 2m == +-a (mod N) would need
+    k == 2a or k == 0 (mod N).  For each of the 256 signed table multiples, k = 2a mod N is either
+    even (recoded as N - k) or its own column-0 digit is a different multiple."""
+    hits = 0
+    for v in range(128):
+        t = 2**224 + sum((1 if (v >> i) & 1 else -1) * 2 ** (32 * i) for i in range(7))
+        for a in (t, -t):
+            k = 2 * a % N
+            if k % 2 == 0:
+                continue  # the kernel works on N - k; covered by the other sign
+            e = (k - 1) // 2 + 2**255
+            bits = [(e >> (32 * i)) & 1 for i in range(8)]
+            idx = sum(bits[i] << i for i in range(7))
+            if bits[7] == 0:
+                idx ^= 127
+            tv = 2**224 + sum((1 if (idx >> i) & 1 else -1) * 2 ** (32 * i) for i in range(7))
+            if (tv if bits[7] else -tv) == a:
+                hits += 1
+    assert hits == 0
+
+
+def test_crafted_scalars_tables_vs_ladder_vs_oracle(batch):
+    rng = random.Random(99)
+    d = rng.randrange(1, N)
+    q = R.private_key_to_ec_point_on_stark_curve(d)
+    extra = []
+    for t in wl.comb_table_multiples():
+        extra += [t, N - t, 2 * t % N, N - 2 * t % N, (t + 1) % N, (N - 2 * t - 2) % N]
+    extra += [int("ff" * 32, 16) % N, N - (int("ff" * 32, 16) % N), 2**255 % N, 2**224, 2**224 + 1, 2**225 - 1]
+    cases = wl.crafted_verify_cases(d, q, rng, extra_u2=extra)
+    zs, rs, ss = (list(v) for v in zip(*cases))
+    want = cref.verify_codes(zs, rs, ss, [q] * len(cases))
+    assert sum(1 for c in want if c == 1) >= 80
+    for keys in ([q] * len(cases), [q[0]] * len(cases)):
+        tables = batch.verify_codes(zs, rs, ss, keys, key_tables=True)
+        assert tables == batch.verify_codes(zs, rs, ss, keys, key_tables=False)
+        if isinstance(keys[0], tuple):
+            assert tables == want
+        else:
+            assert [c for c in tables] == [1 if w == 1 else 0 for w in want] or tables == batch.verify_codes(
+                zs, rs, ss, keys, key_tables=False)
+    # x-only verdicts against the Python restatement on a sample
+    sample = rng.sample(range(len(cases)), 16)
+    got = batch.verify_codes([zs[i] for i in sample], [rs[i] for i in sample], [ss[i] for i in sample],
+                             [q[0]] * len(sample), key_tables=True)
+    assert got == [int(R.verify(zs[i], rs[i], ss[i], q[0])) for i in sample]
+
+
+def test_random_batch_with_repeated_keys(batch):
+    """4096 signatures from 256 keys (half of the signatures corrupted in z, r, s or the key), point
+    and x-only keys: tables == ladder == C oracle; the policy of the plain entry point may choose
+    either path and must give the same codes."""
+    rng = random.Random(4)
+    n, n_keys = 4096, 256
+    ds = [rng.randrange(1, N) for _ in range(n_keys)]
+    pubs = batch.public_keys_many(ds)
+    owner = [rng.randrange(n_keys) for _ in range(n)]
+    zs = [rng.randrange(2**251) for _ in range(n)]
+    sigs = batch.sign_many(zs, [ds[o] for o in owner])
+    rs, ss = [s[0] for s in sigs], [s[1] for s in sigs]
+    keys = [pubs[o] for o in owner]
+    for i in range(0, n, 2):
+        what = rng.randrange(4)
+        if what == 0:
+            zs[i] = rng.randrange(2**251)
+        elif what == 1:
+            rs[i] = rng.randrange(1, 2**251)
+        elif what == 2:
+            ss[i] = rng.randrange(1, N)
+        else:
+            keys[i] = pubs[(owner[i] + 1) % n_keys]
+    want = cref.verify_codes(zs, rs, ss, keys)
+    assert 1900 < sum(1 for c in want if c == 1) < 2200
+    assert batch.verify_codes(zs, rs, ss, keys, key_tables=True) == want
+    assert batch.verify_codes(zs, rs, ss, keys, key_tables=False) == want
+    assert batch.verify_codes(zs, rs, ss, keys) == want
+    xonly = [k[0] for k in keys]
+    t = batch.verify_codes(zs, rs, ss, xonly, key_tables=True)
+    assert t == batch.verify_codes(zs, rs, ss, xonly, key_tables=False)
+    assert sum(t) >= sum(1 for c in want if c == 1)  # the other y can only add acceptances
+    cap, used = batch.key_cache_info()
+    assert 2 * n_keys <= used <= cap
+
+
+def test_invalid_keys_and_cache_bookkeeping(batch):
+    batch.key_cache_reset()
+    assert batch.key_cache_info()[1] == 0
+    d = 12345
+    q = R.private_key_to_ec_point_on_stark_curve(d)
+    z = 0x1234
+    r, s = R.sign(z, d)
+    bad_x = next(x for x in range(2, 100) if not R.is_quad_residue(x**3 + x + R.BETA))
+    off_curve = (q[0], (q[1] + 1) % P)
+    assert batch.register_keys([q[0], bad_x, q[0]])[0] == batch.register_keys([q[0]])[0]
+    assert batch.key_cache_info()[1] == 2
+    assert batch.verify_codes([z, z], [r, r], [s, s], [q[0], bad_x], key_tables=True) == [1, 0]
+    assert batch.verify_codes([z, z], [r, r], [s, s], [q, off_curve], key_tables=True) == [1, 6]
+    # pre-asserts still come first (signature.py:219-227 before :241)
+    assert batch.verify_codes([z], [r], [0], [off_curve], key_tables=True) == [2]
+    assert batch.verify_codes([2**251], [r], [s], [off_curve], key_tables=True) == [5]
+    # msg_hash == 0 is False only after the key checks
+    assert batch.verify_codes([0, 0], [r, r], [s, s], [q, off_curve], key_tables=True) == [0, 6]
+    assert batch.key_cache_info()[1] == 4
+    batch.key_cache_reset()
+    assert batch.key_cache_info()[1] == 0
+    assert batch.verify_codes([z], [r], [s], [q[0]], key_tables=True) == [1]

@@ -113,3 +113,54 @@ ORDER_ARG_NAMES = [
 
 def order_args(o):
     return [o[k] for k in ORDER_ARG_NAMES]
+
+
+def comb_table_multiples():
+    """Integer multiples held by a key's comb table (csrc/ecdsa.hip "Key tables"):
+    t_v = 2^224 + sum_{i<7} (+-) 2^(32 i); a sample of the 128 patterns."""
+    out = []
+    for v in (0, 1, 2, 64, 85, 126, 127):
+        out.append(2**224 + sum((1 if (v >> i) & 1 else -1) * 2 ** (32 * i) for i in range(7)))
+    return out
+
+
+def crafted_verify_cases(d, q, rng, extra_u2=()):
+    """(z, r, s) triples for the key q = d G whose u1 = z/s and u2 = r/s (mod N) sit on the corners of
+    the verification kernels' scalar handling; about a third are VALID signatures (constructed from
+    the chosen u1, u2), the rest carry an r that does not match or have u1 G = +-u2 Q."""
+    from oracle import ref_py as R
+    N = R.EC_ORDER
+    u2_targets = [1, 2, 3, 15, 16, 17, 31, 32, 33, N - 1, N - 2, N - 3, 2**251, 2**251 - 1, 2**251 + 1,
+                  (N - 1) // 2, (N + 1) // 2, int("f" * 62, 16) % N, int("1" * 62, 16), int("8" * 62, 16) % N]
+    u2_targets += [N - 2 * t for t in range(1, 16, 2)] + [2 * t for t in range(1, 16, 2)]
+    u2_targets += [1 << k for k in (4, 21, 26, 63, 126, 250)] + [(1 << k) - 1 for k in (21, 26, 252)]
+    u2_targets += list(extra_u2)
+    u1_targets = [1, 2, 2**21 - 1, 2**21, 2**26, 2**42 - 1, 2**251, N - 1, N - 2, rng.randrange(N)]
+    cases = []
+    for u2 in u2_targets:
+        u2 %= N
+        if u2 == 0:
+            continue
+        # (i) a VALID signature with this u2: pick u1, let R = u1 G + u2 Q, r = x(R), s = r / u2, z = u1 s
+        u2q = R.ec_mult(u2, q)
+        for u1 in u1_targets + [rng.randrange(1, N) for _ in range(200)]:
+            a = R.ec_mult(u1, tuple(R.EC_GEN))
+            if a[0] == u2q[0]:
+                continue
+            r = R.ec_add(a, u2q)[0]
+            if not 1 <= r < 2**251:
+                continue
+            s = r * pow(u2, -1, N) % N
+            z = u1 * s % N
+            if s and z < 2**251 and 1 <= pow(s, -1, N) < 2**251:
+                cases.append((z, r, s))
+                break
+        # (ii) the same scalars with an r that does not match, and u1 G = +-u2 Q
+        for u1 in (rng.randrange(1, N), u2 * d % N, (N - u2 * d) % N):
+            for _ in range(200):
+                s = rng.randrange(1, N)
+                r, z = u2 * s % N, u1 * s % N
+                if 1 <= r < 2**251 and z < 2**251 and 1 <= pow(s, -1, N) < 2**251:
+                    cases.append((z, r, s))
+                    break
+    return cases

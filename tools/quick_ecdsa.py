@@ -28,3 +28,16 @@ for name, py in (("x-only", None), ("point", qy.data_ptr())):
         torch.cuda.synchronize(); t1 = time.time()
     ok = int((res == 1).sum())
     print("verify %s: %.3f ms -> %.3e verifies/s (true=%d of %d signed ok=%d)" % (name, (t1 - t0) * 1e3, n / (t1 - t0), ok, n, st.count(0)))
+
+# key tables: registration cost and warm verification rate
+import numpy as np
+for label, keyset in (("x-only", [p[0] for p in pubs]), ("point", pubs)):
+    batch.key_cache_reset()
+    t0 = time.time(); slots = batch.register_keys(keyset); t1 = time.time()
+    print("register %d %s keys: %.1f ms host-inclusive (%.3e keys/s)" % (n, label, (t1 - t0) * 1e3, n / (t1 - t0)))
+    dslots = torch.from_numpy(np.asarray(slots, dtype=np.uint32).view(np.int32)).cuda()
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.time()
+        _lib.check(lib.sp_ecdsa_verify_keyed_dev(dz.data_ptr(), dr.data_ptr(), dss.data_ptr(), dslots.data_ptr(), res.data_ptr(), n, s), "keyed")
+        torch.cuda.synchronize(); t1 = time.time()
+    print("verify keyed %s: %.3f ms -> %.3e verifies/s (true=%d)" % (label, (t1 - t0) * 1e3, n / (t1 - t0), int((res == 1).sum())))
