@@ -473,14 +473,24 @@ def extras(torch, lib, _lib, dev, stream):
     t0 = time.perf_counter()
     ok = _batch.verify_many(zsig, [r for r, _ in sigs], [s_ for _, s_ in sigs],
                             [pubs[o["key_index"]][0] for o in orders])
-    t_verify = time.perf_counter() - t0
+    t_verify = time.perf_counter() - t0  # first sight of the 1024 keys: includes building their tables
+    t0 = time.perf_counter()
+    ok2 = _batch.verify_many(zsig, [r for r, _ in sigs], [s_ for _, s_ in sigs],
+                             [pubs[o["key_index"]][0] for o in orders])
+    t_verify_warm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ok3 = _batch.verify_codes(zsig, [r for r, _ in sigs], [s_ for _, s_ in sigs],
+                              [pubs[o["key_index"]][0] for o in orders], key_tables=False)
+    t_verify_ladder = time.perf_counter() - t0
     _state.orders_tree_root({1: 1}, 64)  # warm the per-leaf cache of empty-subtree roots
     t0 = time.perf_counter()
     _state.orders_tree_root({_state.order_id_of(z): o["amount_synthetic"] for z, o in zip(zs, orders)}, 64)
     t_tree = time.perf_counter() - t0
     out["c3_4096_orders_host_inclusive_seconds"] = {
         "message_hashes": t_msgs, "verify_x_only": t_verify, "orders_tree_height64_update": t_tree,
-        "all_verified": bool(all(ok))}
+        "verify_x_only_keys_already_tabulated": t_verify_warm,
+        "verify_x_only_per_signature_ladder": t_verify_ladder,
+        "all_verified": bool(all(ok) and all(ok2) and all(c == 1 for c in ok3))}
     out["c3_orders_per_sec_host_inclusive"] = 4096 / (t_msgs + t_verify + t_tree)
     # device-resident verification rate
     nv = 1 << 16
@@ -497,6 +507,17 @@ def extras(torch, lib, _lib, dev, stream):
         dz.data_ptr(), dr.data_ptr(), dsig.data_ptr(), dq.data_ptr(), None, res.data_ptr(), nv, stream), "verify"), 3)
     out["ecdsa_verifies_per_sec_x_only_2p16"] = nv / sv_t
     out["ecdsa_verify_all_true"] = bool(int((res == 1).sum()) == stv.count(0))
+    # the same signatures through per-key comb tables (csrc/ecdsa.hip "Key tables")
+    import numpy as _np
+    _batch.key_cache_reset()
+    t0 = time.perf_counter()
+    slots = _batch.register_keys([q[0] for q in pv])
+    out["ecdsa_key_registrations_per_sec_host_inclusive"] = nv / (time.perf_counter() - t0)
+    dslots = torch.from_numpy(_np.asarray(slots, dtype=_np.uint32).view(_np.int32)).to(dev)
+    kv_t = timed(lambda: _lib.check(lib.sp_ecdsa_verify_keyed_dev(
+        dz.data_ptr(), dr.data_ptr(), dsig.data_ptr(), dslots.data_ptr(), res.data_ptr(), nv, stream), "keyed"), 3)
+    out["ecdsa_verifies_per_sec_key_tables_2p16"] = nv / kv_t
+    out["ecdsa_verify_key_tables_all_true"] = bool(int((res == 1).sum()) == stv.count(0))
 
     # BASELINE.json configs[3]: 2^20-row trace -> LDE -> commit -> AIR -> commit -> FRI (+commits)
     import random
