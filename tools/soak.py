@@ -37,3 +37,21 @@ got_x = batch.verify_codes(zs, rs, ss, [q[0] for q in pubs])
 print("signatures: %d, oracle true=%d, point-key mismatches=%d, x-only mismatches=%d, %.1f s" % (
     nsig, exp.count(1), sum(a != b for a, b in zip(exp, got_p)), sum(a != b for a, b in zip(exp, got_x)),
     time.time() - t0))
+# key tables (signed comb) against the same oracle verdicts, keys repeated 8x
+t0 = time.time()
+nk = max(1, nsig // 8)
+own = [rng.randrange(nk) for _ in range(nsig)]
+zs2 = [rng.randrange(2**251) for _ in range(nsig)]
+sig2 = batch.sign_many(zs2, [ds[o] for o in own])
+rs2, ss2 = [a for a, _ in sig2], [b for _, b in sig2]
+keys2 = [pubs[o] for o in own]
+for i in range(0, nsig, 3):
+    zs2[i] = (zs2[i] + 1 + rng.randrange(1000)) % 2**251
+exp2 = cref.verify_codes(zs2, rs2, ss2, keys2)
+tab_p = batch.verify_codes(zs2, rs2, ss2, keys2, key_tables=True)
+tab_x = batch.verify_codes(zs2, rs2, ss2, [q[0] for q in keys2], key_tables=True)
+lad_x = batch.verify_codes(zs2, rs2, ss2, [q[0] for q in keys2], key_tables=False)
+print("key tables: %d signatures over %d keys, oracle true=%d, point-key mismatches=%d, x-only vs oracle=%d, "
+      "x-only tables vs ladder=%d, %.1f s" % (
+          nsig, nk, exp2.count(1), sum(a != b for a, b in zip(exp2, tab_p)),
+          sum(a != b for a, b in zip(exp2, tab_x)), sum(a != b for a, b in zip(tab_x, lad_x)), time.time() - t0))
