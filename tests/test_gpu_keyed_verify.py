@@ -50,29 +50,6 @@ def test_golden_verdicts_through_the_tables(batch):
         assert batch.verify_codes(*args, key_tables=True) == tables
 
 
-def test_no_scalar_meets_its_own_table_entry():
-    """Why the comb needs no exceptional-case branch for honest tables (the kernel keeps a guard
-    anyway): the last column adds a = +-t_v to 2m with 2m + a = k, and 2m == +-a (mod N) would need
-    k == 2a or k == 0 (mod N).  For each of the 256 signed table multiples, k = 2a mod N is either
-    even (recoded as N - k) or its own column-0 digit is a different multiple."""
-    hits = 0
-    for v in range(128):
-        t = 2**224 + sum((1 if (v >> i) & 1 else -1) * 2 ** (32 * i) for i in range(7))
-        for a in (t, -t):
-            k = 2 * a % N
-            if k % 2 == 0:
-                continue  # the kernel works on N - k; covered by the other sign
-            e = (k - 1) // 2 + 2**255
-            bits = [(e >> (32 * i)) & 1 for i in range(8)]
-            idx = sum(bits[i] << i for i in range(7))
-            if bits[7] == 0:
-                idx ^= 127
-            tv = 2**224 + sum((1 if (idx >> i) & 1 else -1) * 2 ** (32 * i) for i in range(7))
-            if (tv if bits[7] else -tv) == a:
-                hits += 1
-    assert hits == 0
-
-
 def test_crafted_scalars_tables_vs_ladder_vs_oracle(batch):
     rng = random.Random(99)
     d = rng.randrange(1, N)
