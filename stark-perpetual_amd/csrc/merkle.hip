@@ -6,7 +6,8 @@
 // the hint-side helper starkware/python/merkle_tree.py:4-26 builds the subtree induced by the
 // modified leaves level by level (parents = set(index // 2)).  Same walk here: the host does the
 // integer bookkeeping of which two children feed each induced node (the merkle_tree.py part),
-// the GPU does every hash: per level one gather kernel + the batched Pedersen kernels.
+// the GPU does every hash: per level one pair of Pedersen launches whose accumulate kernel picks its
+// operands through the host's child-index list (gathered mode of csrc/pedersen.hip).
 #include <map>
 #include <vector>
 
@@ -20,21 +21,8 @@ struct Scratch {
 };
 int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
                      size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
-                     const Scratch& s);
+                     const Scratch& s, const int2* src);
 int get_scratch_public(size_t n, Scratch& s, hipStream_t st);
-
-// x[t], y[t] <- children of induced node t (source index < 0: empty-subtree root of this level)
-__global__ void __launch_bounds__(256)
-gather_children_kernel(const uint64_t* __restrict__ prev, const int2* __restrict__ src, size_t m,
-                       const uint64_t* __restrict__ empty_root, uint64_t* __restrict__ x,
-                       uint64_t* __restrict__ y) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= m) return;
-  const int2 s = src[t];
-  const u256 e = ld_u256(empty_root);
-  st_u256(x + 4 * t, s.x >= 0 ? ld_u256(prev + 4 * (size_t)s.x) : e);
-  st_u256(y + 4 * t, s.y >= 0 ? ld_u256(prev + 4 * (size_t)s.y) : e);
-}
 
 static DeviceBuffer g_sparse_buf;
 // empty-subtree roots are a pure function of the empty leaf: cached on the host per leaf value
@@ -82,19 +70,17 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
     level_cnt.push_back(nxt.size());
     idx.swap(nxt);
   }
-  // ---- device buffers: empties[height+1], vals ping/pong [n], x[n], y[n], src ----
+  // ---- device buffers: empties[height+1], vals ping/pong [n], src ----
   const size_t nn = n ? n : 1;
   const size_t fb = nn * 32;
   const size_t emp_bytes = ((size_t)height + 1) * 32;
   const size_t src_bytes = (src.size() + 1) * sizeof(int2);
-  SP_HIP(g_sparse_buf.reserve(emp_bytes + 4 * fb + src_bytes + 1024));
+  SP_HIP(g_sparse_buf.reserve(emp_bytes + 2 * fb + src_bytes + 1024));
   char* b = (char*)g_sparse_buf.ptr;
   uint64_t* d_emp = (uint64_t*)b;
   uint64_t* d_a = (uint64_t*)(b + emp_bytes);
   uint64_t* d_b = (uint64_t*)(b + emp_bytes + fb);
-  uint64_t* d_x = (uint64_t*)(b + emp_bytes + 2 * fb);
-  uint64_t* d_y = (uint64_t*)(b + emp_bytes + 3 * fb);
-  int2* d_src = (int2*)(b + emp_bytes + 4 * fb);
+  int2* d_src = (int2*)(b + emp_bytes + 2 * fb);
   Scratch s;
   int rc = get_scratch_public(nn, s, 0);
   if (rc != SP_OK) return rc;
@@ -110,7 +96,7 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
       SP_HIP(hipMalloc(&d_full, 65 * 32));
       SP_HIP(hipMemcpy(d_full, empty_leaf, 32, hipMemcpyHostToDevice));
       for (unsigned k2 = 0; k2 < 64; ++k2) {
-        rc = enqueue_pedersen(d_full + 4 * k2, 1, d_full + 4 * k2, 1, d_full + 4 * (k2 + 1), 1, nullptr, s.flag, 1, 0, s);
+        rc = enqueue_pedersen(d_full + 4 * k2, 1, d_full + 4 * k2, 1, d_full + 4 * (k2 + 1), 1, nullptr, s.flag, 1, 0, s, nullptr);
         if (rc != SP_OK) { (void)hipFree(d_full); return rc; }
       }
       std::vector<uint64_t> all(65 * 4);
@@ -130,9 +116,9 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
     uint64_t *cur = d_a, *nxt = d_b;
     for (size_t l = 0; l < level_cnt.size(); ++l) {
       const size_t m = level_cnt[l];
-      hipLaunchKernelGGL(gather_children_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, cur,
-                         d_src + level_off[l], m, d_emp + 4 * l, d_x, d_y);
-      rc = enqueue_pedersen(d_x, 1, d_y, 1, nxt, 1, nullptr, s.flag, m, 0, s);
+      // gathered mode: operand pointers come from src (children in `cur`, or this level's
+      // empty-subtree root) inside the accumulate kernel - no separate gather pass
+      rc = enqueue_pedersen(cur, 1, d_emp + 4 * l, 1, nxt, 1, nullptr, s.flag, m, 0, s, d_src + level_off[l]);
       if (rc != SP_OK) return rc;
       std::swap(cur, nxt);
     }

@@ -67,16 +67,34 @@ __device__ __forceinline__ fe load_limbs(const int32_t* base, size_t n, size_t e
   return v;
 }
 
+// Where hash e reads its two operands.  Dense mode (src == nullptr): x + 4 e xstride, y + 4 e ystride.
+// Gathered mode (sparse Merkle update): src[e] = indices of the two children in the previous level
+// `x`, a negative index meaning "the empty-subtree root of this level", which `y` points at.
+__device__ __forceinline__ void operand_pointers(const uint64_t* x, const uint64_t* y, size_t xstride,
+                                                 size_t ystride, const int2* __restrict__ src, size_t e,
+                                                 const uint64_t*& fx, const uint64_t*& fy) {
+  if (src == nullptr) {
+    fx = x + 4 * e * xstride;
+    fy = y + 4 * e * ystride;
+  } else {
+    const int2 s = src[e];
+    fx = s.x >= 0 ? x + 4 * (size_t)s.x : y;
+    fy = s.y >= 0 ? x + 4 * (size_t)s.y : y;
+  }
+}
+
 // Kernel A: one hash per thread -> projective (X, ZZ) in scratch.
 __global__ void __launch_bounds__(256, SP_ACC_WAVES)
 ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
                       size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits, int nwin,
                       int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, uint8_t* __restrict__ status,
-                      unsigned* __restrict__ flag) {
+                      unsigned* __restrict__ flag, const int2* __restrict__ src) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
-  u256 sx = ld_u256(x + 4 * e * xstride);
-  u256 sy = ld_u256(y + 4 * e * ystride);
+  const uint64_t *fx, *fy;
+  operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
+  u256 sx = ld_u256(fx);
+  u256 sy = ld_u256(fy);
   uint8_t st = SP_HASH_OK;
   if (!u256_lt(sx, U256_P) || !u256_lt(sy, U256_P)) {  // signature.py:307
     st = SP_HASH_OUT_OF_RANGE;
@@ -176,15 +194,16 @@ __global__ void __launch_bounds__(256)
 ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
                             size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits,
                             int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
-                            uint8_t* __restrict__ status, unsigned* __restrict__ flag) {
+                            uint8_t* __restrict__ status, unsigned* __restrict__ flag,
+                            const int2* __restrict__ src) {
   constexpr int L = 1 << LOG_L;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t e_raw = gt >> LOG_L;
   const int sub = (int)(gt & (L - 1));
   const bool active = e_raw < n;
   const size_t e = active ? e_raw : n - 1;  // clamp: whole lane groups stay convergent for the shuffles
-  const uint64_t* fx = x + 4 * e * xstride;
-  const uint64_t* fy = y + 4 * e * ystride;
+  const uint64_t *fx, *fy;
+  operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
   const xyzz acc = split_accumulate<LOG_L>(fx, fy, sub, ped, wbits, nwin);
   if (!active || sub != 0) return;
   uint8_t st = SP_HASH_OK;
@@ -310,7 +329,7 @@ void release_pedersen_state() {
 // Enqueue n hashes; x/y/out strides in felts.  `flag` (device, may be null) ORs item status.
 int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
                      size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
-                     const Scratch& s) {
+                     const Scratch& s, const int2* src) {
   if (n == 0) return SP_OK;
   Context& c = ctx();
   const unsigned blocksA = (unsigned)((n + 255) / 256);
@@ -326,18 +345,18 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
   }
   if (log_l == 0) {
     hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped,
-                       c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+                       c.wbits, c.nwin, s.X, s.ZZ, status, flag, src);
   } else {
     const unsigned blocks = (unsigned)(((n << log_l) + 255) / 256);
     if (log_l == 3)
       hipLaunchKernelGGL(ped_accumulate_split_kernel<3>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
-                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag, src);
     else if (log_l == 2)
       hipLaunchKernelGGL(ped_accumulate_split_kernel<2>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
-                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag, src);
     else
       hipLaunchKernelGGL(ped_accumulate_split_kernel<1>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
-                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag);
+                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag, src);
   }
   if (prof) {
     (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
@@ -366,7 +385,7 @@ int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, u
   Scratch s;
   int rc = get_scratch(n, s, (hipStream_t)stream);
   if (rc != SP_OK) return rc;
-  return enqueue_pedersen(x, 1, y, 1, out, 1, status, nullptr, n, (hipStream_t)stream, s);
+  return enqueue_pedersen(x, 1, y, 1, out, 1, status, nullptr, n, (hipStream_t)stream, s, nullptr);
 }
 
 int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n) {
@@ -385,7 +404,7 @@ int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8
   Scratch s;
   int rc = get_scratch(n, s, 0);
   if (rc != SP_OK) return rc;
-  rc = enqueue_pedersen(dx, 1, dy, 1, dout, 1, dst, nullptr, n, 0, s);
+  rc = enqueue_pedersen(dx, 1, dy, 1, dout, 1, dst, nullptr, n, 0, s, nullptr);
   if (rc != SP_OK) return rc;
   SP_HIP(hipDeviceSynchronize());
   SP_HIP(hipMemcpy(out, dout, fb, hipMemcpyDeviceToHost));
@@ -470,7 +489,7 @@ int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, ui
   // kernel A of the same launch pair consumed it (A and B are separate kernels on one stream).
   const uint64_t* h = elems;
   for (size_t j = 1; j < depth; ++j) {
-    rc = enqueue_pedersen(h, 1, elems + 4 * j * width, 1, out, 1, nullptr, s.flag, width, st, s);
+    rc = enqueue_pedersen(h, 1, elems + 4 * j * width, 1, out, 1, nullptr, s.flag, width, st, s, nullptr);
     if (rc != SP_OK) return rc;
     h = out;
   }
@@ -536,7 +555,7 @@ int sp_pedersen_chain_right(const uint64_t* elems, size_t n_elems, uint64_t* out
   const uint64_t* h = d_el + 4 * (n_elems - 1);
   uint64_t* nxt = d_a;
   for (size_t i = n_elems - 1; i-- > 0;) {
-    rc = enqueue_pedersen(d_el + 4 * i, 1, h, 1, nxt, 1, nullptr, s.flag, 1, 0, s);
+    rc = enqueue_pedersen(d_el + 4 * i, 1, h, 1, nxt, 1, nullptr, s.flag, 1, 0, s, nullptr);
     if (rc != SP_OK) return rc;
     h = nxt;
     nxt = (nxt == d_a) ? d_b : d_a;
@@ -573,7 +592,7 @@ int sp_merkle_forest_dev(uint64_t* levels, size_t n_trees, unsigned height, uint
   size_t n = n0;
   for (unsigned k = 0; k < height; ++k, n >>= 1) {
     uint64_t* nxt = cur + 4 * n;
-    rc = enqueue_pedersen(cur, 2, cur + 4, 2, nxt, 1, nullptr, s.flag, n / 2, st, s);
+    rc = enqueue_pedersen(cur, 2, cur + 4, 2, nxt, 1, nullptr, s.flag, n / 2, st, s, nullptr);
     if (rc != SP_OK) return rc;
     cur = nxt;
   }
