@@ -96,6 +96,21 @@ def cpu_baseline_c(leaf_ints, gpu_root):
             "root_matches_gpu": levels[-1][0] == gpu_root}
 
 
+def combine_check(slot, world, _lib):
+    """N > 1: the job root of tree 0 of the last call issued on stream 0 against the C oracle's tree
+    over the gathered sub-roots (rank order).  None when the oracle library is not available."""
+    try:
+        from oracle import cref
+        nb = slot["last_nb"]
+        top = slot["top"][: nb * (2 * world - 1)].cpu().numpy().astype("<i8")
+        felts = _lib.unpack_felts((ctypes.c_uint64 * (4 * top.shape[0])).from_buffer_copy(top.tobytes()), top.shape[0])
+        leaves, root = felts[:world], felts[nb * (2 * world - 1) - nb]
+        return cref.merkle_levels(leaves)[-1][0] == root
+    except Exception as e:  # noqa: BLE001 - a missing checker must not void the measurement
+        sys.stderr.write("bench: combine check skipped (%s)\n" % e)
+        return None
+
+
 def valu_issue(bulk_hashes_per_sec, window_bits):
     """The roofline that actually bounds the hash kernels: wave64 VALU
     instructions issued per second against 1024 SIMDs x one instruction per 4 cycles.  Instruction
@@ -169,24 +184,31 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Test hook for boxes with ONE GPU (tests/test_gpu_bench_ranks.py): every rank on device 0 and the
+    # sub-root exchange over gloo, so that the N > 1 code path runs end to end.  Never set by the driver.
+    share_gpu = os.environ.get("STARKPERP_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from starkperp import _lib
     from starkperp.distributed import combine_forest_dev
 
     try:
-        lib = _lib.ensure_init(local_rank, args.window_bits or None)
+        lib = _lib.ensure_init(dev_index, args.window_bits or None)
     except _lib.StarkPerpError as e:
         if not args.window_bits:
             raise
         sys.stderr.write("bench: %d-bit tables unavailable (%s); using the library default\n" % (args.window_bits, e))
-        lib = _lib.ensure_init(local_rank, None)
+        lib = _lib.ensure_init(dev_index, None)
     if args.workload == "airfri":
         return run_airfri(args, torch, dist, lib, _lib, dev, rank, world)
     n_leaves = 1 << HEIGHT
@@ -237,6 +259,7 @@ def main():
         """One lockstep call: nb complete 2^16-leaf rebuilds (+ the cross-rank combine)."""
         sl = slots[call_counter[0] % n_streams]
         call_counter[0] += 1
+        sl["last_nb"] = nb
         with torch.cuda.stream(sl["stream"]):
             h = sl["stream"].cuda_stream
             buf = sl["levels"][nb]
@@ -319,6 +342,8 @@ def main():
                         "because the contract asks for it",
             },
         }
+        if world > 1:
+            result["combine_matches_oracle"] = combine_check(slots[0], world, _lib)
         if world == 1 and not args.no_extras:
             result["extra"] = extras(torch, lib, _lib, dev, stream)
         if world == 1 and not args.no_cpu_baseline:

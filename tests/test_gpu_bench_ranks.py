@@ -1,0 +1,38 @@
+"""bench.py's N > 1 path end to end on a one-GPU box: two ranks launched exactly as the driver does
+(torch.distributed.run), both on device 0, sub-roots exchanged over gloo (STARKPERP_BENCH_SHARE_GPU=1,
+a hook that exists only for this test).  Checks the JSON contract and the combined root."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("workload,extra", [("merkle", ["--steps", "6", "--warmup", "2"]),
+                                            ("airfri", ["--steps", "1", "--warmup", "1", "--log-rows", "14"])])
+def test_two_ranks_share_one_gpu(workload, extra):
+    env = dict(os.environ, STARKPERP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--workload", workload, "--window-bits", "0", "--no-extras", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["steps"] == int(extra[1]) and d["warmup"] == int(extra[3])
+    if workload == "merkle":
+        assert d["config"]["hashes_per_step"] == 2 * 65535 + 1
+        assert d["combine_matches_oracle"] is True
