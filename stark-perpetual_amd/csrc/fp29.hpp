@@ -455,6 +455,19 @@ SP_HD fe fe_inv_plain_gcd(const fe& x) {
     zeta = divsteps_29(zeta, (uint32_t)f.l[0], (uint32_t)g.l[0], t);
     gcd_update_de(d, e, t);
     gcd_update_fg(f, g, t);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Once g == 0 the remaining divsteps only halve and re-double (d, e) / (f, g) in lockstep and
+    // leave d * sign(f) unchanged, so leaving early is exact.  Random inputs need 491..523 divsteps
+    // (mean 507): a wave is done after 18 rounds, rarely 19, instead of the worst-case 21.  The
+    // test is wave-uniform, so there is no divergence.  Field inversions only see public data
+    // (hash outputs, signature verification); the mod-N inversion used by signing stays fixed-length.
+    if (it >= 16) {
+      int32_t nz = 0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) nz |= g.l[i];
+      if (__all(nz == 0)) break;
+    }
+#endif
   }
   // f = +-1; result = d * sign(f), brought to [0, p)
   const int32_t sf = f.l[NL - 1] >> 31;  // -1 if f negative
