@@ -127,7 +127,7 @@ def valu_issue(bulk_hashes_per_sec, window_bits):
     return {"bound": "valu_issue", "workload": "2^22 independent hashes (bulk_pedersen_hashes_per_sec)",
             "instr_per_hash": per_hash, "achieved": achieved, "peak": peak, "unit": "wave64 VALU instr/s",
             "frac": achieved / peak,
-            "note": "peak at the nominal 2.4 GHz; the chip runs this kernel at about 1.94 GHz "
+            "note": "peak at the nominal 2.4 GHz; the chip runs this kernel at about 1.9 GHz "
                     "(GRBM_GUI_ACTIVE), where the measured issue interval is 4.2 cycles per SIMD"}
 
 
@@ -163,10 +163,12 @@ def main():
                     help="comma-separated call sizes (trees per lockstep call, issued round-robin over the "
                          "streams) for the TIMED steps; must sum to --steps.  Default: see plan()")
     ap.add_argument("--window-bits", type=int, default=26,
-                    help="table window width: 26 = 120 GB of the 288 GB HBM as tables (10 windows per "
-                         "operand instead of 12, +12 %% on this workload, ~5 s to build, outside the timed "
-                         "region); 0 = the library default 21 = 4.5 GiB.  If the wide tables cannot be "
-                         "allocated the bench falls back to the library default and says so in config")
+                    help="log2 of the entries per signed window of the Pedersen tables: 26 = 75 GiB of the "
+                         "288 GB HBM as tables, 19 table entries per hash (~2 s to build, outside the timed "
+                         "region; 27 = 155 GiB / 18 entries is no faster: its gathers stop hiding behind the "
+                         "arithmetic); 0 = the library default 21 = 4.3 GiB, 23 entries per hash.  If the "
+                         "wide tables cannot be allocated the bench falls back to the library default and "
+                         "says so in config")
     ap.add_argument("--log-rows", type=int, default=20,
                     help="airfri workload: log2 of the trace rows per GPU (20 = configs[3]; 24 = the whole "
                          "configs[4] trace on ONE GPU, 14 GiB of columns and trees)")
@@ -337,7 +339,7 @@ def main():
                 "launches": int(k_launches.value),
                 "avg_launch_us": avg_launch_s * 1e6,
                 "timing": "HIP events around every launch inside the timed region",
-                "note": "integer-ALU bound kernel (DESIGN.md section 4): 33-39e3 VALU instructions per hash at the "
+                "note": "integer-ALU bound kernel (DESIGN.md section 4): 31-38e3 VALU instructions per hash at the "
                         "VALU issue limit (extra.valu_issue has that roofline); the HBM fraction is reported "
                         "because the contract asks for it",
             },

@@ -1,15 +1,23 @@
 // sp_init / sp_shutdown and the HBM window-table builder.
 //
-// Pedersen (signature.py:300-318) is  shift + sum_j x_j C[2+j] + sum_j y_j C[254+j]  over the 504
-// per-bit constant points.  The device tables hold, for element e, window i and window value v,
-//     T[e][i][v] = S[e][i] + sum_{b : bit b of v set} C[2 + 252 e + i w + b]
-// as affine points, where the offsets S are points of unknown discrete logarithm relative to the
-// hash generators (random multiples of EC_GEN) chosen so that sum_{e,i} S[e][i] = SHIFT_POINT.
-// A hash is then the sum of 2*nwin table entries - no entry is the point at infinity, and a
-// partial sum can only meet the next entry's x-coordinate through a non-trivial relation between
-// independent generators, i.e. never for inputs anyone can compute.
-// The EC_GEN table (k*G for sign / public keys / the z*G leg of verify) has the same shape with
-// offsets that are multiples of P0 and sum to the point at infinity.
+// Pedersen (signature.py:300-318) is  SHIFT + sum_j b_j C_j  over the 504 per-bit constant points
+// C_j of the string b = x || y (C_j = C[2 + j] of the reference's table: doublings of P0 for bits
+// 0..247, of P1 for 248..251, of P2, P3 for y).  The device tables use the SIGNED form of that sum:
+// with the half points C'_j = C_j / 2 (C'_j = C_{j-1} inside a doubling chain; the four chain heads
+// P_i / 2 are computed once with the scalar (N + 1) / 2) and s_j = 2 b_j - 1,
+//     SHIFT + sum_j b_j C_j  =  K + sum_j s_j C'_j,      K = SHIFT + sum_j C'_j.
+// A window of w + 1 bits then needs only 2^w entries: the entry for the complemented pattern is the
+// negated point, so the window's top bit is read as the sign (negating y is free) and the low w bits
+// (complemented when the sign is negative) index
+//     T_g[v] = C'_top - sum_{b<w} C'_{s+b} + sum_{b : bit b of v set} C_{s+b}.
+// Window 0 is unsigned and carries K:  T_0[v] = SHIFT + sum_{j >= w0} C'_j + sum_{b in v} C_b.
+// With 2^27-entry windows (163 GB of the 288 GB) 504 = 28 + 17 * 28 bits are 18 entries per hash;
+// the default 2^21 (4.3 GiB) gives 20 + 22 * 22 -> 23 entries.  No entry is the point at infinity
+// (a signed window is an odd multiple of half a chain head; window 0 carries SHIFT), and a partial
+// sum meets the next entry only through a relation between independent generators or between
+// windows of different 2-adic weight - never.  The builder checks every entry against the curve.
+// The EC_GEN table (k*G for sign / public keys / the z*G leg of verify) is the plain unsigned
+// uniform-window table with offsets that are multiples of P0 and sum to the point at infinity.
 #include <cstring>
 #include <vector>
 
@@ -37,21 +45,15 @@ int hip_fail(hipError_t e, const char* what) {
   return SP_ERR_HIP;
 }
 
-// One thread per table entry.
+// One thread per entry of ONE window: tab[v] = off + sum_{b < nb : bit b of v set} bits[b].
 __global__ void __launch_bounds__(256)
-build_table_kernel(aff_packed* tab, const aff_packed* bits, const aff_packed* offs, int wbits,
-                   int nwin, int total_bits, fe beta_m, unsigned* bad) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t per = (size_t)1 << wbits;
-  if (idx >= per * (size_t)nwin) return;
-  const int win = (int)(idx >> wbits);
-  const uint32_t v = (uint32_t)(idx & (per - 1));
-  int nb = total_bits - win * wbits;
-  if (nb > wbits) nb = wbits;
-  if (nb < 32 && v >= (1u << nb)) return;
-  xyzz acc = xyzz_from_aff(ld_aff(offs + win));
+build_window_kernel(aff_packed* tab, const aff_packed* bits, const aff_packed* off, int nb, fe beta_m,
+                    unsigned* bad) {
+  const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >> nb) return;
+  xyzz acc = xyzz_from_aff(ld_aff(off));
   for (int b = 0; b < nb; ++b) {
-    if ((v >> b) & 1u) acc = xyzz_madd(acc, ld_aff(bits + win * wbits + b));
+    if ((v >> b) & 1u) acc = xyzz_madd(acc, ld_aff(bits + b));
   }
   const fe izzz = fe_inv(acc.ZZZ);
   const fe izz = fe_sqr(fe_mul(acc.ZZ, izzz));  // 1/ZZ = (ZZ/ZZZ)^2
@@ -64,7 +66,7 @@ build_table_kernel(aff_packed* tab, const aff_packed* bits, const aff_packed* of
   aff_packed out;
   out.x = fe_pack(fe_canon(x));
   out.y = fe_pack(fe_canon(y));
-  tab[idx] = out;
+  tab[v] = out;
 }
 
 static aff_packed pack_point(const haff& p) {
@@ -82,29 +84,21 @@ static uint64_t splitmix(uint64_t& s) {
   return z ^ (z >> 31);
 }
 
-// Builds one table group on the device: `nseg` scalars (1 for EC_GEN, 2 for Pedersen), each with
-// 252 per-bit points `bit_pts[seg*252 + j]`, offsets from multiples of `off_base` that sum to
-// `target` (may be infinity).
-static int build_group(aff_packed* dev_tab, int nseg, const std::vector<haff>& bit_pts,
-                       const haff& off_base, const haff& target, uint64_t seed, int wbits,
-                       int nwin) {
-  const int nofs = nseg * nwin;
-  std::vector<haff> offs(nofs);
-  haff sum{FE_ZERO, FE_ZERO, true};
-  uint64_t st = seed;
-  for (int i = 1; i < nofs; ++i) {
-    uint64_t k[4] = {splitmix(st), splitmix(st), splitmix(st), splitmix(st) >> 6};
-    offs[i] = h_mul(k, off_base);
-    sum = h_add(sum, offs[i]);
-  }
-  offs[0] = h_add(target, h_neg(sum));
-  if (offs[0].inf) {
-    set_error("table offsets degenerate");
-    return SP_ERR_TABLE_BUILD;
-  }
-  std::vector<aff_packed> h_bits(bit_pts.size()), h_offs(nofs);
+// Builds windows on the device: window g = `nb[g]` per-bit points starting at bit_pts[first[g]],
+// offset point offs[g], entries written at dev_tab + base[g].
+static int build_windows(aff_packed* dev_tab, const std::vector<haff>& bit_pts, const std::vector<haff>& offs,
+                         const std::vector<int>& first, const std::vector<int>& nb,
+                         const std::vector<uint64_t>& base) {
+  const size_t nw = offs.size();
+  std::vector<aff_packed> h_bits(bit_pts.size()), h_offs(nw);
   for (size_t i = 0; i < bit_pts.size(); ++i) h_bits[i] = pack_point(bit_pts[i]);
-  for (int i = 0; i < nofs; ++i) h_offs[i] = pack_point(offs[i]);
+  for (size_t i = 0; i < nw; ++i) {
+    if (offs[i].inf) {
+      set_error("table offsets degenerate");
+      return SP_ERR_TABLE_BUILD;
+    }
+    h_offs[i] = pack_point(offs[i]);
+  }
   aff_packed *d_bits = nullptr, *d_offs = nullptr;
   unsigned* d_bad = nullptr;
   SP_HIP(hipMalloc(&d_bits, h_bits.size() * sizeof(aff_packed)));
@@ -114,11 +108,10 @@ static int build_group(aff_packed* dev_tab, int nseg, const std::vector<haff>& b
   SP_HIP(hipMemcpy(d_offs, h_offs.data(), h_offs.size() * sizeof(aff_packed), hipMemcpyHostToDevice));
   SP_HIP(hipMemset(d_bad, 0, sizeof(unsigned)));
   const fe beta_m = fe_to_mont(fe_unpack(CURVE_BETA));
-  const size_t per_seg = (size_t)nwin << wbits;
-  for (int seg = 0; seg < nseg; ++seg) {
-    const unsigned blocks = (unsigned)((per_seg + 255) / 256);
-    hipLaunchKernelGGL(build_table_kernel, dim3(blocks), dim3(256), 0, 0, dev_tab + seg * per_seg,
-                       d_bits + seg * 252, d_offs + seg * nwin, wbits, nwin, 252, beta_m, d_bad);
+  for (size_t g = 0; g < nw; ++g) {
+    const size_t count = (size_t)1 << nb[g];
+    hipLaunchKernelGGL(build_window_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0,
+                       dev_tab + base[g], d_bits + first[g], d_offs + g, nb[g], beta_m, d_bad);
   }
   SP_HIP(hipGetLastError());
   SP_HIP(hipDeviceSynchronize());
@@ -131,6 +124,55 @@ static int build_group(aff_packed* dev_tab, int nseg, const std::vector<haff>& b
     set_error("table build produced " + std::to_string(bad) + " off-curve entries");
     return SP_ERR_TABLE_BUILD;
   }
+  return SP_OK;
+}
+
+// EC_GEN table: uniform unsigned windows, offsets = random multiples of `off_base` summing to infinity.
+static int build_gen_table(aff_packed* dev_tab, const std::vector<haff>& bit_pts, const haff& off_base,
+                           uint64_t seed, int wbits, int nwin) {
+  std::vector<haff> offs(nwin);
+  haff sum{FE_ZERO, FE_ZERO, true};
+  uint64_t st = seed;
+  for (int i = 1; i < nwin; ++i) {
+    uint64_t k[4] = {splitmix(st), splitmix(st), splitmix(st), splitmix(st) >> 6};
+    offs[i] = h_mul(k, off_base);
+    sum = h_add(sum, offs[i]);
+  }
+  offs[0] = h_neg(sum);
+  std::vector<int> first(nwin), nb(nwin);
+  std::vector<uint64_t> base(nwin);
+  for (int i = 0; i < nwin; ++i) {
+    first[i] = i * wbits;
+    nb[i] = 252 - i * wbits < wbits ? 252 - i * wbits : wbits;
+    base[i] = (uint64_t)i << wbits;
+  }
+  return build_windows(dev_tab, bit_pts, offs, first, nb, base);
+}
+
+// Window plan for 2^log2e-entry signed windows: as many (log2e + 1)-bit signed windows as fit below
+// bit 504, the remaining low bits (at least one) as the unsigned window 0.
+static int make_plan(int log2e, PedPlan& p) {
+  const int sw = log2e + 1;
+  int k = 504 / sw;
+  int w0 = 504 - k * sw;
+  if (w0 == 0) { --k; w0 = sw; }
+  if (k + 1 > PED_MAX_WINDOWS) {
+    set_error("window_bits too small for the window plan");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  p.nwin = k + 1;
+  p.log2e = log2e;
+  p.start[0] = 0;
+  p.bits[0] = (uint8_t)w0;
+  p.base[0] = 0;
+  uint64_t next = (uint64_t)1 << w0;
+  for (int g = 1; g <= k; ++g) {
+    p.start[g] = (uint16_t)(w0 + (g - 1) * sw);
+    p.bits[g] = (uint8_t)sw;
+    p.base[g] = next;
+    next += (uint64_t)1 << log2e;
+  }
+  p.entries = next;
   return SP_OK;
 }
 
@@ -148,26 +190,51 @@ static int init_locked(int device, int window_bits) {
     set_error("device index out of range");
     return SP_ERR_BAD_ARGUMENT;
   }
-  if (window_bits == 0) window_bits = 21;  // 12 windows of 21 bits cover the 252-bit scalars exactly
-  if (window_bits < 4 || window_bits > 26) {
-    set_error("window_bits must be in [4, 26]");
+  if (window_bits == 0) window_bits = 21;  // 2^21-entry windows: 23 entries per hash, 4.3 GiB
+  if (window_bits < 4 || window_bits > 27) {
+    set_error("window_bits must be in [4, 27]");
     return SP_ERR_BAD_ARGUMENT;
   }
   SP_HIP(hipSetDevice(device));
   c.device = device;
-  c.wbits = window_bits;
-  c.nwin = (252 + window_bits - 1) / window_bits;
+  int rc = make_plan(window_bits, c.plan);
+  if (rc != SP_OK) return rc;
+  c.wbits = window_bits < 22 ? window_bits : 22;  // EC_GEN table: 12 windows are plenty for ECDSA
+  c.nwin = (252 + c.wbits - 1) / c.wbits;
 
-  // per-bit points: C[2 + 252 e + j] (nothing_up_my_sleeve_gen.py:88-90: 248 doublings of P0/P2,
-  // 4 of P1/P3) and 2^j * EC_GEN
-  std::vector<haff> ped_bits(504), gen_bits(252);
+  // per-bit points C_j of x || y (nothing_up_my_sleeve_gen.py:88-90: 248 doublings of P0/P2, 4 of
+  // P1/P3), their halves C'_j, and 2^j * EC_GEN
+  std::vector<haff> ped_bits(504), half_bits(504), gen_bits(252);
   const haff bases[4] = {h_make(PT_P0_X, PT_P0_Y), h_make(PT_P1_X, PT_P1_Y),
                          h_make(PT_P2_X, PT_P2_Y), h_make(PT_P3_X, PT_P3_Y)};
+  uint64_t half_n[4];
+  {  // (N + 1) / 2: halving in the (odd, prime order) group
+    uint64_t n[4];
+    for (int i = 0; i < 4; ++i) n[i] = (uint64_t)U256_N.w[2 * i] | ((uint64_t)U256_N.w[2 * i + 1] << 32);
+    unsigned carry = 1;  // N + 1
+    for (int i = 0; i < 4; ++i) {
+      const uint64_t v = n[i] + carry;
+      carry = (carry && v == 0) ? 1 : 0;
+      n[i] = v;
+    }
+    for (int i = 0; i < 4; ++i) half_n[i] = (n[i] >> 1) | (i < 3 ? n[i + 1] << 63 : 0);
+  }
   for (int e2 = 0; e2 < 2; ++e2) {
-    haff q = bases[2 * e2];
-    for (int j = 0; j < 248; ++j) { ped_bits[252 * e2 + j] = q; q = h_dbl(q); }
-    q = bases[2 * e2 + 1];
-    for (int j = 0; j < 4; ++j) { ped_bits[252 * e2 + 248 + j] = q; q = h_dbl(q); }
+    for (int part = 0; part < 2; ++part) {
+      const int first = 252 * e2 + (part ? 248 : 0), count = part ? 4 : 248;
+      const haff head = bases[2 * e2 + part];
+      const haff half_head = h_mul(half_n, head);
+      if (half_head.inf || !fe_eq(h_dbl(half_head).x, head.x)) {
+        set_error("halving a chain head failed");
+        return SP_ERR_TABLE_BUILD;
+      }
+      haff q = head;
+      for (int j = 0; j < count; ++j) {
+        ped_bits[first + j] = q;
+        half_bits[first + j] = j == 0 ? half_head : ped_bits[first + j - 1];
+        q = h_dbl(q);
+      }
+    }
   }
   const haff G = h_make(PT_GEN_X, PT_GEN_Y);
   {
@@ -175,17 +242,40 @@ static int init_locked(int device, int window_bits) {
     for (int j = 0; j < 252; ++j) { gen_bits[j] = q; q = h_dbl(q); }
   }
   const haff shift = h_make(PT_SHIFT_X, PT_SHIFT_Y);
-  const haff infinity{FE_ZERO, FE_ZERO, true};
 
-  const size_t per_seg = (size_t)c.nwin << c.wbits;
-  SP_HIP(hipMalloc(&c.ped, 2 * per_seg * sizeof(aff_packed)));
-  SP_HIP(hipMalloc(&c.gen, per_seg * sizeof(aff_packed)));
-  SP_HIP(hipMemset(c.ped, 0, 2 * per_seg * sizeof(aff_packed)));
-  SP_HIP(hipMemset(c.gen, 0, per_seg * sizeof(aff_packed)));
-  c.table_bytes = 3 * per_seg * sizeof(aff_packed);
-  int rc = build_group(c.ped, 2, ped_bits, G, shift, 0x5350454445525345ull, c.wbits, c.nwin);
+  // window offsets: O_0 = SHIFT + sum_{j >= w0} C'_j;  O_g = C'_top - sum_{b < log2e} C'_{s+b}
+  const PedPlan& p = c.plan;
+  std::vector<haff> offs(p.nwin);
+  std::vector<int> first(p.nwin), nb(p.nwin);
+  std::vector<uint64_t> base(p.nwin);
+  {
+    haff o = shift;
+    for (int j = p.bits[0]; j < 504; ++j) o = h_add(o, half_bits[j]);
+    offs[0] = o;
+    first[0] = 0;
+    nb[0] = p.bits[0];
+    base[0] = 0;
+  }
+  for (int g = 1; g < p.nwin; ++g) {
+    const int s0 = p.start[g];
+    haff o = half_bits[s0 + p.log2e];
+    for (int b = 0; b < p.log2e; ++b) o = h_add(o, h_neg(half_bits[s0 + b]));
+    offs[g] = o;
+    first[g] = s0;
+    nb[g] = p.log2e;
+    base[g] = p.base[g];
+  }
+
+  const size_t gen_entries = (size_t)c.nwin << c.wbits;
+  SP_HIP(hipMalloc(&c.ped, p.entries * sizeof(aff_packed)));
+  SP_HIP(hipMalloc(&c.gen, gen_entries * sizeof(aff_packed)));
+  SP_HIP(hipMemset(c.gen, 0, gen_entries * sizeof(aff_packed)));
+  SP_HIP(hipMalloc(&c.d_plan, sizeof(PedPlan)));
+  SP_HIP(hipMemcpy(c.d_plan, &c.plan, sizeof(PedPlan), hipMemcpyHostToDevice));
+  c.table_bytes = (p.entries + gen_entries) * sizeof(aff_packed);
+  rc = build_windows(c.ped, ped_bits, offs, first, nb, base);
   if (rc != SP_OK) return rc;
-  rc = build_group(c.gen, 1, gen_bits, bases[0], infinity, 0x5350474E54424C45ull, c.wbits, c.nwin);
+  rc = build_gen_table(c.gen, gen_bits, bases[0], 0x5350474E54424C45ull, c.wbits, c.nwin);
   if (rc != SP_OK) return rc;
   c.ready = true;
   return SP_OK;
@@ -203,7 +293,9 @@ int sp_init(int device, int window_bits) {
   if (rc != SP_OK && !g_ctx.ready) {
     if (g_ctx.ped) (void)hipFree(g_ctx.ped);
     if (g_ctx.gen) (void)hipFree(g_ctx.gen);
+    if (g_ctx.d_plan) (void)hipFree(g_ctx.d_plan);
     g_ctx.ped = g_ctx.gen = nullptr;
+    g_ctx.d_plan = nullptr;
   }
   return rc;
 }
@@ -217,7 +309,9 @@ void sp_shutdown(void) {
   sp::release_ecdsa_state();
   if (g_ctx.ped) (void)hipFree(g_ctx.ped);
   if (g_ctx.gen) (void)hipFree(g_ctx.gen);
+  if (g_ctx.d_plan) (void)hipFree(g_ctx.d_plan);
   g_ctx.ped = g_ctx.gen = nullptr;
+  g_ctx.d_plan = nullptr;
   g_ctx.io.release();
   g_ctx.io2.release();
   g_ctx.ready = false;
@@ -231,7 +325,7 @@ const char* sp_last_error(void) {
 }
 
 int sp_is_initialised(void) { return g_ctx.ready ? 1 : 0; }
-int sp_window_bits(void) { return g_ctx.wbits; }
+int sp_window_bits(void) { return g_ctx.plan.log2e; }
 size_t sp_table_bytes(void) { return g_ctx.table_bytes; }
 
 int sp_synchronize(void* stream) {

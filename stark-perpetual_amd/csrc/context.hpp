@@ -15,6 +15,20 @@ struct alignas(64) aff_packed {
   u256 x, y;
 };
 
+// Window plan of the Pedersen tables over the 504-bit string  x (252 bits) || y (252 bits).
+// Window 0 is unsigned: `bits[0]` bits, 2^bits[0] entries.  Every other window is SIGNED: it covers
+// log2e + 1 bits with 2^log2e entries - the top bit of the window is the sign of the whole entry
+// (see context.hip).  Windows may straddle the x | y boundary.
+constexpr int PED_MAX_WINDOWS = 128;
+struct PedPlan {
+  int nwin = 0;
+  int log2e = 0;                       // entries per signed window = 2^log2e  (what sp_window_bits reports)
+  uint16_t start[PED_MAX_WINDOWS];     // first bit of window g in the 504-bit string
+  uint8_t bits[PED_MAX_WINDOWS];       // bits the window consumes
+  uint64_t base[PED_MAX_WINDOWS];      // index of the window's first entry in the table
+  uint64_t entries = 0;                // total
+};
+
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t bytes = 0;
@@ -39,10 +53,12 @@ struct DeviceBuffer {
 struct Context {
   bool ready = false;
   int device = -1;
-  int wbits = 16;        // window width
-  int nwin = 16;         // windows per 252-bit scalar = ceil(252 / wbits)
-  aff_packed* ped = nullptr;   // [2][nwin][1 << wbits]  Pedersen: element, window, value
+  int wbits = 16;        // EC_GEN table: window width
+  int nwin = 16;         // EC_GEN table: windows per 252-bit scalar = ceil(252 / wbits)
+  aff_packed* ped = nullptr;   // Pedersen window tables, laid out by `plan`
   aff_packed* gen = nullptr;   // [nwin][1 << wbits]     fixed-base EC_GEN
+  PedPlan plan;                // host copy
+  PedPlan* d_plan = nullptr;   // device copy the kernels read (uniform loads)
   size_t table_bytes = 0;
   DeviceBuffer io;             // staging for host-pointer entry points
   DeviceBuffer io2;

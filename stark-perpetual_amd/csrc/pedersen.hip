@@ -3,12 +3,13 @@
 // Reference semantics: pedersen_hash(x, y) = x-coordinate of
 //     SHIFT + sum_j x_j C[2+j] + sum_j y_j C[254+j]            (signature.py:300-318)
 // computed there with ~252 affine additions (one modular inversion each).  Here one thread sums
-// the 2*nwin window-table entries selected by the bits of (x, y) in XYZZ coordinates (8M + 2S per
+// the window-table entries selected by the 504 bits of x || y (signed window plan, context.hip:
+// 18 entries with 2^27-entry windows, 23 with the default 2^21) in XYZZ coordinates (8M + 2S per
 // entry, no inversion), and a second kernel turns X/ZZ into the canonical affine x with one
 // shared inversion per K hashes (Montgomery's trick, K up to 32).
 //
 // HBM layout
-//   tables  aff_packed[2][nwin][2^w] : 64-byte entries, one random 64-byte gather per window
+//   tables  aff_packed[entries]      : 64-byte entries, one random 64-byte gather per window
 //   inputs  x[n], y[n]               : 32-byte felts, element strides given in felts
 //   scratch int32[9][n] x 3          : X, ZZ and prefix products, limb-major so that a wave's
 //                                      64 lanes touch 64 consecutive dwords
@@ -47,13 +48,56 @@ __device__ __forceinline__ aff unpack_raw(const raw_aff& t) {
   return r;
 }
 
-// Pops the low `wbits` of s and shifts s right.
-__device__ __forceinline__ uint32_t pop_window(u256& s, int wbits) {
-  const uint32_t v = s.w[0] & ((1u << wbits) - 1u);
+// The 504-bit string x || y the window plan is laid over (context.hpp PedPlan), low bits first.
+struct bits512 {
+  uint32_t w[16];
+};
+__device__ __forceinline__ bits512 concat_xy(const u256& x, const u256& y) {  // x < 2^252
+  bits512 s;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) s.w[i] = (s.w[i] >> wbits) | (s.w[i + 1] << (32 - wbits));
-  s.w[7] >>= wbits;
+  for (int i = 0; i < 7; ++i) s.w[i] = x.w[i];
+  s.w[7] = x.w[7] | (y.w[0] << 28);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s.w[8 + i] = (y.w[i] >> 4) | (y.w[i + 1] << 28);
+  s.w[15] = y.w[7] >> 4;
+  return s;
+}
+// Pops the low `width` (< 32) bits of s and shifts s right.
+__device__ __forceinline__ uint32_t pop_bits(bits512& s, int width) {
+  const uint32_t v = s.w[0] & ((1u << width) - 1u);
+#pragma unroll
+  for (int i = 0; i < 15; ++i) s.w[i] = __builtin_amdgcn_alignbit(s.w[i + 1], s.w[i], (uint32_t)width);
+  s.w[15] >>= width;
   return v;
+}
+// Window g of the plan: window 0 is unsigned (w0 bits); window g >= 1 has log2e + 1 bits whose top
+// bit is the sign of the entry and whose low bits (complemented for a negative entry) are its index.
+struct window_ref {
+  const aff_packed* entry;
+  bool negative;
+};
+__device__ __forceinline__ window_ref window_entry(const aff_packed* __restrict__ ped, int g, uint32_t raw,
+                                                    int w0, int log2e) {
+  window_ref r;
+  if (g == 0) {
+    r.entry = ped + raw;
+    r.negative = false;
+  } else {
+    const uint32_t mask = (1u << log2e) - 1u;
+    r.negative = (raw >> log2e) == 0;
+    const uint32_t idx = r.negative ? (~raw & mask) : (raw & mask);
+    r.entry = ped + ((size_t)1 << w0) + ((size_t)(g - 1) << log2e) + idx;
+  }
+  return r;
+}
+__device__ __forceinline__ int window_width(int g, int w0, int log2e) { return g == 0 ? w0 : log2e + 1; }
+__device__ __forceinline__ int window_start(int g, int w0, int log2e) {
+  return g == 0 ? 0 : w0 + (g - 1) * (log2e + 1);
+}
+__device__ __forceinline__ aff signed_aff(const raw_aff& t, bool negative) {
+  aff q = unpack_raw(t);
+  if (negative) q.y = fe_neg(q.y);
+  return q;
 }
 
 __device__ __forceinline__ void store_limbs(int32_t* base, size_t n, size_t e, const fe& v) {
@@ -86,9 +130,10 @@ __device__ __forceinline__ void operand_pointers(const uint64_t* x, const uint64
 // Kernel A: one hash per thread -> projective (X, ZZ) in scratch.
 __global__ void __launch_bounds__(256, SP_ACC_WAVES)
 ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
-                      size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits, int nwin,
-                      int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, uint8_t* __restrict__ status,
-                      unsigned* __restrict__ flag, const int2* __restrict__ src) {
+                      size_t ystride, size_t n, const aff_packed* __restrict__ ped, int w0, int log2e,
+                      int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
+                      uint8_t* __restrict__ status, unsigned* __restrict__ flag,
+                      const int2* __restrict__ src) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const uint64_t *fx, *fy;
@@ -101,22 +146,31 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sx.w[i] = 0; sy.w[i] = 0; }
   }
-  const size_t per = (size_t)1 << wbits;
+  bits512 str = concat_xy(sx, sy);
   // The first entry initialises the accumulator; entries i+1 and i+2 are in flight (two 64-byte
   // gathers) while entry i is added, which hides the random-HBM latency behind ~3.5e3 instructions of arithmetic.
-  const int total = 2 * nwin;
-  auto next_index = [&](int g) -> const aff_packed* {  // consumes the next window of x, then of y
-    const uint32_t v = (g < nwin) ? pop_window(sx, wbits) : pop_window(sy, wbits);
-    return ped + (size_t)g * per + v;
+  auto next_window = [&](int g) {  // consumes the next window of the string
+    return window_entry(ped, g, pop_bits(str, window_width(g, w0, log2e)), w0, log2e);
   };
-  xyzz acc = xyzz_from_aff(unpack_raw(ld_raw(next_index(0))));
-  raw_aff n1 = ld_raw(next_index(1 < total ? 1 : 0));
+  xyzz acc = xyzz_from_aff(unpack_raw(ld_raw(next_window(0).entry)));  // window 0 is never negative
+  window_ref r1 = next_window(1 < nwin ? 1 : 0);
+  raw_aff n1 = ld_raw(r1.entry);
+  bool neg1 = r1.negative, neg2 = false;
   raw_aff n2 = n1;
-  if (total > 2) n2 = ld_raw(next_index(2));
-  for (int i = 1; i < total; ++i) {
-    const aff q = unpack_raw(n1);
+  if (nwin > 2) {
+    const window_ref r2 = next_window(2);
+    n2 = ld_raw(r2.entry);
+    neg2 = r2.negative;
+  }
+  for (int i = 1; i < nwin; ++i) {
+    const aff q = signed_aff(n1, neg1);
     n1 = n2;
-    if (i + 2 < total) n2 = ld_raw(next_index(i + 2));
+    neg1 = neg2;
+    if (i + 2 < nwin) {
+      const window_ref r = next_window(i + 2);
+      n2 = ld_raw(r.entry);
+      neg2 = r.negative;
+    }
     acc = xyzz_madd(acc, q);
   }
   store_limbs(sX, n, e, acc.X);
@@ -140,39 +194,57 @@ __device__ __forceinline__ fe shfl_xor_fe(const fe& v, int mask) {
   for (int i = 0; i < NL; ++i) r.l[i] = __shfl_xor(v.l[i], mask, 64);
   return r;
 }
-__device__ __forceinline__ uint32_t window_from_memory(const uint64_t* felt, int win, int wbits) {
+// `width` (< 32) bits of a 256-bit operand in memory starting at `bit`; bits beyond 255 read as 0.
+__device__ __forceinline__ uint32_t field_from_memory(const uint64_t* felt, int bit, int width) {
   const uint32_t* w = reinterpret_cast<const uint32_t*>(felt);
-  const int bit = win * wbits, wi = bit >> 5, sh = bit & 31;
+  const int wi = bit >> 5, sh = bit & 31;
   uint64_t two = (uint64_t)w[wi];
   if (wi + 1 < 8) two |= (uint64_t)w[wi + 1] << 32;
-  return (uint32_t)(two >> sh) & ((1u << wbits) - 1u);
+  return (uint32_t)(two >> sh) & ((1u << width) - 1u);
+}
+// Bits [start, start + width) of the string x || y straight from the two operands in memory.
+__device__ __forceinline__ uint32_t window_from_memory(const uint64_t* fx, const uint64_t* fy, int start,
+                                                       int width) {
+  if (start + width <= 252) return field_from_memory(fx, start, width);
+  if (start >= 252) return field_from_memory(fy, start - 252, width);
+  const int lo_n = 252 - start;
+  return field_from_memory(fx, start, lo_n) | (field_from_memory(fy, 0, width - lo_n) << lo_n);
 }
 
-// Partial sums of one lane group: returns the full XYZZ sum on every lane of the group.
+// Partial sums of one lane group: returns the full XYZZ sum on every lane of the group.  Lane `sub`
+// sums a contiguous run of windows (the first nwin % L lanes take one more than the others; the
+// host guarantees at least two per lane).
 template <int LOG_L>
 __device__ __forceinline__ xyzz split_accumulate(const uint64_t* fx, const uint64_t* fy, int sub,
-                                                 const aff_packed* __restrict__ ped, int wbits, int nwin) {
+                                                 const aff_packed* __restrict__ ped, int w0, int log2e,
+                                                 int nwin) {
   constexpr int L = 1 << LOG_L;
-  const int total = 2 * nwin;
-  const int cnt = total / L;  // host guarantees divisibility and cnt >= 2
-  const size_t per = (size_t)1 << wbits;
+  const int cnt_lo = nwin / L, extra = nwin % L;
+  const int cnt = cnt_lo + (sub < extra ? 1 : 0);
+  const int g0 = sub * cnt_lo + (sub < extra ? sub : extra);
   auto entry = [&](int g) {
-    const uint64_t* f = g < nwin ? fx : fy;
-    const int win = g < nwin ? g : g - nwin;
-    return ped + (size_t)g * per + window_from_memory(f, win, wbits);
+    return window_entry(ped, g, window_from_memory(fx, fy, window_start(g, w0, log2e), window_width(g, w0, log2e)),
+                        w0, log2e);
   };
-  const int g0 = sub * cnt;
-  const aff q0 = ld_aff(entry(g0));
-  raw_aff nxt = ld_raw(entry(g0 + 1));
+  const window_ref r0 = entry(g0);
+  const aff q0 = signed_aff(ld_raw(r0.entry), r0.negative);
+  window_ref rn = entry(g0 + 1);
+  raw_aff nxt = ld_raw(rn.entry);
   xyzz acc;
   {
-    const aff q1 = unpack_raw(nxt);
-    if (cnt > 2) nxt = ld_raw(entry(g0 + 2));
+    const aff q1 = signed_aff(nxt, rn.negative);
+    if (cnt > 2) {
+      rn = entry(g0 + 2);
+      nxt = ld_raw(rn.entry);
+    }
     acc = xyzz_mmadd(q0, q1);
   }
   for (int j = 2; j < cnt; ++j) {
-    const aff q = unpack_raw(nxt);
-    if (j + 1 < cnt) nxt = ld_raw(entry(g0 + j + 1));
+    const aff q = signed_aff(nxt, rn.negative);
+    if (j + 1 < cnt) {
+      rn = entry(g0 + j + 1);
+      nxt = ld_raw(rn.entry);
+    }
     acc = xyzz_madd(acc, q);
   }
   // NOT unrolled on purpose: one copy of the 14-multiplication general addition keeps the kernel
@@ -192,7 +264,7 @@ __device__ __forceinline__ xyzz split_accumulate(const uint64_t* fx, const uint6
 template <int LOG_L>
 __global__ void __launch_bounds__(256)
 ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
-                            size_t ystride, size_t n, const aff_packed* __restrict__ ped, int wbits,
+                            size_t ystride, size_t n, const aff_packed* __restrict__ ped, int w0, int log2e,
                             int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
                             uint8_t* __restrict__ status, unsigned* __restrict__ flag,
                             const int2* __restrict__ src) {
@@ -204,7 +276,7 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
   const size_t e = active ? e_raw : n - 1;  // clamp: whole lane groups stay convergent for the shuffles
   const uint64_t *fx, *fy;
   operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
-  const xyzz acc = split_accumulate<LOG_L>(fx, fy, sub, ped, wbits, nwin);
+  const xyzz acc = split_accumulate<LOG_L>(fx, fy, sub, ped, w0, log2e, nwin);
   if (!active || sub != 0) return;
   uint8_t st = SP_HASH_OK;
   if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
@@ -250,8 +322,8 @@ ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int
 // helper in the reference; one thread does its own inversion.
 __global__ void __launch_bounds__(128)
 ped_point_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t n,
-                 const aff_packed* __restrict__ ped, int wbits, int nwin, uint64_t* __restrict__ ox,
-                 uint64_t* __restrict__ oy, uint8_t* __restrict__ status) {
+                 const aff_packed* __restrict__ ped, int w0, int log2e, int nwin,
+                 uint64_t* __restrict__ ox, uint64_t* __restrict__ oy, uint8_t* __restrict__ status) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   u256 sx = ld_u256(x + 4 * e);
@@ -260,11 +332,11 @@ ped_point_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y,
     status[e] = SP_HASH_OUT_OF_RANGE;
     return;
   }
-  const size_t per = (size_t)1 << wbits;
-  xyzz acc = xyzz_from_aff(ld_aff(ped + pop_window(sx, wbits)));
-  for (int i = 1; i < 2 * nwin; ++i) {
-    const uint32_t v = (i < nwin) ? pop_window(sx, wbits) : pop_window(sy, wbits);
-    acc = xyzz_madd(acc, ld_aff(ped + (size_t)i * per + v));
+  bits512 str = concat_xy(sx, sy);
+  xyzz acc = xyzz_from_aff(ld_aff(ped + pop_bits(str, w0)));
+  for (int g = 1; g < nwin; ++g) {
+    const window_ref r = window_entry(ped, g, pop_bits(str, log2e + 1), w0, log2e);
+    acc = xyzz_madd(acc, signed_aff(ld_raw(r.entry), r.negative));
   }
   if (fe_is_zero(acc.ZZ)) {
     status[e] = SP_HASH_UNHASHABLE;
@@ -335,28 +407,30 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
   const unsigned blocksA = (unsigned)((n + 255) / 256);
   const bool prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size();
   if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
-  // lanes per hash: fill ~2 waves per SIMD (131072 lanes) before falling back to one lane per hash
+  // lanes per hash: fill ~2 waves per SIMD (131072 lanes) before falling back to one lane per hash;
+  // every lane needs at least two windows
+  const int w0 = c.plan.bits[0], log2e = c.plan.log2e, nwin = c.plan.nwin;
   int log_l = 0;
   if (g_split_enabled) {
     if (n <= 16384) log_l = 3;
     else if (n <= 32768) log_l = 2;
     else if (n <= 65536) log_l = 1;
-    while (log_l > 0 && ((2 * c.nwin) % (1 << log_l) != 0 || (2 * c.nwin) >> log_l < 2)) --log_l;
+    while (log_l > 0 && nwin < (2 << log_l)) --log_l;
   }
   if (log_l == 0) {
-    hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped,
-                       c.wbits, c.nwin, s.X, s.ZZ, status, flag, src);
+    hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped, w0,
+                       log2e, nwin, s.X, s.ZZ, status, flag, src);
   } else {
     const unsigned blocks = (unsigned)(((n << log_l) + 255) / 256);
     if (log_l == 3)
       hipLaunchKernelGGL(ped_accumulate_split_kernel<3>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
-                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag, src);
+                         c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src);
     else if (log_l == 2)
       hipLaunchKernelGGL(ped_accumulate_split_kernel<2>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
-                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag, src);
+                         c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src);
     else
       hipLaunchKernelGGL(ped_accumulate_split_kernel<1>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
-                         c.ped, c.wbits, c.nwin, s.X, s.ZZ, status, flag, src);
+                         c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src);
   }
   if (prof) {
     (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
@@ -461,7 +535,7 @@ int sp_pedersen_point_batch(const uint64_t* x, const uint64_t* y, uint64_t* ox, 
   SP_HIP(hipMemcpy(dy, y, fb, hipMemcpyHostToDevice));
   SP_HIP(hipMemset(dox, 0, 2 * fb));
   hipLaunchKernelGGL(ped_point_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, 0, dx, dy, n,
-                     c.ped, c.wbits, c.nwin, dox, doy, dst);
+                     c.ped, (int)c.plan.bits[0], c.plan.log2e, c.plan.nwin, dox, doy, dst);
   SP_HIP(hipGetLastError());
   SP_HIP(hipDeviceSynchronize());
   SP_HIP(hipMemcpy(ox, dox, fb, hipMemcpyDeviceToHost));
