@@ -99,8 +99,16 @@ SP_HD fe fe_unpack(const u256& a) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int bit = LB * k, wi = bit >> 5, sh = bit & 31;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // One funnel shift per limb.  Written with the builtin on purpose: the portable 64-bit form
+    // below makes LLVM merge the two adjacent word loads into overlapping 64-bit loads, after which
+    // it can no longer keep the eight words in registers and round-trips them through LDS / scratch.
+    const uint32_t hi = wi + 1 < 8 ? a.w[wi + 1] : 0u;
+    r.l[k] = (int32_t)((sh == 0 ? a.w[wi] : __builtin_amdgcn_alignbit(hi, a.w[wi], (uint32_t)sh)) & LMASK);
+#else
     uint64_t two = (uint64_t)a.w[wi] | ((uint64_t)(wi + 1 < 8 ? a.w[wi + 1] : 0u) << 32);
     r.l[k] = (int32_t)((uint32_t)(two >> sh) & LMASK);
+#endif
   }
   r.l[8] = (int32_t)(a.w[7] >> 8);
   fe_pin(r);

@@ -27,24 +27,25 @@
 
 namespace sp {
 
+// A table entry as loaded (packed 256-bit words), unpacked into limbs only when it is consumed:
+// prefetched entries cost 16 VGPRs instead of 18.
 struct raw_aff {
-  uint4 a, b, c, d;
+  u256 x, y;
 };
 __device__ __forceinline__ raw_aff ld_raw(const aff_packed* e) {
   const uint4* q = reinterpret_cast<const uint4*>(e);
+  const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
   raw_aff r;
-  r.a = q[0]; r.b = q[1]; r.c = q[2]; r.d = q[3];
+  r.x.w[0] = a.x; r.x.w[1] = a.y; r.x.w[2] = a.z; r.x.w[3] = a.w;
+  r.x.w[4] = b.x; r.x.w[5] = b.y; r.x.w[6] = b.z; r.x.w[7] = b.w;
+  r.y.w[0] = c.x; r.y.w[1] = c.y; r.y.w[2] = c.z; r.y.w[3] = c.w;
+  r.y.w[4] = d.x; r.y.w[5] = d.y; r.y.w[6] = d.z; r.y.w[7] = d.w;
   return r;
 }
 __device__ __forceinline__ aff unpack_raw(const raw_aff& t) {
-  u256 x, y;
-  x.w[0] = t.a.x; x.w[1] = t.a.y; x.w[2] = t.a.z; x.w[3] = t.a.w;
-  x.w[4] = t.b.x; x.w[5] = t.b.y; x.w[6] = t.b.z; x.w[7] = t.b.w;
-  y.w[0] = t.c.x; y.w[1] = t.c.y; y.w[2] = t.c.z; y.w[3] = t.c.w;
-  y.w[4] = t.d.x; y.w[5] = t.d.y; y.w[6] = t.d.z; y.w[7] = t.d.w;
   aff r;
-  r.x = fe_unpack(x);
-  r.y = fe_unpack(y);
+  r.x = fe_unpack(t.x);
+  r.y = fe_unpack(t.y);
   return r;
 }
 
@@ -65,9 +66,11 @@ __device__ __forceinline__ bits512 concat_xy(const u256& x, const u256& y) {  //
 // Pops the low `width` (< 32) bits of s and shifts s right.
 __device__ __forceinline__ uint32_t pop_bits(bits512& s, int width) {
   const uint32_t v = s.w[0] & ((1u << width) - 1u);
+  bits512 n;
 #pragma unroll
-  for (int i = 0; i < 15; ++i) s.w[i] = __builtin_amdgcn_alignbit(s.w[i + 1], s.w[i], (uint32_t)width);
-  s.w[15] >>= width;
+  for (int i = 0; i < 15; ++i) n.w[i] = __builtin_amdgcn_alignbit(s.w[i + 1], s.w[i], (uint32_t)width);
+  n.w[15] = s.w[15] >> width;
+  s = n;
   return v;
 }
 // Window g of the plan: window 0 is unsigned (w0 bits); window g >= 1 has log2e + 1 bits whose top
