@@ -264,13 +264,16 @@ __device__ __forceinline__ xyzz split_accumulate(const uint64_t* fx, const uint6
   return acc;
 }
 
-template <int LOG_L>
+// FUSED: lane 0 of each group also inverts ZZ and writes the affine x itself - no scratch planes and
+// no second launch.  Used only while the whole level fits one wave per SIMD (the inversion then costs
+// latency, not throughput): it saves the launch gap and the plane round trip of the small levels.
+template <int LOG_L, bool FUSED>
 __global__ void __launch_bounds__(256)
 ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
                             size_t ystride, size_t n, const aff_packed* __restrict__ ped, int w0, int log2e,
                             int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
                             uint8_t* __restrict__ status, unsigned* __restrict__ flag,
-                            const int2* __restrict__ src) {
+                            const int2* __restrict__ src, uint64_t* __restrict__ out, size_t ostride) {
   constexpr int L = 1 << LOG_L;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t e_raw = gt >> LOG_L;
@@ -280,11 +283,28 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
   const uint64_t *fx, *fy;
   operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
   const xyzz acc = split_accumulate<LOG_L>(fx, fy, sub, ped, w0, log2e, nwin);
-  if (!active || sub != 0) return;
   uint8_t st = SP_HASH_OK;
+  u256 xa_plain;
+  if (FUSED) {
+    // EVERY lane inverts (all lanes of a group hold the same sum after the butterfly): measured
+    // (tools/ubench/inv_lanes.hip) an inversion under a 1-lane-in-8 execution mask takes 4x as long as
+    // the same code with all lanes active - 136 vs 33 us - so the redundant copies are the fast way.
+    fe zz = acc.ZZ;
+    const bool unhashable = fe_is_zero(zz);  // exceptional addition happened (signature.py:313 territory)
+    if (unhashable) {
+      zz = FE_ONE_M;
+      st = SP_HASH_UNHASHABLE;
+    }
+    xa_plain = fe_pack(fe_from_mont(fe_mul(acc.X, fe_inv(zz))));
+  }
+  if (!active || sub != 0) return;
   if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
-  store_limbs(sX, n, e, acc.X);
-  store_limbs(sZZ, n, e, acc.ZZ);
+  if (FUSED) {
+    st_u256(out + 4 * e * ostride, xa_plain);
+  } else {
+    store_limbs(sX, n, e, acc.X);
+    store_limbs(sZZ, n, e, acc.ZZ);
+  }
   if (status) status[e] = st;
   if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
 }
@@ -360,6 +380,7 @@ struct KernelProfile {
 };
 static KernelProfile g_prof;
 static bool g_split_enabled = getenv("STARKPERP_NO_SPLIT") == nullptr;  // A/B switches
+static bool g_fuse_enabled = getenv("STARKPERP_NO_FUSE") == nullptr;
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
   int32_t *X, *ZZ, *Pre;
@@ -414,6 +435,7 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
   // every lane needs at least two windows
   const int w0 = c.plan.bits[0], log2e = c.plan.log2e, nwin = c.plan.nwin;
   int log_l = 0;
+  bool fused = false;
   if (g_split_enabled) {
     if (n <= 16384) log_l = 3;
     else if (n <= 32768) log_l = 2;
@@ -425,26 +447,27 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
                        log2e, nwin, s.X, s.ZZ, status, flag, src);
   } else {
     const unsigned blocks = (unsigned)(((n << log_l) + 255) / 256);
-    if (log_l == 3)
-      hipLaunchKernelGGL(ped_accumulate_split_kernel<3>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
-                         c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src);
-    else if (log_l == 2)
-      hipLaunchKernelGGL(ped_accumulate_split_kernel<2>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
-                         c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src);
-    else
-      hipLaunchKernelGGL(ped_accumulate_split_kernel<1>, dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n,
-                         c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src);
+    fused = g_fuse_enabled && (n << log_l) <= 65536;  // at most one wave per SIMD
+#define SP_LAUNCH_SPLIT(LOGL, FUSEDV)                                                                      \
+  hipLaunchKernelGGL((ped_accumulate_split_kernel<LOGL, FUSEDV>), dim3(blocks), dim3(256), 0, st, x, y, xs, \
+                     ys, n, c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src, out, os)
+    if (log_l == 3) { if (fused) SP_LAUNCH_SPLIT(3, true); else SP_LAUNCH_SPLIT(3, false); }
+    else if (log_l == 2) { if (fused) SP_LAUNCH_SPLIT(2, true); else SP_LAUNCH_SPLIT(2, false); }
+    else { if (fused) SP_LAUNCH_SPLIT(1, true); else SP_LAUNCH_SPLIT(1, false); }
+#undef SP_LAUNCH_SPLIT
   }
   if (prof) {
     (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
     g_prof.units.push_back(n);
     g_prof.used += 2;
   }
-  const size_t T = finish_threads(n);
-  const unsigned tpb = T >= 256 ? 256 : 64;
-  const unsigned blocksB = (unsigned)((T + tpb - 1) / tpb);
-  hipLaunchKernelGGL(ped_finish_kernel, dim3(blocksB), dim3(tpb), 0, st, s.X, s.ZZ, s.Pre, n, T, out,
-                     os, status, flag);
+  if (!fused) {
+    const size_t T = finish_threads(n);
+    const unsigned tpb = T >= 256 ? 256 : 64;
+    const unsigned blocksB = (unsigned)((T + tpb - 1) / tpb);
+    hipLaunchKernelGGL(ped_finish_kernel, dim3(blocksB), dim3(tpb), 0, st, s.X, s.ZZ, s.Pre, n, T, out,
+                       os, status, flag);
+  }
   SP_HIP(hipGetLastError());
   return SP_OK;
 }
