@@ -142,11 +142,19 @@ def ensure_init(device=None, window_bits=None):
 MASK64 = (1 << 64) - 1
 
 
+_INT_TO_BYTES = int.to_bytes
+
+
 def pack_felts(values):
     """ints (0 <= v < 2^256) -> ctypes uint64 array of 4 LE limbs each."""
     n = len(values)
-    raw = b"".join([int(v).to_bytes(32, "little") for v in values])
-    return (ctypes.c_uint64 * (4 * n)).from_buffer_copy(raw) if n else (ctypes.c_uint64 * 0)()
+    if not n:
+        return (ctypes.c_uint64 * 0)()
+    try:  # plain ints: the unbound method skips one call per element
+        raw = b"".join([_INT_TO_BYTES(v, 32, "little") for v in values])
+    except TypeError:  # numpy integers and the like
+        raw = b"".join([int(v).to_bytes(32, "little") for v in values])
+    return (ctypes.c_uint64 * (4 * n)).from_buffer_copy(raw)
 
 
 def unpack_felts(buf, n):

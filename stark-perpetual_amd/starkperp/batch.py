@@ -77,11 +77,9 @@ def pedersen_chains_many(chains):
     depth = len(chains[0])
     assert depth >= 2 and all(len(c) == depth for c in chains)
     flat = []
-    for j in range(depth):  # element j of chain i at index j * width + i
-        for c in chains:
-            v = c[j]
-            assert 0 <= v < FIELD_PRIME
-            flat.append(v)
+    for column in zip(*chains):  # element j of chain i at index j * width + i
+        assert min(column) >= 0 and max(column) < FIELD_PRIME
+        flat.extend(column)
     lib = _lib.ensure_init()
     out, st = new_felts(width), new_bytes(1)
     _lib.check(lib.sp_pedersen_chains(pack_felts(flat), width, depth, out, st), "sp_pedersen_chains")
@@ -202,17 +200,18 @@ def _verify_inputs(msg_hashes, rs, ss, public_keys):
     assert len(rs) == len(ss) == len(public_keys) == n
     xonly = isinstance(public_keys[0], int)
     assert all(isinstance(q, int) == xonly for q in public_keys), "mix of x-only and point keys"
+    p = FIELD_PRIME
     if xonly:
-        qx, qy = [int(q) % FIELD_PRIME for q in public_keys], None
+        qx, qy = [q if 0 <= q < p else q % p for q in public_keys], None
     else:
-        qx = [int(q[0]) % FIELD_PRIME for q in public_keys]
-        qy = pack_felts([int(q[1]) % FIELD_PRIME for q in public_keys])
+        qx = [q[0] if 0 <= q[0] < p else q[0] % p for q in public_keys]
+        qy = pack_felts([q[1] if 0 <= q[1] < p else q[1] % p for q in public_keys])
     # Values that do not fit the 256-bit ABI fail the same pre-asserts as in signature.py:219-227;
     # they are clamped to an out-of-range representative so the kernel reports the right code.
-    clamp = lambda v, bad: v if 0 <= v < 2**256 else bad
-    z = [clamp(int(v), 2**256 - 1) for v in msg_hashes]
-    r = [clamp(int(v), 0) for v in rs]
-    s = [clamp(int(v), 0) for v in ss]
+    top = 2**256
+    z = [v if 0 <= v < top else top - 1 for v in msg_hashes]
+    r = [v if 0 <= v < top else 0 for v in rs]
+    s = [v if 0 <= v < top else 0 for v in ss]
     return pack_felts(z), pack_felts(r), pack_felts(s), pack_felts(qx), qy
 
 
