@@ -255,8 +255,11 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
                     const uint64_t* __restrict__ ps, const uint64_t* __restrict__ pqx,
                     const uint64_t* __restrict__ pqy, uint8_t* __restrict__ result, size_t n,
                     const aff_packed* __restrict__ gen, int wbits, int nwin, int32_t* __restrict__ tab) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+  // Lanes past the end redo the last item instead of idling (identical reads, identical writes): a
+  // wave with <= 8 active lanes runs VALU code ~3.7x slower on this chip (tools/ubench/inv_lanes.hip),
+  // which is what a scalar call (n = 1) would otherwise get.
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) e = n - 1;
   verify_scalars v;
   uint8_t code = verify_prepare(pz, pr, ps, e, v);
   if (code != VERIFY_CONTINUE) { result[e] = code; return; }
@@ -305,8 +308,8 @@ key_rows_kernel(const uint64_t* __restrict__ pqx, const uint64_t* __restrict__ p
                 const uint8_t* __restrict__ has_y, const uint32_t* __restrict__ slot_of, size_t n_new,
                 uint64_t* __restrict__ key_c, uint8_t* __restrict__ key_flag,
                 aff_packed* __restrict__ rows, int32_t* __restrict__ work) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_new) return;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_new) e = n_new - 1;  // redundant copy of the last key, see ecdsa_verify_kernel
   const uint32_t slot = slot_of[e];
   aff base;
   fe c, a_coef;
@@ -363,10 +366,10 @@ __global__ void __launch_bounds__(64)
 key_table_kernel(const aff_packed* __restrict__ rows, const uint32_t* __restrict__ slot_of, size_t n_new,
                  const uint8_t* __restrict__ key_flag, aff_packed* __restrict__ key_tab,
                  int32_t* __restrict__ work) {
-  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t e = gt >> 2;
+  size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int t = (int)(gt & 3);
-  if (e >= n_new) return;
+  if ((gt >> 2) >= n_new) gt = ((n_new - 1) << 2) | (size_t)t;  // redundant copy, see ecdsa_verify_kernel
+  const size_t e = gt >> 2;
   const uint32_t slot = slot_of[e];
   const uint8_t flag = key_flag[slot];
   if (flag != KEY_XONLY && flag != KEY_POINT) return;
@@ -476,8 +479,8 @@ ecdsa_verify_keyed_kernel(const uint64_t* __restrict__ pz, const uint64_t* __res
                           int wbits, int nwin, const aff_packed* __restrict__ key_tab,
                           const uint64_t* __restrict__ key_c, const uint8_t* __restrict__ key_flag,
                           uint32_t n_slots) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) e = n - 1;  // redundant copy of the last item, see ecdsa_verify_kernel
   verify_scalars v;
   const uint8_t code = verify_prepare(pz, pr, ps, e, v);
   if (code != VERIFY_CONTINUE) { result[e] = code; return; }
@@ -502,8 +505,8 @@ __global__ void __launch_bounds__(128)
 public_key_kernel(const uint64_t* __restrict__ pd, uint64_t* __restrict__ ox, uint64_t* __restrict__ oy,
                   uint8_t* __restrict__ status, size_t n, const aff_packed* __restrict__ gen, int wbits,
                   int nwin) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) e = n - 1;  // redundant copy of the last item, see ecdsa_verify_kernel
   const u256 d = ld_u256(pd + 4 * e);
   if (u256_is_zero(d) || !u256_lt(d, U256_N)) {  // signature.py:105
     if (status) status[e] = SP_SIGN_BAD_INPUT;
@@ -524,8 +527,8 @@ ecdsa_sign_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ 
                   const uint64_t* __restrict__ pk, uint64_t* __restrict__ orr, uint64_t* __restrict__ os,
                   uint8_t* __restrict__ status, size_t n, const aff_packed* __restrict__ gen, int wbits,
                   int nwin) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) e = n - 1;  // redundant copy of the last item, see ecdsa_verify_kernel
   const u256 z = ld_u256(pz + 4 * e), d = ld_u256(pd + 4 * e), k = ld_u256(pk + 4 * e);
   if (!u256_lt(z, U256_2P251) || u256_is_zero(d) || !u256_lt(d, U256_N) || u256_is_zero(k) ||
       !u256_lt(k, U256_N)) {

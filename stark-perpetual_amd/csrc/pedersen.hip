@@ -347,8 +347,8 @@ __global__ void __launch_bounds__(128)
 ped_point_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t n,
                  const aff_packed* __restrict__ ped, int w0, int log2e, int nwin,
                  uint64_t* __restrict__ ox, uint64_t* __restrict__ oy, uint8_t* __restrict__ status) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) e = n - 1;  // redundant copy of the last item (few active lanes are slow, see ecdsa.hip)
   u256 sx = ld_u256(x + 4 * e);
   u256 sy = ld_u256(y + 4 * e);
   if (!u256_lt(sx, U256_P) || !u256_lt(sy, U256_P)) {
