@@ -165,7 +165,7 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
     n2 = ld_raw(r2.entry);
     neg2 = r2.negative;
   }
-  for (int i = 1; i < nwin; ++i) {
+  for (int i = 1; i + 1 < nwin; ++i) {
     const aff q = signed_aff(n1, neg1);
     n1 = n2;
     neg1 = neg2;
@@ -176,8 +176,16 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
     }
     acc = xyzz_madd(acc, q);
   }
-  store_limbs(sX, n, e, acc.X);
-  store_limbs(sZZ, n, e, acc.ZZ);
+  if (nwin > 1) {
+    // only x = X / ZZ of the result is wanted: the last addition skips Y3 and ZZZ3 (3 of 10 multiplications)
+    fe X3, ZZ3;
+    xyzz_madd_x_only(acc, signed_aff(n1, neg1), X3, ZZ3);
+    store_limbs(sX, n, e, X3);
+    store_limbs(sZZ, n, e, ZZ3);
+  } else {
+    store_limbs(sX, n, e, acc.X);
+    store_limbs(sZZ, n, e, acc.ZZ);
+  }
   if (st != SP_HASH_OK) {
     if (status) status[e] = st;
     if (flag) atomicOr(flag, (unsigned)st);
@@ -214,7 +222,8 @@ __device__ __forceinline__ uint32_t window_from_memory(const uint64_t* fx, const
   return field_from_memory(fx, start, lo_n) | (field_from_memory(fy, 0, width - lo_n) << lo_n);
 }
 
-// Partial sums of one lane group: returns the full XYZZ sum on every lane of the group.  Lane `sub`
+// Partial sums of one lane group: returns X and ZZ of the full sum on every lane of the group (Y and
+// ZZZ are not computed for the last combine).  Lane `sub`
 // sums a contiguous run of windows (the first nwin % L lanes take one more than the others; the
 // host guarantees at least two per lane).
 template <int LOG_L>
@@ -253,13 +262,25 @@ __device__ __forceinline__ xyzz split_accumulate(const uint64_t* fx, const uint6
   // NOT unrolled on purpose: one copy of the 14-multiplication general addition keeps the kernel
   // inside the instruction cache (a 58 KB straight-line body ran 2x slower than a 25 KB loop).
 #pragma unroll 1
-  for (int r = 0; r < LOG_L; ++r) {
+  for (int r = 0; r + 1 < LOG_L; ++r) {
     xyzz o;
     o.X = shfl_xor_fe(acc.X, 1 << r);
     o.Y = shfl_xor_fe(acc.Y, 1 << r);
     o.ZZ = shfl_xor_fe(acc.ZZ, 1 << r);
     o.ZZZ = shfl_xor_fe(acc.ZZZ, 1 << r);
     acc = xyzz_add(acc, o);
+  }
+  {  // last round: only x = X / ZZ of the total is wanted (Y, ZZZ of the result are left stale)
+    constexpr int r = LOG_L - 1;
+    xyzz o;
+    o.X = shfl_xor_fe(acc.X, 1 << r);
+    o.Y = shfl_xor_fe(acc.Y, 1 << r);
+    o.ZZ = shfl_xor_fe(acc.ZZ, 1 << r);
+    o.ZZZ = shfl_xor_fe(acc.ZZZ, 1 << r);
+    fe X3, ZZ3;
+    xyzz_add_x_only(acc, o, X3, ZZ3);
+    acc.X = X3;
+    acc.ZZ = ZZ3;
   }
   return acc;
 }
