@@ -135,3 +135,39 @@ def test_invalid_keys_and_cache_bookkeeping(batch):
     batch.key_cache_reset()
     assert batch.key_cache_info()[1] == 0
     assert batch.verify_codes([z], [r], [s], [q[0]], key_tables=True) == [1]
+
+
+def test_full_cache_is_reported_and_the_host_entry_point_falls_back():
+    """A 4-slot cache (STARKPERP_KEY_CACHE_SLOTS, read when the cache is first used - hence the
+    subprocess): registering a fifth key fails with SP_ERR_CACHE_FULL and registers nothing, the
+    plain verify entry point quietly uses the ladder, and a reset makes room again."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r]
+from oracle import ref_py as R
+from starkperp import batch, _lib
+keys = [R.private_to_stark_key(100 + i) for i in range(6)]
+sigs = [R.sign(7 + i, 100 + i) for i in range(6)]
+zs = [7 + i for i in range(6)]
+assert len(set(batch.register_keys(keys[:4]))) == 4
+assert batch.key_cache_info() == (4, 4)
+try:
+    batch.register_keys(keys[3:6])
+    raise SystemExit("registration beyond the capacity succeeded")
+except _lib.StarkPerpError as e:
+    assert "rc=-5" in str(e), e
+assert batch.key_cache_info() == (4, 4)              # the failed call left nothing behind
+assert batch.register_keys(keys[:4]) == batch.register_keys(keys[:4])
+# six signatures, two of them from keys that do not fit: the policy must not fail the call
+assert batch.verify_codes(zs, [r for r, _ in sigs], [s for _, s in sigs], keys) == [1] * 6
+batch.key_cache_reset()
+assert batch.verify_codes(zs[4:], [r for r, _ in sigs[4:]], [s for _, s in sigs[4:]], keys[4:], key_tables=True) == [1, 1]
+assert batch.key_cache_info() == (4, 2)
+print("ok")
+''' % (root, os.path.join(root, "stark-perpetual_amd"))
+    env = dict(os.environ, STARKPERP_KEY_CACHE_SLOTS="4")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr[-1500:]
