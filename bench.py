@@ -485,6 +485,26 @@ def extras(torch, lib, _lib, dev, stream):
     del x, y, o
     out["valu_issue"] = valu_issue(n / s, int(lib.sp_window_bits()))
 
+    # BASELINE.json configs[0]: the reference's scalar API, one call at a time through the import overlay
+    # (host-inclusive latency per call; the reference itself: 11 ms / 16 ms / 60 ms per hash / sign / verify)
+    from starkware.crypto.signature import signature as _sig
+    def _latency(fn, reps=20):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps * 1e3
+    _d, _z = 0x3C1E9550E66958296D11B60F8E8E7A7AD990D07FA65D5F7652C4A6C87D4E3CC, 0x1234567
+    _pub = _sig.private_to_stark_key(_d)
+    _r, _s = _sig.sign(_z, _d)
+    out["c1_scalar_call_latency_ms"] = {
+        "pedersen_hash": _latency(lambda: _sig.pedersen_hash(_z, _d)),
+        "private_to_stark_key": _latency(lambda: _sig.private_to_stark_key(_d)),
+        "sign": _latency(lambda: _sig.sign(_z, _d)),
+        "verify_x_only_key": _latency(lambda: _sig.verify(_z, _r, _s, _pub)),
+        "verify_all_true": bool(_sig.verify(_z, _r, _s, _pub)),
+    }
+
     # BASELINE.json configs[2]: 4096 limit orders - message hashes, ECDSA verify, orders-tree update
     import random as _random
     from starkperp import batch as _batch, perpetual_messages as _pm, state as _state

@@ -141,7 +141,9 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
  *   sp_ecdsa_verify_keyed_dev  device pointers; slots[i] names the key of signature i.
  *   sp_ecdsa_verify_batch_keyed  host pointers: registers what is new, then verifies.
  * sp_ecdsa_verify_batch itself switches to the tables when at most 40 % of a batch's signatures bring
- * a key that is not registered yet (STARKPERP_VERIFY_KEYED=0 / 1 forces the ladder / the tables). */
+ * a key the library has never met (not registered, not seen in an earlier call, not repeated inside the
+ * batch) - so a caller verifying one signature at a time reaches the tables on the second sighting of
+ * a key.  STARKPERP_VERIFY_KEYED=0 / 1 forces the ladder / the tables. */
 int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uint32_t* slots);
 int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                               const uint32_t* slots, uint8_t* result, size_t n, void* stream);

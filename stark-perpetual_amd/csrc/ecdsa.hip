@@ -585,6 +585,7 @@ struct KeyCache {
   std::unordered_map<KeyId, uint32_t, KeyIdHash> slot_of;
 };
 static KeyCache g_keys;
+static std::unordered_map<KeyId, uint8_t, KeyIdHash> g_seen_keys;  // unregistered keys met before (verify policy)
 static KeyId key_id(const uint64_t* qx, const uint64_t* qy) {
   KeyId k;
   for (int i = 0; i < 4; ++i) {
@@ -603,6 +604,7 @@ void release_ecdsa_state() {
   g_keys.stage.release();
   g_keys.capacity = g_keys.used = 0;
   g_keys.slot_of.clear();
+  g_seen_keys.clear();
 }
 }
 static inline unsigned nblocks(size_t n, unsigned tpb) { return (unsigned)((n + tpb - 1) / tpb); }
@@ -769,21 +771,30 @@ int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64
 }
 
 // Policy of the host-pointer entry point.  A new key costs about 1.25 ladder verifications to
-// tabulate and a tabulated verification about 0.25, so the tables pay off when fewer than ~60 % of the
-// batch's signatures bring a key that is not cached yet; the threshold used is 40 %.
-// STARKPERP_VERIFY_KEYED=0 / 1 forces the ladder / the tables.
+// tabulate and a tabulated verification about 0.25, so the tables pay off for keys that come back.
+// A key counts as "coming back" when it is registered already, when it was seen in an earlier call
+// (so a caller that verifies one signature at a time reaches the tables on the second sighting of a
+// key), or when it repeats inside the batch; the tables are used when at most 40 % of the batch's
+// signatures bring a key that is none of these.  STARKPERP_VERIFY_KEYED=0 / 1 forces the ladder /
+// the tables.
 static bool use_key_tables(const uint64_t* qx, const uint64_t* qy, size_t n) {
   static const char* mode = getenv("STARKPERP_VERIFY_KEYED");
   if (mode && mode[0] == '0') return false;
   if (key_cache_ready() != SP_OK) return false;
-  std::unordered_map<KeyId, int, KeyIdHash> fresh;
+  std::unordered_map<KeyId, int, KeyIdHash> fresh;  // unregistered keys of this batch -> occurrences
   for (size_t i = 0; i < n; ++i) {
     const KeyId id = key_id(qx + 4 * i, qy ? qy + 4 * i : nullptr);
-    if (g_keys.slot_of.find(id) == g_keys.slot_of.end()) fresh.emplace(id, 0);
+    if (g_keys.slot_of.find(id) == g_keys.slot_of.end()) ++fresh[id];
   }
+  size_t first_sightings = 0;  // signatures whose key is new to the library and unique in the batch
+  for (const auto& kv : fresh) {
+    if (kv.second == 1 && g_seen_keys.find(kv.first) == g_seen_keys.end()) ++first_sightings;
+  }
+  if (g_seen_keys.size() > ((size_t)1 << 20)) g_seen_keys.clear();
+  for (const auto& kv : fresh) g_seen_keys.emplace(kv.first, 1);
   if (g_keys.used + fresh.size() > g_keys.capacity) return false;
   if (mode && mode[0] == '1') return true;
-  return fresh.size() * 5 <= n * 2;
+  return first_sightings * 5 <= n * 2;
 }
 
 // Host-pointer verification through the key tables: registers the keys it has not seen, then runs
