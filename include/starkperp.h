@@ -150,6 +150,9 @@ int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64
 int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                                 const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n);
 int sp_ecdsa_key_cache_info(size_t* capacity, size_t* used);
+/* Empties the cache after waiting for the device.  Every slot index handed out before the reset is
+ * invalid afterwards (it may come to name another key): callers of sp_ecdsa_verify_keyed_dev must
+ * register their keys again. */
 int sp_ecdsa_key_cache_reset(void);
 /* One signing attempt per item with caller-supplied nonce k (host RFC 6979, signature.py:117-134):
  * the body of the loop at signature.py:146-173. */
