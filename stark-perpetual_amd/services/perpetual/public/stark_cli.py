@@ -14,6 +14,9 @@ import traceback
 
 # the CLI never uses torch: stay on the system HIP runtime (keeps stderr empty, see starkperp._lib)
 os.environ.setdefault("STARKPERP_SKIP_TORCH_RUNTIME", "1")
+# one call per process: 2^12-entry windows (39 table entries per hash, 10 MiB, built in milliseconds)
+# instead of the 4.3 GiB default that a long-lived service amortises
+os.environ.setdefault("STARKPERP_WINDOW_BITS", "12")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", "..", ".."))  # .../stark-perpetual_amd
