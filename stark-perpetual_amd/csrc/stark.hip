@@ -41,8 +41,11 @@ __device__ __forceinline__ fe ld_fe_packed(const uint64_t* p) { return fe_unpack
 __global__ void __launch_bounds__(256)
 ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int log_e, int log_t,
                 int log_lo, int nst, int t_first, int dit, const uint64_t* __restrict__ tw, int log_tw,
-                int in_plain, int out_plain, int use_scale, fe scale) {
+                int in_plain, int out_plain, int use_scale, fe scale, size_t in_col_stride,
+                size_t out_col_stride) {
   __shared__ int32_t lds[NL * TILE];
+  in += 4 * in_col_stride * blockIdx.y;    // grid.y = column: independent columns share one launch
+  out += 4 * out_col_stride * blockIdx.y;
   const int E = 1 << log_e;
   const int log_c = log_e - log_t;
   const int C = 1 << log_c;
@@ -117,6 +120,8 @@ lde_pad_kernel(const uint64_t* __restrict__ coef, uint64_t* __restrict__ out, in
                const uint64_t* __restrict__ G) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >> (log_n + log_b)) return;
+  coef += ((size_t)4 << log_n) * blockIdx.y;            // grid.y = column
+  out += ((size_t)4 << (log_n + log_b)) * blockIdx.y;
   u256 v;
 #pragma unroll
   for (int q = 0; q < 8; ++q) v.w[q] = 0;
@@ -560,14 +565,15 @@ static int get_twiddles(int log_n, int inverse, const uint64_t** out, hipStream_
 // Full transform of one column.  dit = 0: natural -> bit-reversed (DIF), dit = 1: bit-reversed ->
 // natural.  in/out may alias.  Montgomery/plain conversion happens in the first/last pass.
 static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse, int dit, int in_plain,
-                      int out_plain, int use_scale, fe scale, hipStream_t st) {
+                      int out_plain, int use_scale, fe scale, hipStream_t st, unsigned ncols = 1,
+                      size_t in_col_stride = 0, size_t out_col_stride = 0) {
   const uint64_t* tw;
   int rc = get_twiddles(log_n, inverse, &tw, st);
   if (rc != SP_OK) return rc;
   if (log_n == 0) {
     // single point: (optionally) scale and convert
-    hipLaunchKernelGGL(ntt_tile_kernel, dim3(1), dim3(256), 0, st, in, out, 0, 0, 0, 0, 0, dit, tw, 1,
-                       in_plain, out_plain, use_scale, scale);
+    hipLaunchKernelGGL(ntt_tile_kernel, dim3(1, ncols), dim3(256), 0, st, in, out, 0, 0, 0, 0, 0, dit, tw, 1,
+                       in_plain, out_plain, use_scale, scale, in_col_stride, out_col_stride);
     SP_HIP(hipGetLastError());
     return SP_OK;
   }
@@ -599,14 +605,16 @@ static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse,
     plan.push_back(loc);
   }
   const uint64_t* src = in;
+  size_t src_stride = in_col_stride;
   for (size_t pi = 0; pi < plan.size(); ++pi) {
     const Pass& ps = plan[pi];
     const bool first = pi == 0, last = pi + 1 == plan.size();
     const unsigned blocks = (unsigned)(((size_t)1 << log_n) >> ps.log_e);
-    hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks), dim3(256), 0, st, src, out, ps.log_e, ps.log_t,
+    hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks, ncols), dim3(256), 0, st, src, out, ps.log_e, ps.log_t,
                        ps.log_lo, ps.nst, ps.t_first, dit, tw, log_n, first ? in_plain : 0,
-                       last ? out_plain : 0, last ? use_scale : 0, scale);
+                       last ? out_plain : 0, last ? use_scale : 0, scale, src_stride, out_col_stride);
     src = out;
+    src_stride = out_col_stride;
   }
   SP_HIP(hipGetLastError());
   return SP_OK;
@@ -663,17 +671,17 @@ int sp_lde_dev(const uint64_t* in, uint64_t* out, unsigned ncols, unsigned log_n
     it = g_tab.coset.emplace(key, buf).first;
   }
   const uint64_t* G = (const uint64_t*)it->second.ptr;
+  // all columns go through each pass together (grid.y = column): 7 launches instead of 7 per column
   DeviceBuffer& work = g_tab.work[st];
-  SP_HIP(work.reserve(n * 32));
+  SP_HIP(work.reserve((size_t)ncols * n * 32));
   uint64_t* coef = (uint64_t*)work.ptr;
-  for (unsigned c = 0; c < ncols; ++c) {
-    const uint64_t* src = in + 4 * (size_t)c * n;
-    uint64_t* dst = out + 4 * (size_t)c * m;
-    int rc = ntt_column(src, coef, (int)log_n, 1, 0, 1, 0, 0, FE_ONE_M, st);  // -> bit-reversed coefficients
+  if (ncols > 65535) { set_error("too many columns"); return SP_ERR_BAD_ARGUMENT; }
+  if (ncols > 0) {
+    int rc = ntt_column(in, coef, (int)log_n, 1, 0, 1, 0, 0, FE_ONE_M, st, ncols, n, n);  // -> bit-reversed coefficients
     if (rc != SP_OK) return rc;
-    hipLaunchKernelGGL(lde_pad_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, coef, dst,
+    hipLaunchKernelGGL(lde_pad_kernel, dim3((unsigned)((m + 255) / 256), ncols), dim3(256), 0, st, coef, out,
                        (int)log_n, (int)log_blowup, G);
-    rc = ntt_column(dst, dst, (int)(log_n + log_blowup), 0, 1, 0, 1, 0, FE_ONE_M, st);
+    rc = ntt_column(out, out, (int)(log_n + log_blowup), 0, 1, 0, 1, 0, FE_ONE_M, st, ncols, m, m);
     if (rc != SP_OK) return rc;
   }
   SP_HIP(hipGetLastError());
