@@ -301,3 +301,20 @@ def test_verify_crafted_scalars_differential(batch):
     got = batch.verify_codes([zs[i] for i in sample], [rs[i] for i in sample], [ss[i] for i in sample],
                              [q[0]] * len(sample))
     assert got == [int(R.verify(zs[i], rs[i], ss[i], q[0])) for i in sample]
+
+
+def test_extra_reference_fixtures(sig, batch):
+    g = load("g8_reference_fixtures_extra.json")
+    for name, c in g["verify"].items():
+        assert sig.verify(h(c["message_hash"]), h(c["r"]), h(c["s"]), h(c["public_key"])) == c["reference_verify"], name
+    names = list(g["sign"])
+    zs = [h(g["sign"][n]["message_hash"]) for n in names]
+    ds = [h(g["sign"][n]["private_key"]) for n in names]
+    for n, z, d in zip(names, zs, ds):
+        assert sig.sign(z, d) == (h(g["sign"][n]["r"]), h(g["sign"][n]["s"])), n
+        assert sig.private_to_stark_key(d) == h(g["sign"][n]["public_key"]), n
+    assert batch.sign_many(zs, ds) == [(h(g["sign"][n]["r"]), h(g["sign"][n]["s"])) for n in names]
+    keys = [h(g["sign"][n]["public_key"]) for n in names]
+    sigs = [(h(g["sign"][n]["r"]), h(g["sign"][n]["s"])) for n in names]
+    for tables in (False, True):
+        assert batch.verify_codes(zs, [r for r, _ in sigs], [s for _, s in sigs], keys, key_tables=tables) == [1] * len(names)

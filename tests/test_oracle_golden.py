@@ -176,3 +176,14 @@ def test_g6_merkle_small():
     for pos, exp in list(zip(poss, g["position_hashes_seed3"]))[::8]:
         assert R.position_hash(*pos) == h(exp)
     assert R.position_hash(0, 0, []) == h(g["empty_position_leaf"])
+
+
+def test_extra_reference_fixtures():
+    """g8: every signature fixture of signature_test_data.json with the reference's verdict, and
+    the reference's deterministic signatures for every (message_hash, private_key) it holds."""
+    g = load("g8_reference_fixtures_extra.json")
+    for name, c in g["verify"].items():
+        assert R.verify(h(c["message_hash"]), h(c["r"]), h(c["s"]), h(c["public_key"])) == c["reference_verify"], name
+    for name, c in g["sign"].items():
+        assert R.sign(h(c["message_hash"]), h(c["private_key"])) == (h(c["r"]), h(c["s"])), name
+        assert R.private_to_stark_key(h(c["private_key"])) == h(c["public_key"]), name
