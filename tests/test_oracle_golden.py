@@ -187,3 +187,19 @@ def test_extra_reference_fixtures():
     for name, c in g["sign"].items():
         assert R.sign(h(c["message_hash"]), h(c["private_key"])) == (h(c["r"]), h(c["s"])), name
         assert R.private_to_stark_key(h(c["private_key"])) == h(c["public_key"]), name
+
+
+def test_grind_key_published_vectors():
+    """The reference's own key-grinding known answers (key_derivation.spec.js:45-52 "Key grinding" and
+    :63-70, where the seed is the r half of an Ethereum signature); signature.py:263-288 is the
+    Python twin of that routine."""
+    from starkperp import signature as S
+    kats = {
+        0x86F3E7293141F20A8BAFF320E8EE4ACCB9D4A4BF2B4D295E8CEE784DB46E0519:
+            0x5C8C8683596C732541A59E03007B2D30DBBBB873556FE65B5FB63C16688F941,
+        0x21FBF0696D5E0AA2EF41A2B4FFB623BCAF070461D61CF7251C74161F82FEC3A4:
+            0x766F11E90CD7C7B43085B56DA35C781F8C067AC0D578EABDCEEBC4886435BDA,
+    }
+    for seed, want in kats.items():
+        assert R.grind_key(seed, R.EC_ORDER) == want
+        assert S.grind_key(seed, S.EC_ORDER) == want
