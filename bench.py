@@ -565,6 +565,12 @@ def extras(torch, lib, _lib, dev, stream):
         dz.data_ptr(), dr.data_ptr(), dsig.data_ptr(), dslots.data_ptr(), res.data_ptr(), nv, stream), "keyed"), 3)
     out["ecdsa_verifies_per_sec_key_tables_2p16"] = nv / kv_t
     out["ecdsa_verify_key_tables_all_true"] = bool(int((res == 1).sum()) == stv.count(0))
+    # full deterministic signing (RFC 6979 nonce + attempt on the device), Python ints in and out
+    t0 = time.perf_counter()
+    signed = _batch.sign_many(zv, dsk)
+    out["ecdsa_signs_per_sec_2p16_host_inclusive"] = nv / (time.perf_counter() - t0)
+    out["ecdsa_sign_sample_matches_host_nonces"] = bool(
+        signed[:64] == _batch._sign_many_host_nonces(zv[:64], dsk[:64], [None] * 64))
 
     # BASELINE.json configs[3]: 2^20-row trace -> LDE -> commit -> AIR -> commit -> FRI (+commits)
     import random

@@ -158,6 +158,13 @@ int sp_ecdsa_key_cache_reset(void);
  * the body of the loop at signature.py:146-173. */
 int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r,
                         uint64_t* s, uint8_t* status, size_t n);
+/* The whole of sign(msg_hash, priv_key, seed) signature.py:137-173 on the device: the RFC 6979 nonce
+ * (HMAC-SHA256, python-ecdsa conventions, signature.py:117-134), the attempt, and the reference's
+ * retry with the next seed.  seeds: one uint64 per item (0 = no seed; NULL = none for every item).
+ * status SP_SIGN_RETRY after 8 rejected nonces in a row (a 2^-55 event each) leaves the item to the
+ * caller. */
+int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
+                                uint64_t* s, uint8_t* status, size_t n);
 /* private_key_to_ec_point_on_stark_curve signature.py:104-106: (qx, qy) = d * EC_GEN.
  * status: 0 ok, 2 when d is not in (0, EC_ORDER). */
 int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* status, size_t n);

@@ -29,6 +29,7 @@
 
 #include "context.hpp"
 #include "curve_consts.hpp"
+#include "rfc6979.hpp"
 
 namespace sp {
 
@@ -521,25 +522,18 @@ public_key_kernel(const uint64_t* __restrict__ pd, uint64_t* __restrict__ ox, ui
   if (status) status[e] = SP_SIGN_OK;
 }
 
-// One pass of the loop body of sign() (signature.py:146-173) with a caller-supplied k.
-__global__ void __launch_bounds__(128)
-ecdsa_sign_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pd,
-                  const uint64_t* __restrict__ pk, uint64_t* __restrict__ orr, uint64_t* __restrict__ os,
-                  uint8_t* __restrict__ status, size_t n, const aff_packed* __restrict__ gen, int wbits,
-                  int nwin) {
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) e = n - 1;  // redundant copy of the last item, see ecdsa_verify_kernel
-  const u256 z = ld_u256(pz + 4 * e), d = ld_u256(pd + 4 * e), k = ld_u256(pk + 4 * e);
+// One pass of the loop body of sign() (signature.py:146-173) for a given nonce k.
+__device__ __forceinline__ uint8_t sign_attempt(const u256& z, const u256& d, const u256& k,
+                                                const aff_packed* __restrict__ gen, int wbits, int nwin,
+                                                u256& r_out, u256& s_out) {
   if (!u256_lt(z, U256_2P251) || u256_is_zero(d) || !u256_lt(d, U256_N) || u256_is_zero(k) ||
-      !u256_lt(k, U256_N)) {
-    status[e] = SP_SIGN_BAD_INPUT;
-    return;
-  }
+      !u256_lt(k, U256_N))
+    return SP_SIGN_BAD_INPUT;
   const xyzz A = gen_mul(k, gen, wbits, nwin);
   const fe izzz = fe_inv(A.ZZZ);
   const fe x = fe_mul(A.X, fe_sqr(fe_mul(A.ZZ, izzz)));
   const u256 r = fe_pack(fe_from_mont(x));
-  if (u256_is_zero(r) || !u256_lt(r, U256_2P251)) { status[e] = SP_SIGN_RETRY; return; }  // :158-161
+  if (u256_is_zero(r) || !u256_lt(r, U256_2P251)) return SP_SIGN_RETRY;  // :158-161
   // t = z + r d mod N
   const fe k_m = montn_of(k);
   const fe one_c = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
@@ -548,15 +542,62 @@ ecdsa_sign_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ 
   cols_mac(acc, montn_of(r), montn_of(d));
   cols_mac(acc, montn_of(z), fn_to_mont(one_c));
   const fe t_m = fn_reduce(acc);  // Montgomery form of z + r d
-  if (limbs_is_zero(fn_from_mont(t_m))) { status[e] = SP_SIGN_RETRY; return; }  // :163-165
+  if (limbs_is_zero(fn_from_mont(t_m))) return SP_SIGN_RETRY;  // :163-165
   const fe I = fn_inv(fn_mul(k_m, t_m));
   const fe w_m = fn_mul(fn_sqr(k_m), I);  // k / t
   const u256 w = fe_pack(fn_from_mont(w_m));
-  if (u256_is_zero(w) || !u256_lt(w, U256_2P251)) { status[e] = SP_SIGN_RETRY; return; }  // :167-170
+  if (u256_is_zero(w) || !u256_lt(w, U256_2P251)) return SP_SIGN_RETRY;  // :167-170
   const fe s_m = fn_mul(fn_sqr(t_m), I);  // t / k = w^-1
-  st_u256(orr + 4 * e, r);
-  st_u256(os + 4 * e, fe_pack(fn_from_mont(s_m)));
-  status[e] = SP_SIGN_OK;
+  r_out = r;
+  s_out = fe_pack(fn_from_mont(s_m));
+  return SP_SIGN_OK;
+}
+
+__global__ void __launch_bounds__(128)
+ecdsa_sign_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pd,
+                  const uint64_t* __restrict__ pk, uint64_t* __restrict__ orr, uint64_t* __restrict__ os,
+                  uint8_t* __restrict__ status, size_t n, const aff_packed* __restrict__ gen, int wbits,
+                  int nwin) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) e = n - 1;  // redundant copy of the last item, see ecdsa_verify_kernel
+  u256 r, s;
+  const uint8_t st = sign_attempt(ld_u256(pz + 4 * e), ld_u256(pd + 4 * e), ld_u256(pk + 4 * e), gen, wbits,
+                                  nwin, r, s);
+  if (st == SP_SIGN_OK) {
+    st_u256(orr + 4 * e, r);
+    st_u256(os + 4 * e, s);
+  }
+  status[e] = st;
+}
+
+// The whole of sign() (signature.py:137-173): RFC 6979 nonce on the device (rfc6979.hpp), the
+// attempt, and - should the nonce be rejected, which takes a 2^-55 event - the reference's retry
+// with the next seed (None -> 1 -> 2 ...; a seed of 0 and "no seed" give the same entropy and the
+// same successor, so 0 stands for None).  After 8 rejected nonces the item is left to the caller.
+__global__ void __launch_bounds__(128)
+ecdsa_sign_rfc6979_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pd,
+                          const uint64_t* __restrict__ pseed, uint64_t* __restrict__ orr,
+                          uint64_t* __restrict__ os, uint8_t* __restrict__ status, size_t n,
+                          const aff_packed* __restrict__ gen, int wbits, int nwin) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) e = n - 1;  // redundant copy of the last item, see ecdsa_verify_kernel
+  const u256 z = ld_u256(pz + 4 * e), d = ld_u256(pd + 4 * e);
+  uint64_t seed = pseed ? pseed[e] : 0;
+  uint8_t st = SP_SIGN_BAD_INPUT;
+  if (u256_lt(z, U256_2P251) && !u256_is_zero(d) && u256_lt(d, U256_N)) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      const u256 k = rfc6979_nonce(z, d, seed);
+      u256 r, s;
+      st = sign_attempt(z, d, k, gen, wbits, nwin, r, s);
+      if (st == SP_SIGN_OK) {
+        st_u256(orr + 4 * e, r);
+        st_u256(os + 4 * e, s);
+      }
+      if (st != SP_SIGN_RETRY) break;
+      ++seed;
+    }
+  }
+  status[e] = st;
 }
 
 }  // namespace sp
@@ -858,6 +899,34 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
   SP_HIP(hipMemset(dr, 0, 2 * fb));
   hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(n, 128)), dim3(128), 0, 0, dev[0], dev[1], dev[2],
                      dr, ds, dst, n, c.gen, c.wbits, c.nwin);
+  SP_HIP(hipGetLastError());
+  SP_HIP(hipDeviceSynchronize());
+  SP_HIP(hipMemcpy(r, dr, fb, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpy(s, ds, fb, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
+  return SP_OK;
+}
+
+int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
+                                uint64_t* s, uint8_t* status, size_t n) {
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  Context& c = ctx();
+  ctx_lock lk(c.mu);
+  const uint64_t* host[2] = {z, d};
+  uint64_t* dev[2];
+  char* extra;
+  const size_t fb = n * 32;
+  int rc = stage_in(host, 2, n, dev, 2 * fb + n * 8 + n + 64, &extra);
+  if (rc != SP_OK) return rc;
+  uint64_t* dr = (uint64_t*)extra;
+  uint64_t* ds = (uint64_t*)(extra + fb);
+  uint64_t* dseed = (uint64_t*)(extra + 2 * fb);
+  uint8_t* dst = (uint8_t*)(extra + 2 * fb + n * 8);
+  SP_HIP(hipMemset(dr, 0, 2 * fb));
+  if (seeds) SP_HIP(hipMemcpy(dseed, seeds, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n, 128)), dim3(128), 0, 0, dev[0], dev[1],
+                     seeds ? dseed : nullptr, dr, ds, dst, n, c.gen, c.wbits, c.nwin);
   SP_HIP(hipGetLastError());
   SP_HIP(hipDeviceSynchronize());
   SP_HIP(hipMemcpy(r, dr, fb, hipMemcpyDeviceToHost));

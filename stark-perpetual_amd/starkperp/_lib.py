@@ -66,6 +66,7 @@ _SIGNATURES = {
     "sp_ecdsa_key_cache_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "sp_ecdsa_key_cache_reset": (ctypes.c_int, []),
     "sp_ecdsa_sign_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
+    "sp_ecdsa_sign_rfc6979_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
     "sp_public_key_batch": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t]),
 }
 

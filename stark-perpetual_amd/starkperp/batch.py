@@ -324,15 +324,49 @@ def sign_attempt_many(msg_hashes, priv_keys, ks):
 
 
 def sign_many(msg_hashes, priv_keys, seeds=None):
-    """[sign(z, d, seed) ...] (signature.py:137-173): RFC 6979 nonces on the host, k*G and the
-    mod-N finish on the GPU, rejected nonces retried with the next seed like the reference."""
-    from .signature import generate_k_rfc6979  # late import (signature imports batch)
-
+    """[sign(z, d, seed) ...] (signature.py:137-173) in one launch: RFC 6979 nonce, k*G, the mod-N
+    finish and the reference's retry rule all run on the GPU (sp_ecdsa_sign_rfc6979_batch).  Items
+    the device hands back (a seed that does not fit 64 bits, or eight rejected nonces in a row)
+    go through the host nonce generator instead, attempt by attempt."""
     n = len(msg_hashes)
     assert len(priv_keys) == n
     seeds = [None] * n if seeds is None else list(seeds)
     for z in msg_hashes:
         assert 0 <= z < _TWO251, "Message not signable."
+    if n == 0:
+        return []
+    out = [None] * n
+    on_device = [i for i in range(n) if seeds[i] is None or 0 <= seeds[i] < 2**64]
+    left = [i for i in range(n) if not (seeds[i] is None or 0 <= seeds[i] < 2**64)]
+    if on_device:
+        m = len(on_device)
+        lib = _lib.ensure_init()
+        r, s, st = new_felts(m), new_felts(m), new_bytes(m)
+        seed_arr = (ctypes.c_uint64 * m)(*[seeds[i] or 0 for i in on_device])
+        _lib.check(lib.sp_ecdsa_sign_rfc6979_batch(pack_felts([msg_hashes[i] for i in on_device]),
+                                                   pack_felts([priv_keys[i] % 2**256 for i in on_device]),
+                                                   seed_arr, r, s, st, m), "sp_ecdsa_sign_rfc6979_batch")
+        rs, ss = unpack_felts(r, m), unpack_felts(s, m)
+        for j, i in enumerate(on_device):
+            if st[j] == SIGN_OK:
+                out[i] = (rs[j], ss[j])
+            elif st[j] == SIGN_RETRY:
+                left.append(i)
+            else:
+                raise AssertionError("sign: input out of range")
+    if left:
+        for i, sig in zip(left, _sign_many_host_nonces([msg_hashes[i] for i in left], [priv_keys[i] for i in left],
+                                                       [seeds[i] for i in left])):
+            out[i] = sig
+    return out
+
+
+def _sign_many_host_nonces(msg_hashes, priv_keys, seeds):
+    """The same loop with RFC 6979 on the host (starkperp/rfc6979.py) and one GPU attempt per nonce."""
+    from .signature import generate_k_rfc6979  # late import (signature imports batch)
+
+    n = len(msg_hashes)
+    seeds = list(seeds)
     out = [None] * n
     todo = list(range(n))
     while todo:

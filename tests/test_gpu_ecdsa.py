@@ -318,3 +318,25 @@ def test_extra_reference_fixtures(sig, batch):
     sigs = [(h(g["sign"][n]["r"]), h(g["sign"][n]["s"])) for n in names]
     for tables in (False, True):
         assert batch.verify_codes(zs, [r for r, _ in sigs], [s for _, s in sigs], keys, key_tables=tables) == [1] * len(names)
+
+
+def test_device_rfc6979_matches_host_nonces(batch):
+    """sign_many's device path (RFC 6979 + attempt + retry rule in one kernel) against the host nonce
+    generator (pinned by g3 and the reference's own signatures) on 1024 random items, seeds of every
+    byte length up to 8, small and nibble-short messages, and seeds that only the host path takes."""
+    import random
+    rng = random.Random(6979)
+    zs, ds, seeds = [], [], []
+    for i in range(1024):
+        bits = rng.choice([1, 8, 200, 244, 247, 248, 249, 250, 251, 251, 251])
+        zs.append(rng.randrange(2 ** (bits - 1), 2**bits) if bits > 1 else rng.randrange(2))
+        ds.append(rng.randrange(1, N))
+        seeds.append(rng.choice([None, 0, 1, 2, 255, 256, 65535, 65536, 2**24, 2**32 - 1, 2**32, 2**40 + 7,
+                                 2**56 - 1, 2**63, 2**64 - 1, rng.randrange(2**64)]))
+    got = batch.sign_many(zs, ds, seeds)
+    assert got == batch._sign_many_host_nonces(zs, ds, seeds)
+    for i in range(0, 1024, 128):
+        assert got[i] == R.sign(zs[i], ds[i], seeds[i])
+    big = [2**64, 2**64 + 1, 2**200 + 3]
+    assert batch.sign_many(zs[:3], ds[:3], big) == [R.sign(z, d, s) for z, d, s in zip(zs[:3], ds[:3], big)]
+    assert batch.sign_many([], []) == []

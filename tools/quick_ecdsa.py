@@ -41,3 +41,10 @@ for label, keyset in (("x-only", [p[0] for p in pubs]), ("point", pubs)):
         _lib.check(lib.sp_ecdsa_verify_keyed_dev(dz.data_ptr(), dr.data_ptr(), dss.data_ptr(), dslots.data_ptr(), res.data_ptr(), n, s), "keyed")
         torch.cuda.synchronize(); t1 = time.time()
     print("verify keyed %s: %.3f ms -> %.3e verifies/s (true=%d)" % (label, (t1 - t0) * 1e3, n / (t1 - t0), int((res == 1).sum())))
+
+# full signing (RFC 6979 nonce + attempt on the device) vs the host-nonce path on a sample
+t0 = time.time(); sigs = batch.sign_many(zs, ds); t1 = time.time()
+print("sign_many (device RFC 6979): %d in %.1f ms host-inclusive -> %.3e signatures/s" % (n, (t1 - t0) * 1e3, n / (t1 - t0)))
+m = min(n, 2048)
+t0 = time.time(); ref = batch._sign_many_host_nonces(zs[:m], ds[:m], [None] * m); t1 = time.time()
+print("host nonces: %d in %.1f ms -> %.3e signatures/s; equal=%s" % (m, (t1 - t0) * 1e3, m / (t1 - t0), ref == sigs[:m]))
