@@ -118,8 +118,8 @@ def generate_k_rfc6979(msg_hash: int, priv_key: int, seed: Optional[int] = None)
 
 
 def sign(msg_hash: int, priv_key: int, seed: Optional[int] = None) -> ECSignature:
-    """:137-173.  The nonce comes from the host (RFC 6979); k * EC_GEN and the mod-N finish run on
-    the GPU; a rejected nonce (:158-170) is retried with the next seed."""
+    """:137-173.  RFC 6979 nonce, k * EC_GEN, the mod-N finish and the retry of a rejected nonce
+    (:158-170) with the next seed all run on the GPU (sp_ecdsa_sign_rfc6979_batch)."""
     assert 0 <= msg_hash < 2**N_ELEMENT_BITS_ECDSA, "Message not signable."
     return batch.sign_many([msg_hash], [priv_key], [seed])[0]
 
