@@ -117,27 +117,42 @@ __device__ __forceinline__ hmac_key hmac_prepare(const uint32_t* key /* 8 BE wor
   sha256_compress(k.outer, blk);
   return k;
 }
+// One-block tail: `words` (8 big-endian words) plus, optionally, one more byte, hashed on top of a
+// midstate that has absorbed 64 bytes already.
+__device__ __forceinline__ void sha256_tail_block(const sha256_state& mid, const uint32_t* words, int extra_byte,
+                                                  uint32_t* digest) {
+  uint32_t blk[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) blk[i] = words[i];
+  blk[8] = extra_byte < 0 ? 0x80000000u : (((uint32_t)extra_byte << 24) | 0x00800000u);
+#pragma unroll
+  for (int i = 9; i < 15; ++i) blk[i] = 0;
+  blk[15] = extra_byte < 0 ? (64u + 32u) * 8u : (64u + 33u) * 8u;
+  sha256_state st = mid;
+  sha256_compress(st, blk);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) digest[i] = st.h[i];
+}
+
 // out = HMAC(key, V || [sep || d || h1 || entropy])   (sep < 0: V only)
 __device__ __forceinline__ void hmac_v(const hmac_key& key, const uint32_t* v, int sep, const uint32_t* d_be,
                                        const uint32_t* h1_be, uint64_t seed, bool with_material, uint32_t* out) {
-  sha256_stream s;
-  sha256_begin(s, key.inner, 64);
-  sha256_put_words(s, v, 8);
-  if (sep >= 0) {
-    sha256_put(s, (uint32_t)sep);
-    if (with_material) {
-      sha256_put_words(s, d_be, 8);
-      sha256_put_words(s, h1_be, 8);
-      int nbytes = 0;
-      for (uint64_t t = seed; t != 0; t >>= 8) ++nbytes;
-      for (int i = nbytes - 1; i >= 0; --i) sha256_put(s, (uint32_t)((seed >> (8 * i)) & 0xff));
-    }
-  }
   uint32_t inner[8];
-  sha256_end(s, inner);
-  sha256_begin(s, key.outer, 64);
-  sha256_put_words(s, inner, 8);
-  sha256_end(s, out);
+  if (sep >= 0 && with_material) {  // the two long messages: byte stream
+    sha256_stream s;
+    sha256_begin(s, key.inner, 64);
+    sha256_put_words(s, v, 8);
+    sha256_put(s, (uint32_t)sep);
+    sha256_put_words(s, d_be, 8);
+    sha256_put_words(s, h1_be, 8);
+    int nbytes = 0;
+    for (uint64_t t = seed; t != 0; t >>= 8) ++nbytes;
+    for (int i = nbytes - 1; i >= 0; --i) sha256_put(s, (uint32_t)((seed >> (8 * i)) & 0xff));
+    sha256_end(s, inner);
+  } else {  // V, or V || sep: a single block with a fixed layout
+    sha256_tail_block(key.inner, v, sep, inner);
+  }
+  sha256_tail_block(key.outer, inner, -1, out);
 }
 
 __device__ __forceinline__ void u256_to_be_words(const u256& a, uint32_t* be) {
