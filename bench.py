@@ -387,32 +387,45 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
     betas = [rng.randrange(P) for _ in range(log_lde - 6)]
     trace = stark.pedersen_trace(xs, ys)  # witness generation is input preparation
     per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
-    stream = torch.cuda.current_stream().cuda_stream
     n_roots = 2 + (log_lde - 7)  # trace, composition, every FRI layer above 64 points
-    roots_dev = torch.zeros((n_roots, 4), dtype=torch.int64, device=dev)
-    gathered = torch.zeros((max(world, 1) * n_roots, 4), dtype=torch.int64, device=dev)
-    tops = torch.zeros((n_roots, 2 * max(world, 1) - 1, 4), dtype=torch.int64, device=dev)
+    # Independent jobs alternate over the streams: the latency-bound tree tops of one job overlap
+    # the throughput-bound row hashing of the next (inside one job every phase depends on the last).
+    n_streams = max(1, args.streams)
+    slots = []
+    for si in range(n_streams):
+        slots.append({
+            "stream": torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream(device=dev),
+            "roots": torch.zeros((n_roots, 4), dtype=torch.int64, device=dev),
+            "gathered": torch.zeros((max(world, 1) * n_roots, 4), dtype=torch.int64, device=dev),
+            "tops": torch.zeros((n_roots, 2 * max(world, 1) - 1, 4), dtype=torch.int64, device=dev),
+        })
+    job_counter = [0]
 
     def step():
-        k = 0
-        t_lde = stark.lde(trace)
-        roots_dev[k] = stark.commit_rows(t_lde)[-1]; k += 1
-        comp = stark.air_eval(t_lde, per, 512 * m, alphas)
-        roots_dev[k] = stark.commit_rows(comp.unsqueeze(0))[-1]; k += 1
-        layer, sh, j = comp, stark.FIELD_GEN, 0
-        while layer.shape[0] > 64:
-            layer = stark.fri_fold(layer, betas[j], sh)
-            sh = sh * sh % P
-            j += 1
-            if layer.shape[0] > 64:
-                roots_dev[k] = stark.commit_rows(layer.unsqueeze(0))[-1]; k += 1
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, roots_dev)
-            g = gathered.reshape(world, n_roots, 4)
-            height = world.bit_length() - 1
-            for c in range(n_roots):
-                tops[c, :world] = g[:, c]
-                _lib.check(lib.sp_merkle_build_dev(tops[c].data_ptr(), height, None, stream), "combine")
+        sl = slots[job_counter[0] % n_streams]
+        job_counter[0] += 1
+        with torch.cuda.stream(sl["stream"]):
+            roots_dev, gathered, tops = sl["roots"], sl["gathered"], sl["tops"]
+            k = 0
+            t_lde = stark.lde(trace)
+            roots_dev[k] = stark.commit_rows(t_lde)[-1]; k += 1
+            comp = stark.air_eval(t_lde, per, 512 * m, alphas)
+            roots_dev[k] = stark.commit_rows(comp.unsqueeze(0))[-1]; k += 1
+            layer, sh, j = comp, stark.FIELD_GEN, 0
+            while layer.shape[0] > 64:
+                layer = stark.fri_fold(layer, betas[j], sh)
+                sh = sh * sh % P
+                j += 1
+                if layer.shape[0] > 64:
+                    roots_dev[k] = stark.commit_rows(layer.unsqueeze(0))[-1]; k += 1
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, roots_dev)
+                g = gathered.reshape(world, n_roots, 4)
+                height = world.bit_length() - 1
+                for c in range(n_roots):
+                    tops[c, :world] = g[:, c]
+                    _lib.check(lib.sp_merkle_build_dev(tops[c].data_ptr(), height, None,
+                                                       sl["stream"].cuda_stream), "combine")
 
     def fence():
         torch.cuda.synchronize()
@@ -454,7 +467,7 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
                                    "%d FRI folds with %d layer commits (BASELINE.json configs[3] at 2^20; N GPUs "
                                    "= configs[4] as N disjoint row ranges; --log-rows 24 = configs[4] on one "
                                    "GPU)" % (args.log_rows, log_lde - 6, log_lde - 7),
-                       "rows_per_gpu": 512 * m, "pedersen_hashes_per_job": hashes,
+                       "rows_per_gpu": 512 * m, "pedersen_hashes_per_job": hashes, "streams": n_streams,
                        "combine": "none" if world == 1 else "all_gather of 17 roots per rank + top hashes"},
             "roofline": {
                 "kernel": "ped_accumulate_kernel / ped_accumulate_split_kernel<L> (commit trees and row chains)",
@@ -621,6 +634,20 @@ def extras(torch, lib, _lib, dev, stream):
     s = timed(job, 2)
     out["air_fri_commit_seconds_2p20_rows"] = s
     out["air_fri_commits_per_sec"] = 1.0 / s
+    # independent jobs alternating over two streams (what `--workload airfri` times): the
+    # latency-bound tree tops of one job overlap the row hashing of the next
+    side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+
+    def pipelined(njobs):
+        for i in range(njobs):
+            with torch.cuda.stream(side[i % 2]):
+                job()
+        torch.cuda.synchronize()
+
+    pipelined(2)
+    t0 = time.perf_counter()
+    pipelined(8)
+    out["air_fri_commits_per_sec_jobs_on_two_streams"] = 8 / (time.perf_counter() - t0)
 
     def phase(fn):
         return timed(fn, 2)
