@@ -153,8 +153,9 @@ def main():
                          "(sp_merkle_forest_dev: one launch pair per level serves all of them; the upper "
                          "levels of a single rebuild are latency-bound and leave most of the chip idle); "
                          "1 = strictly one tree per call")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the lockstep calls are issued on round-robin")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the lockstep calls / independent jobs are issued on round-robin "
+                         "(0 = 2 for the merkle workload, 3 for airfri)")
     ap.add_argument("--workload", choices=["merkle", "airfri"], default="merkle",
                     help="merkle = BASELINE.json configs[1] (default, the headline line); airfri = one "
                          "2^20-row AIR+FRI commit job per GPU per step (configs[3]; with N GPUs the "
@@ -214,7 +215,7 @@ def main():
     if args.workload == "airfri":
         return run_airfri(args, torch, dist, lib, _lib, dev, rank, world)
     n_leaves = 1 << HEIGHT
-    n_streams = max(1, args.streams)
+    n_streams = args.streams if args.streams > 0 else 2
     B = max(1, min(1024, int(args.trees_per_call)))  # independent rebuilds advanced in lockstep per call
 
     def forest_felts(nb):
@@ -390,7 +391,7 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
     n_roots = 2 + (log_lde - 7)  # trace, composition, every FRI layer above 64 points
     # Independent jobs alternate over the streams: the latency-bound tree tops of one job overlap
     # the throughput-bound row hashing of the next (inside one job every phase depends on the last).
-    n_streams = max(1, args.streams)
+    n_streams = args.streams if args.streams > 0 else 3
     slots = []
     for si in range(n_streams):
         slots.append({
