@@ -72,3 +72,39 @@ def test_pi_as_string_leading_digits():
         assert pi_as_string(632)[:600] == ("3" + str(mpmath.mp.pi)[2:])[:600]
     finally:
         mpmath.mp.dps = saved
+
+
+def test_device_nonce_model_equals_the_host_generator():
+    """csrc/rfc6979.hpp relies on two simplifications of signature.py:117-134 + python-ecdsa's
+    generate_k for this curve: h1 is the message hash itself (the one-nibble pad and bits2int cancel)
+    and a candidate is int(V) >> 4.  The same simplified procedure in Python must equal the host
+    generator (starkperp/rfc6979.py, pinned by the reference's signatures) on every input class."""
+    import hashlib
+    import hmac
+    from starkperp.signature import EC_ORDER, generate_k_rfc6979
+
+    def model(z, d, seed):
+        material = d.to_bytes(32, "big") + z.to_bytes(32, "big")
+        if seed:
+            material += seed.to_bytes((seed.bit_length() + 7) // 8, "big")
+        prf = lambda key, msg: hmac.new(key, msg, hashlib.sha256).digest()
+        v, k = b"\x01" * 32, b"\x00" * 32
+        k = prf(k, v + b"\x00" + material)
+        v = prf(k, v)
+        k = prf(k, v + b"\x01" + material)
+        v = prf(k, v)
+        while True:
+            v = prf(k, v)
+            cand = int.from_bytes(v, "big") >> 4
+            if 1 <= cand < EC_ORDER:
+                return cand
+            k = prf(k, v + b"\x00")
+            v = prf(k, v)
+
+    rng = random.Random(1)
+    for bits in [1, 2, 8, 9, 100, 243, 244, 245, 247, 248, 249, 250, 251]:
+        for _ in range(6):
+            z = rng.randrange(2 ** (bits - 1), 2**bits) if bits > 1 else rng.randrange(2)
+            d = rng.randrange(1, EC_ORDER)
+            for seed in (None, 0, 1, 255, 256, 2**32, 2**64 - 1):
+                assert model(z, d, seed) == generate_k_rfc6979(z, d, seed), (bits, seed)
