@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--log-rows", type=int, default=20,
                     help="airfri workload: log2 of the trace rows per GPU (20 = configs[3]; 24 = the whole "
                          "configs[4] trace on ONE GPU, 14 GiB of columns and trees)")
+    ap.add_argument("--with-witness", action="store_true",
+                    help="airfri workload: generate the 2^k-row trace (witness) inside every job instead of "
+                         "treating it as input preparation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -408,7 +411,8 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
         with torch.cuda.stream(sl["stream"]):
             roots_dev, gathered, tops = sl["roots"], sl["gathered"], sl["tops"]
             k = 0
-            t_lde = stark.lde(trace)
+            job_trace = stark.pedersen_trace(xs, ys) if args.with_witness else trace
+            t_lde = stark.lde(job_trace)
             roots_dev[k] = stark.commit_rows(t_lde)[-1]; k += 1
             comp = stark.air_eval(t_lde, per, 512 * m, alphas)
             roots_dev[k] = stark.commit_rows(comp.unsqueeze(0))[-1]; k += 1
