@@ -665,6 +665,20 @@ def extras(torch, lib, _lib, dev, stream):
         "fri_fold_first_layer_2p22": phase(
             lambda: stark.fri_fold(t_lde[0], betas[0], stark.FIELD_GEN)),
     }
+    # BASELINE.json configs[3] asks for the HBM fraction of the streaming phases: algorithmic bytes
+    # (64 B per element per NTT pass, 2 + 3 passes at 2^20 / 2^22 with 2048-felt tiles; the
+    # pad reads 32 B per coefficient and writes 32 B per LDE point; AIR: 7 trace + 6 periodic reads and
+    # one write of 32 B per point; fold: 32 B read, 16 B written per input point) over the measured time
+    n_rows, n_lde, cols = 512 * m, 4 * 512 * m, 4
+    algo = {
+        "lde_4cols_2p20_to_2p22": cols * (2 * 64 * n_rows + 32 * n_rows + 32 * n_lde + 3 * 64 * n_lde),
+        "air_eval_2p22_points": (7 + 6 + 1) * 32 * n_lde,
+        "fri_fold_first_layer_2p22": (32 + 16) * n_lde,
+    }
+    out["phase_hbm"] = {
+        k: {"algorithmic_bytes": b, "achieved_gb_per_s": b / out["phase_seconds"][k] / 1e9,
+            "frac_of_8_tb_per_s": b / out["phase_seconds"][k] / 1e9 / HBM_PEAK_GBS}
+        for k, b in algo.items()}
     return out
 
 
