@@ -570,8 +570,18 @@ def extras(torch, lib, _lib, dev, stream):
     t0 = time.perf_counter()
     _state.orders_tree_root({_state.order_id_of(z): o["amount_synthetic"] for z, o in zip(zs, orders)}, 64)
     t_tree = time.perf_counter() - t0
+    # the same update on a tree that already holds state (the library keeps the tree: sp_tree_*)
+    _tree = _state.LibrarySparseTree(64, 0)
+    _tree.update({_state.order_id_of(z): o["amount_synthetic"] for z, o in zip(zs, orders)})
+    _rng2 = _random.Random(77)
+    _second = {_rng2.randrange(2**64): _rng2.randrange(1, 2**64) for _ in range(4096)}
+    t0 = time.perf_counter()
+    _tree.update(_second)
+    t_tree_state = time.perf_counter() - t0
+    _tree.close()
     out["c3_4096_orders_host_inclusive_seconds"] = {
         "message_hashes": t_msgs, "verify_x_only": t_verify, "orders_tree_height64_update": t_tree,
+        "orders_tree_height64_update_on_existing_state": t_tree_state,
         "verify_x_only_keys_already_tabulated": t_verify_warm,
         "verify_x_only_per_signature_ladder": t_verify_ladder,
         "all_verified": bool(all(ok) and all(ok2) and all(c == 1 for c in ok3))}

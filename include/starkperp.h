@@ -120,6 +120,18 @@ int sp_merkle_forest_dev(uint64_t* levels, size_t n_trees, unsigned height, uint
  * starkware/python/merkle_tree.py:4-26. */
 int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leaves, size_t n, unsigned height,
                           const uint64_t* empty_leaf, uint64_t* root, uint8_t* status);
+/* Persistent sparse tree: merkle_multi_update{hash_ptr=pedersen_ptr} on a tree that already holds
+ * state (services/perpetual/cairo/state/state.cairo:155-173; untouched siblings come from the previous
+ * state, the role of `merkle_facts`, main.cairo:61-64).  The handle keeps, per level, the nodes that
+ * differ from the empty-subtree root (host memory); sp_tree_update writes leaves[i] at keys[i]
+ * (strictly increasing, < 2^height, height <= 64) in one call - one gathered launch per level - and
+ * returns the root before and after.  status != 0 (SP_HASH_*) leaves the tree unchanged. */
+int sp_tree_create(unsigned height, const uint64_t* empty_leaf, int* tree);
+int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_t n, uint64_t* old_root,
+                   uint64_t* new_root, uint8_t* status);
+int sp_tree_get(int tree, const uint64_t* keys, size_t n, uint64_t* leaves);
+int sp_tree_root(int tree, uint64_t* root);
+int sp_tree_destroy(int tree);
 
 /* ---- Stark-curve ECDSA ------------------------------------------------------------------------ */
 /* verify(msg_hash, r, s, public_key) signature.py:217-260.  qy == NULL: public keys are x-only

@@ -30,6 +30,7 @@ void release_pedersen_state();  // per-stream scratch, profiling events (pederse
 void release_merkle_state();    // sparse-update staging (merkle.hip)
 void release_stark_state();     // twiddle / coset tables, work buffers (stark.hip)
 void release_ecdsa_state();     // per-signature window tables (ecdsa.hip)
+void release_tree_state();      // persistent sparse trees (merkle.hip)
 
 static Context g_ctx;
 static std::string g_err;
@@ -307,6 +308,7 @@ void sp_shutdown(void) {
   sp::release_merkle_state();
   sp::release_stark_state();
   sp::release_ecdsa_state();
+  sp::release_tree_state();
   if (g_ctx.ped) (void)hipFree(g_ctx.ped);
   if (g_ctx.gen) (void)hipFree(g_ctx.gen);
   if (g_ctx.d_plan) (void)hipFree(g_ctx.d_plan);

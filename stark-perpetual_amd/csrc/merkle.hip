@@ -8,7 +8,10 @@
 // integer bookkeeping of which two children feed each induced node (the merkle_tree.py part),
 // the GPU does every hash: per level one pair of Pedersen launches whose accumulate kernel picks its
 // operands through the host's child-index list (gathered mode of csrc/pedersen.hip).
+#include <climits>
+#include <cstring>
 #include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "context.hpp"
@@ -35,6 +38,30 @@ void release_merkle_state() {
 }  // namespace sp
 
 using namespace sp;
+
+// empty-subtree roots: empties[k+1] = H(empties[k], empties[k]); 64 sequential hashes the first
+// time a given empty leaf is seen, then served from the host-side cache (65 felts per leaf value)
+static int empty_roots(const uint64_t* empty_leaf, const Scratch& s, const std::vector<uint64_t>** out) {
+  std::vector<uint64_t> key(empty_leaf, empty_leaf + 4);
+  auto it = g_empty_cache.find(key);
+  if (it == g_empty_cache.end()) {
+    uint64_t* d_full = nullptr;
+    SP_HIP(hipMalloc(&d_full, 65 * 32));
+    SP_HIP(hipMemcpy(d_full, empty_leaf, 32, hipMemcpyHostToDevice));
+    for (unsigned k2 = 0; k2 < 64; ++k2) {
+      const int rc = enqueue_pedersen(d_full + 4 * k2, 1, d_full + 4 * k2, 1, d_full + 4 * (k2 + 1), 1, nullptr,
+                                      s.flag, 1, 0, s, nullptr);
+      if (rc != SP_OK) { (void)hipFree(d_full); return rc; }
+    }
+    std::vector<uint64_t> all(65 * 4);
+    SP_HIP(hipDeviceSynchronize());
+    SP_HIP(hipMemcpy(all.data(), d_full, 65 * 32, hipMemcpyDeviceToHost));
+    (void)hipFree(d_full);
+    it = g_empty_cache.emplace(key, all).first;
+  }
+  *out = &it->second;
+  return SP_OK;
+}
 
 extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leaves, size_t n,
                                      unsigned height, const uint64_t* empty_leaf, uint64_t* root,
@@ -85,27 +112,11 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
   int rc = get_scratch_public(nn, s, 0);
   if (rc != SP_OK) return rc;
   SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), 0));
-  // empty-subtree roots: empties[k+1] = H(empties[k], empties[k]); 64 sequential hashes the first
-  // time a given empty leaf is seen, then served from the host-side cache
   {
-    std::vector<uint64_t> key(empty_leaf, empty_leaf + 4);
-    auto it = g_empty_cache.find(key);
-    if (it == g_empty_cache.end()) {
-      SP_HIP(hipMemcpy(d_emp, empty_leaf, 32, hipMemcpyHostToDevice));
-      uint64_t* d_full = nullptr;
-      SP_HIP(hipMalloc(&d_full, 65 * 32));
-      SP_HIP(hipMemcpy(d_full, empty_leaf, 32, hipMemcpyHostToDevice));
-      for (unsigned k2 = 0; k2 < 64; ++k2) {
-        rc = enqueue_pedersen(d_full + 4 * k2, 1, d_full + 4 * k2, 1, d_full + 4 * (k2 + 1), 1, nullptr, s.flag, 1, 0, s, nullptr);
-        if (rc != SP_OK) { (void)hipFree(d_full); return rc; }
-      }
-      std::vector<uint64_t> all(65 * 4);
-      SP_HIP(hipDeviceSynchronize());
-      SP_HIP(hipMemcpy(all.data(), d_full, 65 * 32, hipMemcpyDeviceToHost));
-      (void)hipFree(d_full);
-      it = g_empty_cache.emplace(key, all).first;
-    }
-    SP_HIP(hipMemcpy(d_emp, it->second.data(), emp_bytes, hipMemcpyHostToDevice));
+    const std::vector<uint64_t>* all = nullptr;
+    rc = empty_roots(empty_leaf, s, &all);
+    if (rc != SP_OK) return rc;
+    SP_HIP(hipMemcpy(d_emp, all->data(), emp_bytes, hipMemcpyHostToDevice));
   }
   if (n == 0) {
     SP_HIP(hipDeviceSynchronize());
@@ -132,3 +143,274 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
   }
   return SP_OK;
 }
+
+// =================================================================================================
+// Persistent sparse trees: merkle_multi_update on a tree that already holds state.
+//
+// services/perpetual/cairo/state/state.cairo:155-173 updates the positions tree and the orders
+// tree (height 64) once per batch: old root and new root along the union of the touched paths, the
+// untouched siblings coming from the previous state (the `merkle_facts` store of main.cairo:61-64).
+// sp_merkle_sparse_root only covers the first batch (everything else empty).  A tree handle keeps
+// the state: per level a host map  node index -> value  for every node that differs from the
+// empty-subtree root of its level.  An update is ONE call: the host walks the induced subtree
+// (merkle_tree.py:18-26), looks the untouched siblings up, ships leaves + siblings + child-index
+// lists to the device, every level is one gathered launch (csrc/pedersen.hip), and the new node
+// values come back in one copy to refresh the store.
+struct FeltKey {
+  uint64_t w[4];
+};
+// index -> felt, open addressing with linear probing (no allocation per node: an update inserts
+// ~ n * height nodes, and std::unordered_map's per-node malloc dominated the call)
+class NodeMap {
+ public:
+  const FeltKey* find(uint64_t key) const {
+    if (slots_.empty()) return nullptr;
+    for (size_t i = mix(key) & mask_;; i = (i + 1) & mask_) {
+      const Slot& sl = slots_[i];
+      if (!sl.used) return nullptr;
+      if (sl.key == key) return &sl.value;
+    }
+  }
+  void put(uint64_t key, const FeltKey& value) {
+    if ((count_ + 1) * 2 > slots_.size()) grow();
+    for (size_t i = mix(key) & mask_;; i = (i + 1) & mask_) {
+      Slot& sl = slots_[i];
+      if (!sl.used) { sl.used = true; sl.key = key; sl.value = value; ++count_; return; }
+      if (sl.key == key) { sl.value = value; return; }
+    }
+  }
+  size_t size() const { return count_; }
+
+ private:
+  struct Slot {
+    uint64_t key = 0;
+    FeltKey value{};
+    bool used = false;
+  };
+  static size_t mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (size_t)(z ^ (z >> 31));
+  }
+  void grow() {
+    std::vector<Slot> old;
+    old.swap(slots_);
+    slots_.assign(old.empty() ? 64 : old.size() * 2, Slot{});
+    mask_ = slots_.size() - 1;
+    count_ = 0;
+    for (const Slot& sl : old)
+      if (sl.used) put(sl.key, sl.value);
+  }
+  std::vector<Slot> slots_;
+  size_t mask_ = 0, count_ = 0;
+};
+struct SparseTree {
+  unsigned height = 0;
+  uint64_t empty_leaf[4] = {0, 0, 0, 0};
+  std::vector<NodeMap> nodes;  // [level][index], level 0 = leaves
+};
+static std::map<int, SparseTree> g_trees;
+static int g_next_tree = 1;
+static DeviceBuffer g_tree_buf;
+
+namespace sp {
+void release_tree_state() {
+  g_trees.clear();
+  g_tree_buf.release();
+}
+}  // namespace sp
+
+extern "C" {
+
+int sp_tree_create(unsigned height, const uint64_t* empty_leaf, int* tree) {
+  SP_REQUIRE_READY();
+  if (height < 1 || height > 64) { set_error("height must be in 1..64"); return SP_ERR_BAD_ARGUMENT; }
+  ctx_lock lk(ctx().mu);
+  SparseTree t;
+  t.height = height;
+  std::memcpy(t.empty_leaf, empty_leaf, 32);
+  t.nodes.resize(height + 1);
+  const int id = g_next_tree++;
+  g_trees.emplace(id, std::move(t));
+  *tree = id;
+  return SP_OK;
+}
+
+int sp_tree_destroy(int tree) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  if (g_trees.erase(tree) == 0) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
+  return SP_OK;
+}
+
+int sp_tree_root(int tree, uint64_t* root) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  auto it = g_trees.find(tree);
+  if (it == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
+  SparseTree& t = it->second;
+  if (const FeltKey* top = t.nodes[t.height].find(0)) {
+    std::memcpy(root, top->w, 32);
+    return SP_OK;
+  }
+  Scratch s;
+  int rc = get_scratch_public(1, s, 0);
+  if (rc != SP_OK) return rc;
+  const std::vector<uint64_t>* emp = nullptr;
+  rc = empty_roots(t.empty_leaf, s, &emp);
+  if (rc != SP_OK) return rc;
+  std::memcpy(root, emp->data() + 4 * t.height, 32);
+  return SP_OK;
+}
+
+int sp_tree_get(int tree, const uint64_t* keys, size_t n, uint64_t* leaves) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  auto it = g_trees.find(tree);
+  if (it == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
+  const SparseTree& t = it->second;
+  for (size_t i = 0; i < n; ++i) {
+    if (t.height < 64 && (keys[i] >> t.height) != 0) { set_error("key out of range for height"); return SP_ERR_BAD_ARGUMENT; }
+    const FeltKey* leaf = t.nodes[0].find(keys[i]);
+    std::memcpy(leaves + 4 * i, leaf ? leaf->w : t.empty_leaf, 32);
+  }
+  return SP_OK;
+}
+
+int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_t n, uint64_t* old_root,
+                   uint64_t* new_root, uint8_t* status) {
+  SP_REQUIRE_READY();
+  Context& c = ctx();
+  ctx_lock lk(c.mu);
+  auto tit = g_trees.find(tree);
+  if (tit == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
+  SparseTree& t = tit->second;
+  const unsigned height = t.height;
+  for (size_t i = 0; i < n; ++i) {
+    if (i > 0 && keys[i] <= keys[i - 1]) { set_error("keys must be strictly increasing"); return SP_ERR_BAD_ARGUMENT; }
+    if (height < 64 && (keys[i] >> height) != 0) { set_error("key out of range for height"); return SP_ERR_BAD_ARGUMENT; }
+  }
+  int rc = sp_tree_root(tree, old_root);
+  if (rc != SP_OK) return rc;
+  if (status) *status = 0;
+  if (n == 0) {
+    std::memcpy(new_root, old_root, 32);
+    return SP_OK;
+  }
+  // ---- host: induced subtree, siblings from the store ----
+  // device felt buffer layout: [siblings][level 0 = new leaves][level 1][level 2]...; child indices
+  // are absolute positions in that buffer, -1 = the level's empty-subtree root
+  std::vector<uint64_t> sib;       // sibling values, 4 words each
+  std::vector<int2> src;           // all levels
+  std::vector<size_t> level_off, level_cnt;
+  std::vector<std::vector<uint64_t>> level_idx(1, std::vector<uint64_t>(keys, keys + n));
+  struct Pending { unsigned level; uint64_t child; bool left; size_t src_pos; };
+  std::vector<Pending> want;       // sibling slots to patch once the sibling count is known
+  for (unsigned l = 0; l < height; ++l) {
+    const std::vector<uint64_t>& idx = level_idx[l];
+    std::vector<uint64_t> nxt;
+    nxt.reserve(idx.size());
+    level_off.push_back(src.size());
+    const size_t m = idx.size();
+    for (size_t j = 0; j < m;) {
+      int2 s2;
+      const uint64_t parent = idx[j] >> 1;
+      if ((idx[j] & 1) == 0) {
+        s2.x = (int)j;  // relative to this level's array for now
+        if (j + 1 < m && idx[j + 1] == idx[j] + 1) { s2.y = (int)(j + 1); j += 2; }
+        else { s2.y = INT_MIN; want.push_back({l, idx[j] + 1, false, src.size()}); j += 1; }
+      } else {
+        s2.x = INT_MIN; s2.y = (int)j; want.push_back({l, idx[j] - 1, true, src.size()}); j += 1;
+      }
+      nxt.push_back(parent);
+      src.push_back(s2);
+    }
+    level_cnt.push_back(nxt.size());
+    level_idx.push_back(std::move(nxt));
+  }
+  // resolve siblings: stored value -> position in the sibling region, absent -> empty (-1)
+  std::vector<int> sib_pos(want.size(), -1);
+  for (size_t k = 0; k < want.size(); ++k) {
+    if (const FeltKey* f = t.nodes[want[k].level].find(want[k].child)) {
+      sib_pos[k] = (int)(sib.size() / 4);
+      sib.insert(sib.end(), f->w, f->w + 4);
+    }
+  }
+  const size_t n_sib = sib.size() / 4;
+  size_t total_nodes = n;
+  for (size_t l = 0; l < level_cnt.size(); ++l) total_nodes += level_cnt[l];
+  if (n_sib + total_nodes >= (size_t)INT_MAX) { set_error("update too large"); return SP_ERR_BAD_ARGUMENT; }
+  // absolute positions: level l array starts at base[l]
+  std::vector<size_t> base(height + 1);
+  base[0] = n_sib;
+  for (unsigned l = 0; l < height; ++l) base[l + 1] = base[l] + (l == 0 ? n : level_cnt[l - 1]);
+  {
+    size_t k = 0;
+    for (unsigned l = 0; l < height; ++l) {
+      for (size_t q = level_off[l]; q < level_off[l] + level_cnt[l]; ++q) {
+        int2& s2 = src[q];
+        if (s2.x != INT_MIN) s2.x += (int)base[l];
+        if (s2.y != INT_MIN) s2.y += (int)base[l];
+      }
+    }
+    for (k = 0; k < want.size(); ++k) {
+      int2& s2 = src[want[k].src_pos];
+      (want[k].left ? s2.x : s2.y) = sib_pos[k];  // -1 = empty, else index into the sibling region
+    }
+  }
+  // ---- device ----
+  const size_t emp_bytes = ((size_t)height + 1) * 32;
+  const size_t felt_bytes = (n_sib + total_nodes) * 32;
+  const size_t src_bytes = src.size() * sizeof(int2);
+  SP_HIP(g_tree_buf.reserve(emp_bytes + felt_bytes + src_bytes + 1024));
+  char* b = (char*)g_tree_buf.ptr;
+  uint64_t* d_emp = (uint64_t*)b;
+  uint64_t* d_felts = (uint64_t*)(b + emp_bytes);
+  int2* d_src = (int2*)(b + emp_bytes + felt_bytes);
+  Scratch s;
+  rc = get_scratch_public(n, s, 0);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), 0));
+  const std::vector<uint64_t>* emp = nullptr;
+  rc = empty_roots(t.empty_leaf, s, &emp);
+  if (rc != SP_OK) return rc;
+  SP_HIP(hipMemcpy(d_emp, emp->data(), emp_bytes, hipMemcpyHostToDevice));
+  if (n_sib) SP_HIP(hipMemcpy(d_felts, sib.data(), n_sib * 32, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(d_felts + 4 * base[0], leaves, n * 32, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(d_src, src.data(), src_bytes, hipMemcpyHostToDevice));
+  for (unsigned l = 0; l < height; ++l) {
+    rc = enqueue_pedersen(d_felts, 1, d_emp + 4 * l, 1, d_felts + 4 * base[l + 1], 1, nullptr, s.flag, level_cnt[l],
+                          0, s, d_src + level_off[l]);
+    if (rc != SP_OK) return rc;
+  }
+  SP_HIP(hipDeviceSynchronize());
+  unsigned f = 0;
+  SP_HIP(hipMemcpy(&f, s.flag, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (status) *status = (uint8_t)f;
+  if (f != 0) {  // an input out of range or an unhashable pair: the tree is left as it was
+    std::memcpy(new_root, old_root, 32);
+    return SP_OK;
+  }
+  std::vector<uint64_t> fresh((total_nodes - n) * 4);
+  SP_HIP(hipMemcpy(fresh.data(), d_felts + 4 * base[1], fresh.size() * 8, hipMemcpyDeviceToHost));
+  // ---- refresh the store ----
+  for (size_t i = 0; i < n; ++i) {
+    FeltKey v;
+    std::memcpy(v.w, leaves + 4 * i, 32);
+    t.nodes[0].put(keys[i], v);
+  }
+  size_t pos = 0;
+  for (unsigned l = 0; l < height; ++l) {
+    auto& lvl = t.nodes[l + 1];
+    const std::vector<uint64_t>& idx = level_idx[l + 1];
+    for (size_t q = 0; q < idx.size(); ++q, ++pos) {
+      FeltKey v;
+      std::memcpy(v.w, fresh.data() + 4 * pos, 32);
+      lvl.put(idx[q], v);
+    }
+  }
+  std::memcpy(new_root, fresh.data() + 4 * (pos - 1), 32);
+  return SP_OK;
+}
+
+}  // extern "C"

@@ -58,6 +58,12 @@ _SIGNATURES = {
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_fri_fold_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_tree_create": (ctypes.c_int, [ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_tree_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_tree_get": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "sp_tree_root": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
+    "sp_tree_destroy": (ctypes.c_int, [ctypes.c_int]),
     "sp_ecdsa_verify_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
     "sp_ecdsa_verify_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
     "sp_ecdsa_register_keys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

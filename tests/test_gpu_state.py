@@ -142,3 +142,62 @@ def test_shared_state_on_gpu_matches_oracle_twin():
     accesses = [(1000 + 77 * i, empty, tuple([p[0], p[1], tuple(p[2])])) for i, p in enumerate(poss)]
     orders = [(2**63 + i, 0, 5 * i + 1) for i in range(5)]
     assert gpu.apply_state_updates(accesses, orders) == ref.apply_state_updates(accesses, orders)
+
+
+def test_library_tree_matches_the_python_tree_over_many_batches():
+    """sp_tree_* (the library keeps the tree) against SparseMerkleTree with the oracle's hash over a
+    sequence of batches: fresh keys, overwritten keys, neighbours that share parents, keys reset
+    to the empty leaf, a single-leaf update, an empty update, heights 3, 16 and 64."""
+    import random
+    from oracle import cref
+    from starkperp import state
+
+    def oracle_hash_many(xs, ys):
+        return cref.pedersen_hash_many(list(xs), list(ys))[0]
+
+    rng = random.Random(11)
+    for height, empty_leaf, rounds, per_round in ((3, 0, 6, 3), (16, 5, 5, 40), (64, 0, 4, 150)):
+        lib_tree = state.LibrarySparseTree(height, empty_leaf)
+        ref_tree = state.SparseMerkleTree(height, empty_leaf, hash_many=oracle_hash_many)
+        assert lib_tree.root == ref_tree.root
+        known = []
+        for r in range(rounds):
+            mods = {}
+            for _ in range(per_round):
+                choice = rng.random()
+                if known and choice < 0.3:
+                    k = rng.choice(known)                      # overwrite
+                elif known and choice < 0.5:
+                    k = rng.choice(known) ^ 1                  # sibling of an existing leaf
+                else:
+                    k = rng.randrange(2**height)
+                mods[k] = empty_leaf if rng.random() < 0.1 else rng.randrange(P)
+            if r == 2:
+                mods = {rng.randrange(2**height): 7}           # single leaf
+            if r == 3:
+                mods = {}                                      # nothing
+            known += list(mods)
+            assert lib_tree.update(mods) == ref_tree.update(mods), (height, r)
+            assert lib_tree.root == ref_tree.root
+            probe = rng.sample(known, min(len(known), 10)) + [rng.randrange(2**height)]
+            assert lib_tree.get_many(probe) == ref_tree.get_many(probe)
+        lib_tree.close()
+
+
+def test_library_tree_rejects_bad_input_and_keeps_its_state():
+    from starkperp import _lib, state
+    t = state.LibrarySparseTree(8, 0)
+    before = t.update({3: 9, 200: 11})[1]
+    with pytest.raises(AssertionError):
+        t.update({256: 1})                                     # key out of range (Python-side check)
+    import ctypes
+    lib = _lib.ensure_init()
+    keys = (ctypes.c_uint64 * 2)(5, 5)                          # not strictly increasing
+    old, new, st = _lib.new_felts(1), _lib.new_felts(1), _lib.new_bytes(1)
+    assert lib.sp_tree_update(t._handle, keys, _lib.pack_felts([1, 2]), 2, old, new, st) < 0
+    keys = (ctypes.c_uint64 * 1)(5)
+    rc = lib.sp_tree_update(t._handle, keys, _lib.pack_felts([P]), 1, old, new, st)  # leaf >= p
+    assert rc == 0 and st[0] == 1 and _lib.unpack_felts(new, 1)[0] == before
+    assert t.root == before and t.get(5) == 0
+    assert lib.sp_tree_update(12345, keys, _lib.pack_felts([1]), 1, old, new, st) < 0  # unknown handle
+    t.close()
