@@ -11,6 +11,7 @@
 #include <climits>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -209,6 +210,23 @@ struct SparseTree {
   uint64_t empty_leaf[4] = {0, 0, 0, 0};
   std::vector<NodeMap> nodes;  // [level][index], level 0 = leaves
 };
+// Runs fn(level) for level = 0..count-1 on a few host threads (levels touch disjoint node maps).
+template <typename F>
+static void for_levels_parallel(unsigned count, F fn) {
+  const unsigned workers = count < 8 ? count : 8;
+  if (workers <= 1) {
+    for (unsigned l = 0; l < count; ++l) fn(l);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(workers);
+  for (unsigned w = 0; w < workers; ++w)
+    pool.emplace_back([=]() {
+      for (unsigned l = w; l < count; l += workers) fn(l);
+    });
+  for (auto& th : pool) th.join();
+}
+
 static std::map<int, SparseTree> g_trees;
 static int g_next_tree = 1;
 static DeviceBuffer g_tree_buf;
@@ -328,12 +346,26 @@ int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_
     level_cnt.push_back(nxt.size());
     level_idx.push_back(std::move(nxt));
   }
-  // resolve siblings: stored value -> position in the sibling region, absent -> empty (-1)
+  // resolve siblings: stored value -> position in the sibling region, absent -> empty (-1).
+  // `want` is grouped by level (it was filled level by level): the lookups of different levels go to
+  // different node maps and run on a few host threads; placing the hits is serial and cheap.
+  std::vector<const FeltKey*> hit(want.size(), nullptr);
+  {
+    std::vector<size_t> first(height + 1, want.size());
+    for (size_t k = want.size(); k-- > 0;) first[want[k].level] = k;
+    for (unsigned l = height; l-- > 0;)
+      if (first[l] == want.size()) first[l] = first[l + 1];
+    const SparseTree* tree_c = &t;
+    for_levels_parallel(height, [&, tree_c](unsigned l) {
+      const NodeMap& lvl = tree_c->nodes[l];
+      for (size_t k = first[l]; k < first[l + 1]; ++k) hit[k] = lvl.find(want[k].child);
+    });
+  }
   std::vector<int> sib_pos(want.size(), -1);
   for (size_t k = 0; k < want.size(); ++k) {
-    if (const FeltKey* f = t.nodes[want[k].level].find(want[k].child)) {
+    if (hit[k]) {
       sib_pos[k] = (int)(sib.size() / 4);
-      sib.insert(sib.end(), f->w, f->w + 4);
+      sib.insert(sib.end(), hit[k]->w, hit[k]->w + 4);
     }
   }
   const size_t n_sib = sib.size() / 4;
@@ -393,22 +425,28 @@ int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_
   }
   std::vector<uint64_t> fresh((total_nodes - n) * 4);
   SP_HIP(hipMemcpy(fresh.data(), d_felts + 4 * base[1], fresh.size() * 8, hipMemcpyDeviceToHost));
-  // ---- refresh the store ----
-  for (size_t i = 0; i < n; ++i) {
-    FeltKey v;
-    std::memcpy(v.w, leaves + 4 * i, 32);
-    t.nodes[0].put(keys[i], v);
-  }
-  size_t pos = 0;
-  for (unsigned l = 0; l < height; ++l) {
-    auto& lvl = t.nodes[l + 1];
-    const std::vector<uint64_t>& idx = level_idx[l + 1];
-    for (size_t q = 0; q < idx.size(); ++q, ++pos) {
+  // ---- refresh the store (one node map per level: levels in parallel) ----
+  std::vector<size_t> fresh_off(height + 1, 0);
+  for (unsigned l = 0; l < height; ++l) fresh_off[l + 1] = fresh_off[l] + level_idx[l + 1].size();
+  for_levels_parallel(height + 1, [&](unsigned lvl_no) {
+    NodeMap& lvl = t.nodes[lvl_no];
+    if (lvl_no == 0) {
+      for (size_t i = 0; i < n; ++i) {
+        FeltKey v;
+        std::memcpy(v.w, leaves + 4 * i, 32);
+        lvl.put(keys[i], v);
+      }
+      return;
+    }
+    const std::vector<uint64_t>& idx = level_idx[lvl_no];
+    const uint64_t* vals = fresh.data() + 4 * fresh_off[lvl_no - 1];
+    for (size_t q = 0; q < idx.size(); ++q) {
       FeltKey v;
-      std::memcpy(v.w, fresh.data() + 4 * pos, 32);
+      std::memcpy(v.w, vals + 4 * q, 32);
       lvl.put(idx[q], v);
     }
-  }
+  });
+  const size_t pos = fresh_off[height];
   std::memcpy(new_root, fresh.data() + 4 * (pos - 1), 32);
   return SP_OK;
 }
