@@ -579,6 +579,22 @@ def extras(torch, lib, _lib, dev, stream):
     _tree.update(_second)
     t_tree_state = time.perf_counter() - t0
     _tree.close()
+    # a whole state update (state/state.cairo:135-186): 2048 positions changed + 4096 order fills on
+    # trees that already hold 2048 positions and 4096 orders - squash, previous and new position
+    # hashes, previous-leaf checks, both height-64 trees (state.SharedState)
+    _shared = _state.SharedState(64, 64)
+    _empty_pos = (0, 0, ())
+    _poss = [(p[0], p[1], tuple(p[2])) for p in wl.positions(2048, seed=3)]
+    _pkeys = [_rng2.randrange(2**64) for _ in range(2048)]
+    _okeys = [_rng2.randrange(2**64) for _ in range(4096)]
+    _shared.apply_state_updates([(k, _empty_pos, p) for k, p in zip(_pkeys, _poss)],
+                                [(k, 0, 1 + i) for i, k in enumerate(_okeys)])
+    _poss2 = [(p[0], p[1] + 1, p[2]) for p in _poss]
+    t0 = time.perf_counter()
+    _roots = _shared.apply_state_updates([(k, p, q) for k, p, q in zip(_pkeys, _poss, _poss2)],
+                                         [(k, 1 + i, 2 + i) for i, k in enumerate(_okeys)])
+    t_state = time.perf_counter() - t0
+    out["state_update_2048_positions_4096_orders_seconds"] = t_state
     out["c3_4096_orders_host_inclusive_seconds"] = {
         "message_hashes": t_msgs, "verify_x_only": t_verify, "orders_tree_height64_update": t_tree,
         "orders_tree_height64_update_on_existing_state": t_tree_state,
