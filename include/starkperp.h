@@ -212,6 +212,12 @@ int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodi
  * g(x^2) = (f(x) + f(-x)) / 2 + beta (f(x) - f(-x)) / (2 x). */
 int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uint64_t* beta_host,
                     const uint64_t* shift_host, void* stream);
+/* Commit (build-defined): Pedersen-Merkle tree over the rows of a column-major table of
+ * n_rows (a power of two) x n_cols felts; leaf = left-fold chain of the row's felts (one column: the
+ * felt itself).  levels receives 2 n_rows - 1 felts, leaves first, root last.  Passing a status
+ * pointer makes the call wait for the stream. */
+int sp_commit_rows_dev(const uint64_t* cols, size_t n_rows, size_t n_cols, uint64_t* levels, uint8_t* status,
+                       void* stream);
 
 #ifdef __cplusplus
 }

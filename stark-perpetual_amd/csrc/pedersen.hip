@@ -725,6 +725,31 @@ int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void
   return sp_merkle_forest_dev(levels, 1, height, status, stream);
 }
 
+// Commitment to a table of n_rows x n_cols felts stored column-major (column c at cols + 4 c n_rows):
+// leaf r = left-fold Pedersen chain of row r (a single column commits the felts themselves), then
+// the Merkle tree over the leaves.  levels: 2 n_rows - 1 felts, leaves first, root last.
+int sp_commit_rows_dev(const uint64_t* cols, size_t n_rows, size_t n_cols, uint64_t* levels, uint8_t* status,
+                       void* stream) {
+  SP_REQUIRE_READY();
+  if (n_rows == 0 || (n_rows & (n_rows - 1)) != 0 || n_cols == 0) {
+    set_error("rows must be a power of two, columns at least one");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  ctx_lock lk(ctx().mu);
+  unsigned height = 0;
+  while (((size_t)1 << height) < n_rows) ++height;
+  uint8_t st_chain = 0, st_tree = 0;
+  int rc = sp_pedersen_chains_dev(cols, n_rows, n_cols, levels, status ? &st_chain : nullptr, stream);
+  if (rc != SP_OK) return rc;
+  rc = sp_merkle_build_dev(levels, height, status ? &st_tree : nullptr, stream);
+  if (rc != SP_OK) return rc;
+  if (status) {  // the two flags arrive with the stream; fold them once it has drained
+    SP_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *status = st_chain | st_tree;
+  }
+  return SP_OK;
+}
+
 int sp_merkle_root(const uint64_t* leaves, unsigned height, uint64_t* root, uint64_t* levels_out,
                    uint8_t* status) {
   SP_REQUIRE_READY();

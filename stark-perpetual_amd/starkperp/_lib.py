@@ -58,6 +58,8 @@ _SIGNATURES = {
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_fri_fold_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_commit_rows_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
     "sp_tree_create": (ctypes.c_int, [ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_tree_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

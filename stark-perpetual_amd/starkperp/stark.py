@@ -157,13 +157,8 @@ def commit_rows(cols):
     lib = _lib.ensure_init()
     ncols, n = cols.shape[0], cols.shape[1]
     levels = torch.empty((2 * n - 1, 4), dtype=torch.int64, device=cols.device)
-    if ncols == 1:
-        levels[:n] = cols[0]
-    else:
-        _lib.check(lib.sp_pedersen_chains_dev(cols.data_ptr(), n, ncols, levels.data_ptr(), None, _stream()),
-                   "sp_pedersen_chains_dev")
-    _lib.check(lib.sp_merkle_build_dev(levels.data_ptr(), n.bit_length() - 1, None, _stream()),
-               "sp_merkle_build_dev")
+    _lib.check(lib.sp_commit_rows_dev(cols.contiguous().data_ptr(), n, ncols, levels.data_ptr(), None, _stream()),
+               "sp_commit_rows_dev")
     return levels
 
 
