@@ -97,3 +97,44 @@ def combine_forest_dev(lib, dist, roots, gathered, top, nb: int, stream):
     _lib.check(lib.sp_merkle_forest_dev(top.data_ptr(), nb, world.bit_length() - 1, None, stream),
                "sp_merkle_forest_dev")
     return top[nb * (2 * world - 1) - nb : nb * (2 * world - 1)]
+
+
+# ---- multi-update sharded by key prefix ("Merkle multi-update (C3)") ----------------
+class ShardedSparseTree:
+    """A height-h sparse tree over `world` ranks: rank g owns the subtree of the keys whose top
+    log2(world) bits equal g (a tree of height h - log2(world) over the remaining low bits).  An
+    update is local work on the owned subtree plus the usual exchange: an all_gather of one
+    sub-root per rank and the log2(world) top levels hashed on every rank.
+
+    `make_tree(height, empty_leaf)` builds the local tree - `state.LibrarySparseTree` on the GPU,
+    `state.SparseMerkleTree` with an injected hash in the CPU tests; `hash_many` hashes the top."""
+
+    def __init__(self, dist, torch, height: int, make_tree, hash_many, empty_leaf: int = 0, device=None,
+                 group=None):
+        self.dist, self.torch, self.device, self.group = dist, torch, device, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.top_bits = self.world.bit_length() - 1
+        assert 1 << self.top_bits == self.world and self.top_bits < height
+        self.height = height
+        self.low_bits = height - self.top_bits
+        self.local = make_tree(self.low_bits, empty_leaf)
+        self.hash_many = hash_many
+        self.root = self._combine(self.local.root)
+
+    def owner(self, key: int) -> int:
+        return key >> self.low_bits
+
+    def _combine(self, local_root: int) -> int:
+        return combine_subroots(gather_subroots(self.dist, self.torch, local_root, self.device, self.group),
+                                self.hash_many)
+
+    def update(self, modifications) -> tuple:
+        """Every rank passes the whole batch {key: leaf} (or at least its own share); each applies
+        the keys it owns.  Returns (old_root, new_root) of the full tree on every rank."""
+        mask = (1 << self.low_bits) - 1
+        mine = {k & mask: v for k, v in dict(modifications).items() if self.owner(k) == self.rank}
+        old_root = self.root
+        _, local_new = self.local.update(mine)
+        self.root = self._combine(local_new)
+        return old_root, self.root

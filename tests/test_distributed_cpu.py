@@ -83,3 +83,47 @@ def test_shard_range_covers():
             spans = [D.shard_range(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _sharded_tree_worker(rank, world, port, height, batches, expect, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from starkperp import distributed as D
+    from starkperp import state
+    hash_many = lambda a, b: [R.pedersen_hash(x, y) for x, y in zip(a, b)]
+    make_tree = lambda h, empty: state.SparseMerkleTree(h, empty, hash_many=hash_many)
+    tree = D.ShardedSparseTree(dist, torch, height, make_tree, hash_many)
+    got = [tree.update(mods) for mods in batches]
+    q.put((rank, got == expect))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_multi_update_matches_single_tree(world):
+    """Multi-update sharded by key prefix: every rank owns the subtree of its top key
+    bits, sub-roots are all-gathered, the top levels are hashed everywhere - same (old, new) root
+    pairs as one tree in one process, batch after batch (oracle hash, gloo)."""
+    import random
+    from starkperp import state
+    height = 10
+    rng = random.Random(3)
+    batches = []
+    for _ in range(3):
+        batches.append({rng.randrange(2**height): rng.randrange(1, R.FIELD_PRIME) for _ in range(6)})
+    batches.append({0: 5, 2**height - 1: 6})
+    hash_many = lambda a, b: [R.pedersen_hash(x, y) for x, y in zip(a, b)]
+    single = state.SparseMerkleTree(height, 0, hash_many=hash_many)
+    expect = [single.update(m) for m in batches]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_sharded_tree_worker, args=(r, world, port, height, batches, expect, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, True) for r in range(world)]
