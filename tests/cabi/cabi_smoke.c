@@ -1,7 +1,8 @@
 /* Plain-C consumer of include/starkperp.h: shows the drop-in boundary needs nothing but a C
  * compiler and the shared library (no Python, no torch).  Built and run by tests/test_gpu_cabi.py.
  * Checks pedersen_hash(1, 2) and the two hash_test vectors of the reference's
- * signature_test_data.json:190-201, a 2-leaf tree, a chain, sign -> verify. */
+ * signature_test_data.json:190-201, a 2-leaf tree, a chain, sign -> verify (ladder and key tables),
+ * deterministic signing on the device, a persistent tree. */
 #include <stdio.h>
 #include <string.h>
 #include "../../include/starkperp.h"
@@ -61,6 +62,25 @@ int main(void) {
   felt_from_hex("1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcd", k);
   if (sp_ecdsa_sign_batch(z, d, k, r, s, &code, 1) != SP_OK || code != SP_SIGN_OK) return 16;
   if (sp_ecdsa_verify_batch(z, r, s, qx, NULL, &code, 1) != SP_OK || code != SP_VERIFY_TRUE) return 17;
+
+  /* the whole of sign() on the device reproduces the reference's signature of this order
+   * (signature_test_data.json:17-20), and the key tables give the same verdicts as the ladder */
+  if (sp_ecdsa_sign_rfc6979_batch(z, d, NULL, r, s, &code, 1) != SP_OK || code != SP_SIGN_OK) return 18;
+  if (!felt_eq_hex(r, "173fd03d8b008ee7432977ac27d1e9d1a1f6c98b1a2f05fa84a21c84c44e882")) return 19;
+  if (!felt_eq_hex(s, "4b6d75385aed025aa222f28a0adc6d58db78ff17e51c3f59e259b131cd5a1cc")) return 20;
+  if (sp_ecdsa_verify_batch_keyed(z, r, s, qx, NULL, &code, 1) != SP_OK || code != SP_VERIFY_TRUE) return 21;
+  z[0] ^= 1;
+  if (sp_ecdsa_verify_batch_keyed(z, r, s, qx, NULL, &code, 1) != SP_OK || code != SP_VERIFY_FALSE) return 22;
+  z[0] ^= 1;
+
+  /* persistent tree: two updates of a height-1 tree; the second one sees the first one's leaf */
+  int tree = 0;
+  uint64_t zero[4] = {0, 0, 0, 0}, key0 = 0, key1 = 1, r_old[4], r_new[4], r_new2[4];
+  if (sp_tree_create(1, zero, &tree) != SP_OK) return 23;
+  if (sp_tree_update(tree, &key0, x[0], 1, r_old, r_new, &s1) != SP_OK || s1) return 24;
+  if (sp_tree_update(tree, &key1, y[0], 1, r_old, r_new2, &s1) != SP_OK || s1) return 25;
+  if (memcmp(r_old, r_new, 32) != 0 || memcmp(r_new2, out[0], 32) != 0) return 26;  /* H(x0, y0) */
+  if (sp_tree_destroy(tree) != SP_OK) return 27;
   sp_shutdown();
   printf("cabi_smoke ok\n");
   return 0;
