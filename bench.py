@@ -97,16 +97,17 @@ def cpu_baseline_c(leaf_ints, gpu_root):
 
 
 def combine_check(slot, world, _lib):
-    """N > 1: the job root of tree 0 of the last call issued on stream 0 against the C oracle's tree
-    over the gathered sub-roots (rank order).  None when the oracle library is not available."""
+    """N > 1: the job root of tree 0 of the last call issued on stream 0, recomputed from the gathered
+    sub-roots (rank order) through the library's host-pointer tree entry point - a check of the
+    exchange and of the tree-major transposition, independent of the lockstep device path."""
     try:
-        from oracle import cref
+        from starkperp import batch
         nb = slot["last_nb"]
         top = slot["top"][: nb * (2 * world - 1)].cpu().numpy().astype("<i8")
         felts = _lib.unpack_felts((ctypes.c_uint64 * (4 * top.shape[0])).from_buffer_copy(top.tobytes()), top.shape[0])
         leaves, root = felts[:world], felts[nb * (2 * world - 1) - nb]
-        return cref.merkle_levels(leaves)[-1][0] == root
-    except Exception as e:  # noqa: BLE001 - a missing checker must not void the measurement
+        return batch.merkle_root(leaves) == root
+    except Exception as e:  # noqa: BLE001 - a failed self-check must not void the measurement
         sys.stderr.write("bench: combine check skipped (%s)\n" % e)
         return None
 
@@ -349,7 +350,7 @@ def main():
             },
         }
         if world > 1:
-            result["combine_matches_oracle"] = combine_check(slots[0], world, _lib)
+            result["combine_matches_recomputed"] = combine_check(slots[0], world, _lib)
         if world == 1 and not args.no_extras:
             result["extra"] = extras(torch, lib, _lib, dev, stream)
         if world == 1 and not args.no_cpu_baseline:

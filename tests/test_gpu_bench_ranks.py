@@ -35,4 +35,4 @@ def test_two_ranks_share_one_gpu(workload, extra):
     assert d["steps"] == int(extra[1]) and d["warmup"] == int(extra[3])
     if workload == "merkle":
         assert d["config"]["hashes_per_step"] == 2 * 65535 + 1
-        assert d["combine_matches_oracle"] is True
+        assert d["combine_matches_recomputed"] is True
