@@ -112,7 +112,7 @@ def combine_check(slot, world, _lib):
         return None
 
 
-def valu_issue(bulk_hashes_per_sec, window_bits):
+def valu_issue(bulk_hashes_per_sec, window_bits, workload="2^22 independent hashes (bulk_pedersen_hashes_per_sec)"):
     """The roofline that actually bounds the hash kernels: wave64 VALU
     instructions issued per second against 1024 SIMDs x one instruction per 4 cycles.  Instruction
     counts per hash are the SQ_INSTS_VALU measurements in profiles/r01_valu_issue.json; None when
@@ -125,7 +125,7 @@ def valu_issue(bulk_hashes_per_sec, window_bits):
     per_hash = w["accumulate_instr_per_hash"] + w["finish_instr_per_hash"]
     achieved = bulk_hashes_per_sec * per_hash / 64.0
     peak = m["simds"] * m["nominal_clock_ghz"] * 1e9 / m["cycles_per_wave64_valu_instr"]
-    return {"bound": "valu_issue", "workload": "2^22 independent hashes (bulk_pedersen_hashes_per_sec)",
+    return {"bound": "valu_issue", "workload": workload,
             "instr_per_hash": per_hash, "achieved": achieved, "peak": peak, "unit": "wave64 VALU instr/s",
             "frac": achieved / peak,
             "note": "peak at the nominal 2.4 GHz; the chip runs this kernel at about 1.9 GHz "
@@ -344,6 +344,8 @@ def main():
                 "launches": int(k_launches.value),
                 "avg_launch_us": avg_launch_s * 1e6,
                 "timing": "HIP events around every launch inside the timed region",
+                "valu_issue": valu_issue(value / max(world, 1), int(lib.sp_window_bits()),
+                                         "this run: hashes/s per GPU over the whole timed region"),
                 "note": "integer-ALU bound kernel (DESIGN.md section 4): 31-38e3 VALU instructions per hash at the "
                         "VALU issue limit (extra.valu_issue has that roofline); the HBM fraction is reported "
                         "because the contract asks for it",
