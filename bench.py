@@ -694,6 +694,14 @@ def extras(torch, lib, _lib, dev, stream):
         "fri_fold_first_layer_2p22": phase(
             lambda: stark.fri_fold(t_lde[0], betas[0], stark.FIELD_GEN)),
     }
+    # the full prover on top of the commit job: witness generation, Fiat-Shamir challenges derived from
+    # the roots (so nothing overlaps inside a proof), eight queries with all their Merkle openings
+    stark.prove(xs, ys, n_queries=8, seed=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stark.prove(xs, ys, n_queries=8, seed=1)
+    torch.cuda.synchronize()
+    out["prove_seconds_2p20_rows_8_queries"] = time.perf_counter() - t0
     # BASELINE.json configs[3] asks for the HBM fraction of the streaming phases: algorithmic bytes
     # (64 B per element per NTT pass, 2 + 3 passes at 2^20 / 2^22 with 2048-felt tiles; the
     # pad reads 32 B per coefficient and writes 32 B per LDE point; AIR: 7 trace + 6 periodic reads and
