@@ -82,6 +82,17 @@ int main(void) {
   if (memcmp(r_old, r_new, 32) != 0 || memcmp(r_new2, out[0], 32) != 0) return 26;  /* H(x0, y0) */
   if (sp_tree_destroy(tree) != SP_OK) return 27;
   sp_shutdown();
+
+  /* a second life with another window plan: same answers, no state left over */
+  if (sp_pedersen_batch(&x[0][0], &y[0][0], &out[0][0], st, 2) != SP_ERR_NOT_INITIALISED) return 28;
+  if (sp_init(0, 11) != SP_OK || sp_window_bits() != 11) return 29;
+  if (sp_pedersen_batch(&x[0][0], &y[0][0], &out[0][0], st, 2) != SP_OK || st[0] || st[1]) return 30;
+  if (!felt_eq_hex(out[1], "68cc0b76cddd1dd4ed2301ada9b7c872b23875d5ff837b3a87993e0d9996b87")) return 31;
+  if (sp_tree_root(tree, r_old) == SP_OK) return 32; /* handles do not survive a shutdown */
+  size_t cap = 0, used = 99;
+  if (sp_ecdsa_verify_batch_keyed(z, r, s, qx, NULL, &code, 1) != SP_OK || code != SP_VERIFY_TRUE) return 33;
+  if (sp_ecdsa_key_cache_info(&cap, &used) != SP_OK || used != 1) return 34;
+  sp_shutdown();
   printf("cabi_smoke ok\n");
   return 0;
 }
