@@ -22,7 +22,8 @@ def _free_port():
 @pytest.mark.parametrize("workload,extra", [("merkle", ["--steps", "6", "--warmup", "2"]),
                                             ("airfri", ["--steps", "1", "--warmup", "1", "--log-rows", "14"])])
 def test_two_ranks_share_one_gpu(workload, extra):
-    env = dict(os.environ, STARKPERP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, STARKPERP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               STARKPERP_WINDOW_BITS="16")  # two ranks share one GPU here: small tables whatever the caller set
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--workload", workload, "--window-bits", "0", "--no-extras", "--no-cpu-baseline"] + extra

@@ -18,7 +18,10 @@ KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json
 
 
 def run_cli(*args):
-    return subprocess.run([sys.executable, CLI] + list(args), capture_output=True)
+    # the CLI picks its own small window plan; do not let a plan chosen for this test process leak
+    # into the child (two 155 GiB tables would not fit one GPU)
+    env = {k: v for k, v in os.environ.items() if k != "STARKPERP_WINDOW_BITS"}
+    return subprocess.run([sys.executable, CLI] + list(args), capture_output=True, env=env)
 
 
 HASH_ARGS = ["--oracle", "4d616b6572", "--asset", "42544355534400000000000000000000", "--price",

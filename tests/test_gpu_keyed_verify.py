@@ -168,6 +168,6 @@ assert batch.verify_codes(zs[4:], [r for r, _ in sigs[4:]], [s for _, s in sigs[
 assert batch.key_cache_info() == (4, 2)
 print("ok")
 ''' % (root, os.path.join(root, "stark-perpetual_amd"))
-    env = dict(os.environ, STARKPERP_KEY_CACHE_SLOTS="4")
+    env = dict(os.environ, STARKPERP_KEY_CACHE_SLOTS="4", STARKPERP_WINDOW_BITS="16")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr[-1500:]
