@@ -527,6 +527,63 @@ def get_price_msg(oracle_name, asset_pair, timestamp, price, hash_function=peder
 
 
 # --------------------------------------------------------------------------------------------
+# Multi-asset order: services/exchange/cairo/signature_message_hashes.cairo:171-471
+# (the Cairo program is the only statement of this format; no Python twin exists)
+# --------------------------------------------------------------------------------------------
+MULTI_ASSET_OFFCHAIN_ORDER_TYPE = 6
+
+
+def multi_asset_order_words(signer_key, nonce, expiration_timestamp, system_id, give, receive, conditions):
+    """The felts of the hash chain, in chain order (signature_message_hashes.cairo:405-468).
+    give / receive: lists of (vault_id, public_key, asset_id, amount) in the field order of
+    `VaultInfo` (:172-178).  Linearisation (:290-329, :405-431): receive first, then give; per entry
+    asset -> `assets`, (vault, amount) -> `vaults_and_amounts`, and when the entry's key differs from
+    the signer's its key and its index IN ITS OWN LIST -> `third_party_*`."""
+    vaults_and_amounts, assets, third_keys, third_idx = [], [], [], []
+    for entries in (receive, give):
+        for index, (vault_id, public_key, asset_id, amount) in enumerate(entries):
+            assets.append(asset_id)
+            vaults_and_amounts += [vault_id, amount]
+            if public_key != signer_key:
+                third_idx.append(index)
+                third_keys.append(public_key)
+    words = list(conditions) + assets + third_keys
+    for i in range(0, len(vaults_and_amounts), 3):  # three 64-bit fields per felt (:264-288)
+        acc = 0
+        for v in vaults_and_amounts[i : i + 3]:
+            acc = acc * 2**64 + v
+        words.append(acc)
+    for i in range(0, len(third_idx), 20):  # twenty 12-bit indices per felt (:205-260)
+        acc = 0
+        for v in third_idx[i : i + 20]:
+            acc = acc * 2**12 + v
+        words.append(acc)
+    meta = MULTI_ASSET_OFFCHAIN_ORDER_TYPE  # :433-463
+    meta = meta * 2**32 + nonce
+    meta = meta * 2**32 + expiration_timestamp
+    meta = meta * 2**12 + len(give)
+    meta = meta * 2**12 + len(receive)
+    meta = meta * 2**12 + len(third_idx)
+    meta = meta * 2**12 + len(conditions)
+    meta = meta * 2**126 + system_id
+    words.append(meta * 2**3)
+    return words
+
+
+def multi_asset_order_hash(signer_key, nonce, expiration_timestamp, system_id, give, receive, conditions,
+                           hash_function=pedersen_hash):
+    """signature_message_hashes.cairo:387-471: hash_felts_no_padding(words[1:], initial_hash=words[0]),
+    i.e. the left fold h(...h(h(w0, w1), w2)..., packed_metadata) (:465-470; hash_felts_no_padding is
+    cairo-lang's plain hash2 fold over the data with the given initial value)."""
+    words = multi_asset_order_words(signer_key, nonce, expiration_timestamp, system_id, give, receive,
+                                    conditions)
+    acc = words[0]
+    for w in words[1:]:
+        acc = hash_function(acc, w)
+    return acc
+
+
+# --------------------------------------------------------------------------------------------
 # Position leaf: services/perpetual/cairo/position/hash.cairo:22-74,
 # bounds services/perpetual/cairo/definitions/constants.cairo:11-38
 # --------------------------------------------------------------------------------------------
