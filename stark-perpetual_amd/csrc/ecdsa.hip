@@ -514,7 +514,7 @@ public_key_kernel(const uint64_t* __restrict__ pd, uint64_t* __restrict__ ox, ui
     return;
   }
   const xyzz A = gen_mul(d, gen, wbits, nwin);
-  const fe izzz = fe_inv(A.ZZZ);
+  const fe izzz = fe_inv_gcd(A.ZZZ);  // fixed-length: ZZZ depends on the private key
   const fe x = fe_mul(A.X, fe_sqr(fe_mul(A.ZZ, izzz)));
   const fe y = fe_mul(A.Y, izzz);
   st_u256(ox + 4 * e, fe_pack(fe_from_mont(x)));
@@ -530,7 +530,7 @@ __device__ __forceinline__ uint8_t sign_attempt(const u256& z, const u256& d, co
       !u256_lt(k, U256_N))
     return SP_SIGN_BAD_INPUT;
   const xyzz A = gen_mul(k, gen, wbits, nwin);
-  const fe izzz = fe_inv(A.ZZZ);
+  const fe izzz = fe_inv_gcd(A.ZZZ);  // fixed-length: ZZZ depends on the nonce
   const fe x = fe_mul(A.X, fe_sqr(fe_mul(A.ZZ, izzz)));
   const u256 r = fe_pack(fe_from_mont(x));
   if (u256_is_zero(r) || !u256_lt(r, U256_2P251)) return SP_SIGN_RETRY;  // :158-161

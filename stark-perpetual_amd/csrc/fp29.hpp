@@ -393,6 +393,51 @@ SP_HD int32_t divsteps_29(int32_t zeta, uint32_t f0, uint32_t g0, trans2x2& t) {
   return zeta;
 }
 
+// Variable-time form of the same 29 divsteps (the "var" variant of the safegcd implementations): runs
+// of zero bits of g are skipped with one count-trailing-zeros, and up to six low bits of g are
+// cancelled per iteration by adding the right multiple of f (w = -g / f mod 2^k, with 1/f mod 64 from
+// one Newton step on f itself, f * f = 1 mod 8).  Uses eta = -delta with delta starting at 1 (the
+// classic divstep; the half-delta start of the fixed-length version buys nothing here because the
+// callers stop as soon as g == 0).  Measured on random inputs (tools/sim notes in DESIGN.md): 7.5
+// iterations of ~38 instructions per 29 divsteps instead of 29 x 22, 18.4 batches per inversion.
+// Only for public data (hash outputs, signature verification).
+SP_HD int32_t divsteps_29_var(int32_t eta, uint32_t f0, uint32_t g0, trans2x2& t) {
+  uint32_t u = 1, v = 0, q = 0, r = 1;
+  uint32_t f = f0, g = g0;
+  int32_t i = LB;
+  for (;;) {
+    // sentinel at bit i: never count more zeros than divsteps left (1 <= i <= 29)
+    const int32_t zeros = (int32_t)__builtin_ctz(g | (0xffffffffu << i));
+    g >>= zeros;
+    u <<= zeros;
+    v <<= zeros;
+    eta -= zeros;
+    i -= zeros;
+    if (i == 0) break;
+    // g is odd here.  eta < 0: swap so that the divstep adds a multiple of the (new) f to g.
+    const bool neg = eta < 0;
+    const uint32_t nf = neg ? g : f, ng = neg ? 0u - f : g;
+    const uint32_t nu = neg ? q : u, nq = neg ? 0u - u : q;
+    const uint32_t nv = neg ? r : v, nr = neg ? 0u - v : r;
+    f = nf; g = ng; u = nu; q = nq; v = nv; r = nr;
+    eta = neg ? -eta : eta;
+    // cancel min(eta + 1, i, 6) low bits of g: after that many divsteps the sign of eta would flip
+    const int32_t lim = (eta + 1 < i) ? eta + 1 : i;
+    const uint32_t m = (0xffffffffu >> (32 - lim)) & 63u;
+    uint32_t x = f;            // f^-1 mod 8
+    x *= 2u - f * x;           // f^-1 mod 64
+    const uint32_t w = (g * (0u - x)) & m;
+    g += f * w;
+    q += u * w;
+    r += v * w;
+  }
+  t.u = (int32_t)u;
+  t.v = (int32_t)v;
+  t.q = (int32_t)q;
+  t.r = (int32_t)r;
+  return eta;
+}
+
 // (f, g) <- t (f, g) / 2^29 (exact)
 SP_HD void gcd_update_fg(fe& f, fe& g, const trans2x2& t) {
   const int64_t u = t.u, v = t.v, q = t.q, r = t.r;
@@ -494,6 +539,43 @@ SP_HD fe fe_inv_plain_gcd(const fe& x) {
   return r;
 }
 
+// Variable-time plain inverse (see divsteps_29_var): same contract as fe_inv_plain_gcd.
+SP_HD fe fe_inv_plain_gcd_var(const fe& x) {
+  fe d = FE_ZERO, e = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+  fe f = FE_P, g = x;
+  int32_t eta = -1;
+  // 26 * 29 = 754 >= 741 divsteps bound the classic (delta = 1) iteration for 256-bit inputs; random
+  // inputs are done after 18-19 batches.
+  for (int it = 0; it < 26; ++it) {
+    trans2x2 t;
+    eta = divsteps_29_var(eta, (uint32_t)f.l[0], (uint32_t)g.l[0], t);
+    gcd_update_de(d, e, t);
+    gcd_update_fg(f, g, t);
+    int32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) nz |= g.l[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__all(nz == 0)) break;
+#else
+    if (nz == 0) break;
+#endif
+  }
+  const int32_t sf = f.l[NL - 1] >> 31;  // -1 if f negative
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = (d.l[i] ^ sf) - sf;
+  r = fe_carry(r);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    if (r.l[8] < 0) r = fe_carry(fe_add(r, FE_P));
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (fe_geq_p_canon_limbs(r)) r = fe_carry(fe_sub(r, FE_P));
+  }
+  return r;
+}
+
 // R^3 mod p: turns the plain inverse of a Montgomery value (a R)^-1 = a^-1 R^-1 into a^-1 R.
 constexpr fe FE_R3 = {{0x18c6c71b, 0x1f4501b7, 0xd98e2e, 0x677ffcc, 0x3aa2b83, 0xd8c0006, 0xc2709f0,
                        0x13c0a666, 0x7bcc3}};
@@ -504,8 +586,18 @@ SP_HD fe fe_inv_gcd(const fe& a) {
   return fe_mul(fe_inv_plain_gcd(canon), FE_R3);
 }
 
-// The inversion used everywhere.
+SP_HD fe fe_inv_gcd_var(const fe& a) {
+  const fe canon = fe_canon(fe_mul(a, FE_ONE_M));
+  return fe_mul(fe_inv_plain_gcd_var(canon), FE_R3);
+}
+
+// The inversion used everywhere (public data only: hash outputs, signature verification; the
+// mod-N inversion used by signing, fn_inv, stays fixed-length).
+#ifndef SP_INV_CONST_TIME
+SP_HD fe fe_inv(const fe& a) { return fe_inv_gcd_var(a); }
+#else
 SP_HD fe fe_inv(const fe& a) { return fe_inv_gcd(a); }
+#endif
 
 // Legendre symbol test: a^((p-1)/2) == 1, (p-1)/2 = (2^59 + 17) * 2^191.  a must be non-zero.
 SP_HD bool fe_is_qr(const fe& a) {

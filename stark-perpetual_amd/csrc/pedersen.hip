@@ -270,7 +270,7 @@ __device__ __forceinline__ xyzz split_accumulate(const uint64_t* fx, const uint6
     o.ZZZ = shfl_xor_fe(acc.ZZZ, 1 << r);
     acc = xyzz_add(acc, o);
   }
-  {  // last round: only x = X / ZZ of the total is wanted (Y, ZZZ of the result are left stale)
+  if constexpr (LOG_L > 0) {  // last round: only x = X / ZZ of the total is wanted (Y, ZZZ are left stale)
     constexpr int r = LOG_L - 1;
     xyzz o;
     o.X = shfl_xor_fe(acc.X, 1 << r);
@@ -425,9 +425,15 @@ int get_scratch_public(size_t n, Scratch& s, hipStream_t st) {
   return SP_OK;
 }
 
+static size_t g_finish_lanes = getenv("STARKPERP_FINISH_LANES") ? (size_t)atoll(getenv("STARKPERP_FINISH_LANES")) : 65536;
+static size_t g_split_lanes = getenv("STARKPERP_SPLIT_LANES") ? (size_t)atoll(getenv("STARKPERP_SPLIT_LANES")) : 65536;
 static size_t finish_threads(size_t n) {
-  // K hashes share one inversion (~250 M): K = 32 costs ~8 M per hash of overhead.
-  size_t K = n / 65536;
+  // K hashes share one inversion (Montgomery's trick, 3 multiplications per extra hash).  The
+  // inversion is a ~14 k-instruction dependent chain of mostly 32-bit ops, and a SIMD is already
+  // saturated by ~1.3 such waves: with 1 < waves/SIMD < 2 the launch takes twice as long as with one
+  // wave per SIMD (measured: 81 920 inversions 68 us, 40 960 41 us).  So K is the smallest count that
+  // keeps the launch within one wave per SIMD (65 536 lanes), up to 32.
+  size_t K = (n + g_finish_lanes - 1) / g_finish_lanes;
   if (K < 1) K = 1;
   if (K > 32) K = 32;
   return (n + K - 1) / K;
@@ -452,27 +458,31 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
   const unsigned blocksA = (unsigned)((n + 255) / 256);
   const bool prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size();
   if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
-  // lanes per hash: fill ~2 waves per SIMD (131072 lanes) before falling back to one lane per hash;
-  // every lane needs at least two windows
+  // lanes per hash: a SIMD issues about one VALU instruction per 5 cycles whether one wave or eight
+  // live on it, so a launch takes ceil(waves / 1024) x (the dependent chain of one wave).  With
+  // 1 < waves/SIMD < 2 some SIMDs get two waves and the launch takes twice the chain (measured: 81 920
+  // lanes at L = 2 take 88 us, 40 960 hashes at L = 1 65 us), so the hashes are split over as many lanes
+  // as still fit ONE wave per SIMD (65 536 lanes).  Every lane needs at least two windows.
   const int w0 = c.plan.bits[0], log2e = c.plan.log2e, nwin = c.plan.nwin;
   int log_l = 0;
   bool fused = false;
   if (g_split_enabled) {
-    if (n <= 16384) log_l = 3;
-    else if (n <= 32768) log_l = 2;
-    else if (n <= 65536) log_l = 1;
+    if (n * 8 <= g_split_lanes) log_l = 3;
+    else if (n * 4 <= g_split_lanes) log_l = 2;
+    else if (n * 2 <= g_split_lanes) log_l = 1;
     while (log_l > 0 && nwin < (2 << log_l)) --log_l;
   }
-  if (log_l == 0) {
+  if (log_l == 0 && !(g_split_enabled && g_fuse_enabled && n <= 65536)) {
     hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped, w0,
                        log2e, nwin, s.X, s.ZZ, status, flag, src);
   } else {
     const unsigned blocks = (unsigned)(((n << log_l) + 255) / 256);
-    fused = g_fuse_enabled && (n << log_l) <= 65536;  // at most one wave per SIMD
+    fused = g_fuse_enabled && (n << log_l) <= 65536;  // at most one wave per SIMD: the inversion costs latency only
 #define SP_LAUNCH_SPLIT(LOGL, FUSEDV)                                                                      \
   hipLaunchKernelGGL((ped_accumulate_split_kernel<LOGL, FUSEDV>), dim3(blocks), dim3(256), 0, st, x, y, xs, \
                      ys, n, c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src, out, os)
-    if (log_l == 3) { if (fused) SP_LAUNCH_SPLIT(3, true); else SP_LAUNCH_SPLIT(3, false); }
+    if (log_l == 0) SP_LAUNCH_SPLIT(0, true);  // one lane per hash with its own inversion: saves the second launch
+    else if (log_l == 3) { if (fused) SP_LAUNCH_SPLIT(3, true); else SP_LAUNCH_SPLIT(3, false); }
     else if (log_l == 2) { if (fused) SP_LAUNCH_SPLIT(2, true); else SP_LAUNCH_SPLIT(2, false); }
     else { if (fused) SP_LAUNCH_SPLIT(1, true); else SP_LAUNCH_SPLIT(1, false); }
 #undef SP_LAUNCH_SPLIT

@@ -21,6 +21,8 @@ void t_fe_inv(const uint32_t* a, uint32_t* out) { from_m(fe_inv(to_m(a)), out); 
 void t_fe_inv_fermat(const uint32_t* a, uint32_t* out) { from_m(fe_inv_fermat(to_m(a)), out); }
 void t_fn_inv_fermat(const uint32_t* a, uint32_t* out) { from_mn(fn_inv_fermat(to_mn(a)), out); }
 void t_fe_inv_gcd(const uint32_t* a, uint32_t* out) { from_m(fe_inv_gcd(to_m(a)), out); }
+void t_fe_inv_gcd_var(const uint32_t* a, uint32_t* out) { from_m(fe_inv_gcd_var(to_m(a)), out); }
+void t_fe_inv_plain_gcd_var(const uint32_t* a, uint32_t* out) { store_plain(fe_inv_plain_gcd_var(load_plain(a)), out); }
 void t_fe_inv_plain_gcd(const uint32_t* a, uint32_t* out) { store_plain(fe_inv_plain_gcd(load_plain(a)), out); }
 int t_fe_is_qr(const uint32_t* a) { return fe_is_qr(to_m(a)) ? 1 : 0; }
 // (a - b) * (c + d) - e*f : exercises lazy add/sub feeding products

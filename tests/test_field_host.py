@@ -104,6 +104,24 @@ def test_fe_inv_gcd(shim):
     assert I(out) == 0
 
 
+def test_fe_inv_gcd_variable_time(shim):
+    """divsteps_29_var (ctz jumps + six-bit cancellation, delta = 1 start): the inversion every hash and
+    verification goes through."""
+    rng = random.Random(8)
+    out = (ctypes.c_uint32 * 8)()
+    vals = [1, 2, 3, 4, 5, P - 1, P - 2, 2**251, 2**192 + 1, (P + 1) // 2, 2**29, 2**29 - 1, 2**58 + 1, P - 2**29]
+    vals += [2**k for k in range(0, 252, 7)] + [P - 2**k for k in range(1, 251, 11)]
+    vals += [rng.randrange(1, P) for _ in range(3000)] + [rng.randrange(1, 2**64) for _ in range(200)]
+    for a in vals:
+        shim.t_fe_inv_plain_gcd_var(W(a), out)
+        assert I(out) == pow(a, -1, P), hex(a)
+    for a in vals[:300]:
+        shim.t_fe_inv_gcd_var(W(a), out)
+        assert I(out) == pow(a, -1, P), hex(a)
+    shim.t_fe_inv_plain_gcd_var(W(0), out)
+    assert I(out) == 0
+
+
 def test_fe_lazy_expr(shim):
     rng = random.Random(3)
     out = (ctypes.c_uint32 * 8)()
