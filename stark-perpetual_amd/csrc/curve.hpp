@@ -70,7 +70,9 @@ SP_HD void xyzz_madd_x_only(const xyzz& a, const aff& q, fe& X3, fe& ZZ3) {
 // Sum of two affine points -> XYZZ ("mmadd-2008-s", 4M + 2S).
 SP_HD xyzz xyzz_mmadd(const aff& a, const aff& b) {
   const fe P = fe_sub(b.x, a.x);
-  const fe R = fe_sub(b.y, a.y);
+  // callers pass table entries whose y may be negated (signed windows): b.y - a.y can reach B = 2 and
+  // nine maximal products of its square would exceed the 64-bit column budget - carry it to N
+  const fe R = fe_carry(fe_sub(b.y, a.y));
   const fe PP = fe_sqr(P);
   const fe PPP = fe_mul(P, PP);
   const fe Q = fe_mul(a.x, PP);

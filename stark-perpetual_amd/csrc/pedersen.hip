@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "context.hpp"
+#include "quad.hpp"
 
 #ifndef SP_ACC_WAVES
 #define SP_ACC_WAVES 1
@@ -330,35 +331,146 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
   if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
 }
 
-// Kernel B: thread t owns elements t, t+T, t+2T, ...; one inversion per thread.
+// Kernel Q, the latency path of the small levels: 4 * QUADS lanes (QUADS = 2, 4 or 8 DPP quads) share one
+// hash.  Window g of the plan belongs to quad g mod QUADS.  A quad adds its first four windows pairwise
+// (two affine sums at once on its two lane pairs, then one quad-parallel addition), its further windows
+// one at a time (each a quad-parallel addition with an affine P2), and log2(QUADS) butterfly rounds over
+// lane ^ 4, ^ 8, ^ 16 (ds_swizzle, no LDS memory) leave the total on every quad.  With 8 quads and
+// 16 <= nwin <= 32 that is 3 + 4 + 4 + 4 + 3 = 18 rounds of one field multiplication instead of the ~62
+// dependent multiplications of the 8-lane split kernel; 4 quads take the same 18 rounds up to 20
+// windows.  Every lane then inverts ZZ (all copies are identical; a wave with few active lanes runs the
+// same code 4x slower, tools/ubench/inv_lanes.hip) and lane 0 writes the affine x.  One launch per
+// level, no scratch.  Requires nwin >= 2 * QUADS (every quad owns at least one pair).
+template <int LOG_Q>
+__global__ void __launch_bounds__(256)
+ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride, size_t ystride,
+                size_t n, const aff_packed* __restrict__ ped, int w0, int log2e, int nwin,
+                uint8_t* __restrict__ status, unsigned* __restrict__ flag, const int2* __restrict__ src,
+                uint64_t* __restrict__ out, size_t ostride) {
+  constexpr int QUADS = 1 << LOG_Q, LANES = 4 * QUADS;
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e_raw = gt / LANES;
+  const int g = (int)(gt % LANES), q = g >> 2, k = g & 3;
+  const bool active = e_raw < n;
+  const size_t e = active ? e_raw : n - 1;  // clamp: whole groups stay convergent for the lane exchanges
+  const uint64_t *fx, *fy;
+  operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
+  auto entry = [&](int w) {
+    const window_ref r =
+        window_entry(ped, w, window_from_memory(fx, fy, window_start(w, w0, log2e), window_width(w, w0, log2e)), w0, log2e);
+    return signed_aff(ld_raw(r.entry), r.negative);
+  };
+  const int cnt = nwin / QUADS + (q < nwin % QUADS ? 1 : 0);  // windows of this quad: q, q + QUADS, q + 2 QUADS, ...
+  const int max_cnt = (nwin + QUADS - 1) / QUADS;
+  // lanes 0,1: pair A = windows (q, q + QUADS); lanes 2,3: pair B = (q + 2 QUADS, q + 3 QUADS) where they exist
+  const bool upper = (k & 2) != 0;
+  const bool odd = (k & 1) != 0;
+  const int wa = (upper && cnt >= 3) ? q + 2 * QUADS : q;
+  const int wb = (upper && cnt >= 4) ? q + 3 * QUADS : q + QUADS;
+  const aff pa = entry(wa), pb = entry(wb);
+  qpt p = qmmadd(pa.x, pa.y, pb.x, pb.y, k);
+  if (upper && cnt == 3) {  // a lone third window: P2 = that affine point
+    p.a = odd ? pa.y : pa.x;
+    p.b = FE_ONE_M;
+  }
+  qpt s = qadd<false>(p, k);
+  if (cnt == 2) {  // no pair B: the quad's sum is P1 itself
+    s.a = fe_dpp<quad_perm(0, 1, 0, 1)>(p.a);
+    s.b = fe_dpp<quad_perm(0, 1, 0, 1)>(p.b);
+  }
+  for (int j = 4; j < max_cnt; ++j) {  // further windows of the quad, one quad-parallel addition each
+    const aff pj = entry(j < cnt ? q + j * QUADS : q);
+    qpt t;
+    t.a = fe_sel(upper, odd ? pj.y : pj.x, s.a);
+    t.b = fe_sel(upper, FE_ONE_M, s.b);
+    const qpt u = qadd<false>(t, k);
+    if (j < cnt) s = u;
+  }
+  // butterfly over the quads: own sum is P1, the partner's P2; the last round yields X3 in .a and
+  // ZZ3 in .b of every lane
+#define SP_BUTTERFLY(XORV, LAST)                               \
+  {                                                            \
+    qpt t;                                                     \
+    t.a = fe_sel(upper, fe_swizzle_xor<XORV>(s.a), s.a);       \
+    t.b = fe_sel(upper, fe_swizzle_xor<XORV>(s.b), s.b);       \
+    s = qadd<LAST>(t, k);                                      \
+  }
+  if constexpr (LOG_Q == 1) SP_BUTTERFLY(4, true)
+  if constexpr (LOG_Q == 2) { SP_BUTTERFLY(4, false) SP_BUTTERFLY(8, true) }
+  if constexpr (LOG_Q == 3) { SP_BUTTERFLY(4, false) SP_BUTTERFLY(8, false) SP_BUTTERFLY(16, true) }
+#undef SP_BUTTERFLY
+  uint8_t st = SP_HASH_OK;
+  fe zz = s.b;
+  if (fe_is_zero(zz)) {  // exceptional addition happened (signature.py:313 territory)
+    zz = FE_ONE_M;
+    st = SP_HASH_UNHASHABLE;
+  }
+  const u256 xa_plain = fe_pack(fe_from_mont(fe_mul(s.a, fe_inv(zz))));
+  if (!active || g != 0) return;
+  if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
+  st_u256(out + 4 * e * ostride, xa_plain);
+  if (status) status[e] = st;
+  if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
+}
+
+// Kernel B: thread t owns elements t, t+T, t+2T, ...; one inversion per thread (Montgomery's trick).
+// Launched with at most one wave per SIMD when it can be (finish_threads), so nothing hides a load:
+// both passes are software-pipelined by hand (the operands of element j +- 1 are requested before
+// element j is multiplied), the loops are NOT unrolled (a fully unrolled K = 12 body exceeds the
+// instruction cache and ran 15 % slower than this loop), and the per-element zero test is replaced by
+// one test of the thread's total product: a zero ZZ - an exceptional addition, signature.py:313
+// territory - makes the total zero, and only then the thread re-walks its elements.
 __global__ void __launch_bounds__(256)
 ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int32_t* __restrict__ sPre,
                   size_t n, size_t T, uint64_t* __restrict__ out, size_t ostride,
                   uint8_t* __restrict__ status, unsigned* __restrict__ flag) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
-  fe run = FE_ONE_M;
-  for (size_t e = t; e < n; e += T) {
-    fe z = load_limbs(sZZ, n, e);
-    if (fe_is_zero(z)) {  // exceptional addition happened (signature.py:313 territory)
-      z = FE_ONE_M;
-      store_limbs(sZZ, n, e, z);
-      if (status) status[e] = SP_HASH_UNHASHABLE;
-      if (flag) atomicOr(flag, (unsigned)SP_HASH_UNHASHABLE);
-    }
-    store_limbs(sPre, n, e, run);
-    run = fe_mul(run, z);
-  }
-  fe inv = fe_inv(run);
   const size_t cnt = (n - t + T - 1) / T;  // number of elements owned
+  fe run = FE_ONE_M;
+  {
+    fe znext = load_limbs(sZZ, n, t);
+#pragma unroll 1
+    for (size_t j = 0; j < cnt; ++j) {
+      const size_t e = t + j * T;
+      const fe z = znext;
+      if (j + 1 < cnt) znext = load_limbs(sZZ, n, e + T);
+      store_limbs(sPre, n, e, run);
+      run = fe_mul(run, z);
+    }
+  }
+  if (fe_is_zero(run)) {  // rare: find the zero factors, flag them, and redo the products without them
+    run = FE_ONE_M;
+#pragma unroll 1
+    for (size_t e = t; e < n; e += T) {
+      fe z = load_limbs(sZZ, n, e);
+      if (fe_is_zero(z)) {
+        z = FE_ONE_M;
+        store_limbs(sZZ, n, e, z);
+        if (status) status[e] = SP_HASH_UNHASHABLE;
+        if (flag) atomicOr(flag, (unsigned)SP_HASH_UNHASHABLE);
+      }
+      store_limbs(sPre, n, e, run);
+      run = fe_mul(run, z);
+    }
+  }
+  // the last element's operands travel while the inversion runs
+  size_t e = t + (cnt - 1) * T;
+  fe zn = load_limbs(sZZ, n, e), pn = load_limbs(sPre, n, e), xn = load_limbs(sX, n, e);
+  fe inv = fe_inv(run);
+#pragma unroll 1
   for (size_t j = cnt; j-- > 0;) {
-    const size_t e = t + j * T;
-    const fe z = load_limbs(sZZ, n, e);
-    const fe pre = load_limbs(sPre, n, e);
+    const fe z = zn, pre = pn, xv = xn;
+    const size_t cur = t + j * T;
+    if (j > 0) {
+      zn = load_limbs(sZZ, n, cur - T);
+      pn = load_limbs(sPre, n, cur - T);
+      xn = load_limbs(sX, n, cur - T);
+    }
     const fe zinv = fe_mul(inv, pre);
     inv = fe_mul(inv, z);
-    const fe xa = fe_mul(load_limbs(sX, n, e), zinv);  // Montgomery form of X/ZZ
-    st_u256(out + 4 * e * ostride, fe_pack(fe_from_mont(xa)));
+    const fe xa = fe_mul(xv, zinv);  // Montgomery form of X/ZZ
+    st_u256(out + 4 * cur * ostride, fe_pack(fe_from_mont(xa)));
   }
 }
 
@@ -402,6 +514,9 @@ struct KernelProfile {
 static KernelProfile g_prof;
 static bool g_split_enabled = getenv("STARKPERP_NO_SPLIT") == nullptr;  // A/B switches
 static bool g_fuse_enabled = getenv("STARKPERP_NO_FUSE") == nullptr;
+static bool g_quad_enabled = getenv("STARKPERP_NO_QUAD") == nullptr;
+static bool g_quad2_enabled = getenv("STARKPERP_QUAD2") != nullptr;
+static size_t g_quad_max = getenv("STARKPERP_QUAD_MAX") ? (size_t)atoll(getenv("STARKPERP_QUAD_MAX")) : 2048;
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
   int32_t *X, *ZZ, *Pre;
@@ -456,7 +571,10 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
   if (n == 0) return SP_OK;
   Context& c = ctx();
   const unsigned blocksA = (unsigned)((n + 255) / 256);
-  const bool prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size();
+  // sp_profile_begin/_end time the DOMINANT kernel only (ped_accumulate_kernel, the one-lane-per-hash
+  // bulk launches of n > 65536 hashes): an event pair around every small launch of a tree costs ~5 us
+  // each, 7 % of a 20-tree forest
+  const bool prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size() && n > 65536;
   if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   // lanes per hash: a SIMD issues about one VALU instruction per 5 cycles whether one wave or eight
   // live on it, so a launch takes ceil(waves / 1024) x (the dependent chain of one wave).  With
@@ -472,7 +590,25 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
     else if (n * 2 <= g_split_lanes) log_l = 1;
     while (log_l > 0 && nwin < (2 << log_l)) --log_l;
   }
-  if (log_l == 0 && !(g_split_enabled && g_fuse_enabled && n <= 65536)) {
+  // quad-parallel latency kernels while the level fits one wave per SIMD: 8 quads per hash up to 2048
+  // hashes, 4 up to 4096 (same 18 rounds while nwin <= 20), 2 up to 8192
+  int log_q = 0;
+  if (g_quad_enabled && nwin <= 64) {
+    if (n <= g_quad_max && nwin >= 16) log_q = 3;
+    else if (n <= 2 * g_quad_max && nwin >= 8) log_q = 2;
+    else if (n <= 4 * g_quad_max && nwin >= 4 && g_quad2_enabled) log_q = 1;
+  }
+  if (log_q != 0) {
+    const unsigned blocks = (unsigned)(((n * 4 << log_q) + 255) / 256);
+#define SP_LAUNCH_QUAD(LOGQ)                                                                                   \
+  hipLaunchKernelGGL((ped_quad_kernel<LOGQ>), dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n, c.ped, w0, log2e, \
+                     nwin, status, flag, src, out, os)
+    if (log_q == 3) SP_LAUNCH_QUAD(3);
+    else if (log_q == 2) SP_LAUNCH_QUAD(2);
+    else SP_LAUNCH_QUAD(1);
+#undef SP_LAUNCH_QUAD
+    fused = true;
+  } else if (log_l == 0 && !(g_split_enabled && g_fuse_enabled && n <= 65536)) {
     hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped, w0,
                        log2e, nwin, s.X, s.ZZ, status, flag, src);
   } else {
