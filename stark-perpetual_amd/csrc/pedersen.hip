@@ -317,7 +317,9 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
       zz = FE_ONE_M;
       st = SP_HASH_UNHASHABLE;
     }
-    xa_plain = fe_pack(fe_from_mont(fe_mul(acc.X, fe_inv(zz))));
+    // groups of >= 4 lanes cover whole DPP quads holding the same sum: the four lanes share one inversion
+    const fe zinv = LOG_L >= 2 ? fe_inv_quad(zz, (int)(threadIdx.x & 3)) : fe_inv(zz);
+    xa_plain = fe_pack(fe_from_mont(fe_mul(acc.X, zinv)));
   }
   if (!active || sub != 0) return;
   if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
@@ -346,10 +348,12 @@ __global__ void __launch_bounds__(256)
 ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride, size_t ystride,
                 size_t n, const aff_packed* __restrict__ ped, int w0, int log2e, int nwin,
                 uint8_t* __restrict__ status, unsigned* __restrict__ flag, const int2* __restrict__ src,
-                uint64_t* __restrict__ out, size_t ostride) {
+                uint64_t* __restrict__ out, size_t ostride, int dup) {
   constexpr int QUADS = 1 << LOG_Q, LANES = 4 * QUADS;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t e_raw = gt / LANES;
+  // dup: 2^dup lane groups compute the same hash, so that a wave holds ONE value while the level is small
+  // enough anyway (the variable-time inversion runs as long as the slowest value of the wave)
+  const size_t e_raw = gt / ((size_t)LANES << dup);
   const int g = (int)(gt % LANES), q = g >> 2, k = g & 3;
   const bool active = e_raw < n;
   const size_t e = active ? e_raw : n - 1;  // clamp: whole groups stay convergent for the lane exchanges
@@ -405,7 +409,7 @@ ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, 
     zz = FE_ONE_M;
     st = SP_HASH_UNHASHABLE;
   }
-  const u256 xa_plain = fe_pack(fe_from_mont(fe_mul(s.a, fe_inv(zz))));
+  const u256 xa_plain = fe_pack(fe_from_mont(fe_mul(s.a, fe_inv_quad(zz, k))));
   if (!active || g != 0) return;
   if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
   st_u256(out + 4 * e * ostride, xa_plain);
@@ -515,7 +519,7 @@ static KernelProfile g_prof;
 static bool g_split_enabled = getenv("STARKPERP_NO_SPLIT") == nullptr;  // A/B switches
 static bool g_fuse_enabled = getenv("STARKPERP_NO_FUSE") == nullptr;
 static bool g_quad_enabled = getenv("STARKPERP_NO_QUAD") == nullptr;
-static bool g_quad2_enabled = getenv("STARKPERP_QUAD2") != nullptr;
+static bool g_quad2_enabled = getenv("STARKPERP_NO_QUAD2") == nullptr;
 static size_t g_quad_max = getenv("STARKPERP_QUAD_MAX") ? (size_t)atoll(getenv("STARKPERP_QUAD_MAX")) : 2048;
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
@@ -599,10 +603,12 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
     else if (n <= 4 * g_quad_max && nwin >= 4 && g_quad2_enabled) log_q = 1;
   }
   if (log_q != 0) {
-    const unsigned blocks = (unsigned)(((n * 4 << log_q) + 255) / 256);
+    int dup = 0;
+    while ((4 << (log_q + dup)) < 64 && ((n * 4) << (log_q + dup + 1)) <= 65536) ++dup;  // up to one hash per wave
+    const unsigned blocks = (unsigned)((((n * 4) << (log_q + dup)) + 255) / 256);
 #define SP_LAUNCH_QUAD(LOGQ)                                                                                   \
   hipLaunchKernelGGL((ped_quad_kernel<LOGQ>), dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n, c.ped, w0, log2e, \
-                     nwin, status, flag, src, out, os)
+                     nwin, status, flag, src, out, os, dup)
     if (log_q == 3) SP_LAUNCH_QUAD(3);
     else if (log_q == 2) SP_LAUNCH_QUAD(2);
     else SP_LAUNCH_QUAD(1);

@@ -115,4 +115,80 @@ __device__ __forceinline__ qpt qmmadd(const fe& x1, const fe& y1, const fe& x2, 
   return r;
 }
 
+// ---- inversion on a quad ---------------------------------------------------------------------------
+// The variable-time divsteps inversion (fp29.hpp fe_inv_plain_gcd_var) spends a third of its time applying
+// the 2x2 transition matrix of every 29-divstep batch to the four 9-limb vectors f, g (exactly) and
+// d, e (modulo p): 72 multiply-adds and four carry chains per batch.  When the four lanes of a quad
+// invert the SAME value (every lane of a quad-kernel group holds the same sum) each lane keeps ONE of
+// the four vectors - lane 0: f, 1: g, 2: d, 3: e - and computes only its own row: 18 multiply-adds and
+// one carry chain.  The batch of divsteps itself is computed by all four lanes from the broadcast low
+// limbs of f and g.
+//
+// own <- (c_own * own + c_par * partner [+ m p]) / 2^29 with (c_own, c_par) = (u, v) on the f and d lanes,
+// (r, q) on the g and e lanes; m makes the d / e rows divisible (p = 1 mod 2^29), as in gcd_update_de.
+__device__ __forceinline__ void quad_gcd_update(fe& own, const trans2x2& t, int k) {
+  const bool odd = (k & 1) != 0, modular = (k & 2) != 0;
+  const fe par = fe_dpp<quad_perm(1, 0, 3, 2)>(own);
+  const int32_t co = odd ? t.r : t.u, cp = odd ? t.q : t.v;
+  const int64_t a = co, b = cp;
+  const int32_t so = own.l[NL - 1] >> 31, sp_ = par.l[NL - 1] >> 31;
+  int32_t m = (co & so) + (cp & sp_);
+  int64_t c = a * own.l[0] + b * par.l[0];
+  m -= (int32_t)(((uint32_t)c + (uint32_t)m) & LMASK);
+  m = modular ? m : 0;  // the f, g rows divide exactly
+  c += m;
+  c >>= LB;
+  fe r;
+#pragma unroll
+  for (int i = 1; i < NL; ++i) {
+    c += a * own.l[i] + b * par.l[i];
+    if (i == 6) c += (int64_t)P6 * m;
+    if (i == 8) c += (int64_t)P8 * m;
+    r.l[i - 1] = (int32_t)((uint32_t)c & LMASK);
+    c >>= LB;
+  }
+  r.l[NL - 1] = (int32_t)c;
+  fe_pin(r);
+  own = r;
+}
+
+// x canonical in [0, p), identical on the four lanes of every quad -> canonical x^-1 mod p on every lane.
+__device__ __forceinline__ fe fe_inv_plain_quad(const fe& x, int k) {
+  const fe one = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+  fe own = k == 0 ? FE_P : (k == 1 ? x : (k == 2 ? FE_ZERO : one));  // f | g | d | e
+  int32_t eta = -1;
+  for (int it = 0; it < 26; ++it) {
+    const uint32_t f0 = (uint32_t)__builtin_amdgcn_mov_dpp(own.l[0], quad_perm(0, 0, 0, 0), 0xF, 0xF, true);
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_mov_dpp(own.l[0], quad_perm(1, 1, 1, 1), 0xF, 0xF, true);
+    trans2x2 t;
+    eta = divsteps_29_var(eta, f0, g0, t);
+    quad_gcd_update(own, t, k);
+    int32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) nz |= own.l[i];
+    if (__all(k != 1 || nz == 0)) break;  // g == 0 on every quad of the wave
+  }
+  const int32_t sf = __builtin_amdgcn_mov_dpp(own.l[NL - 1], quad_perm(0, 0, 0, 0), 0xF, 0xF, true) >> 31;
+  const fe d = fe_dpp<quad_perm(2, 2, 2, 2)>(own);
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = (d.l[i] ^ sf) - sf;
+  r = fe_carry(r);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    if (r.l[8] < 0) r = fe_carry(fe_add(r, FE_P));
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (fe_geq_p_canon_limbs(r)) r = fe_carry(fe_sub(r, FE_P));
+  }
+  return r;
+}
+
+// Montgomery-form inverse; a (N-form, |value| < 16p) must be identical on the four lanes of every quad.
+__device__ __forceinline__ fe fe_inv_quad(const fe& a, int k) {
+  const fe canon = fe_canon(fe_mul(a, FE_ONE_M));
+  return fe_mul(fe_inv_plain_quad(canon, k), FE_R3);
+}
+
 }  // namespace sp
