@@ -56,6 +56,9 @@ extern "C" {
 #define SP_VERIFY_ASSERT_W 4     /* signature.py:226  assert 1 <= w < 2**251 */
 #define SP_VERIFY_ASSERT_MSG 5   /* signature.py:227  assert 0 <= msg_hash < 2**251 */
 #define SP_VERIFY_ASSERT_CURVE 6 /* signature.py:241  assert is_point_on_curve */
+#define SP_VERIFY_STALE_SLOT 7   /* sp_ecdsa_verify_keyed_dev only: the slot handle is not from the current
+                                    cache generation (handed out before sp_ecdsa_key_cache_reset) or was never
+                                    handed out; no verdict was computed for this item */
 
 /* per-item status of sp_ecdsa_sign_* (signature.py:137-173) */
 #define SP_SIGN_OK 0
@@ -162,9 +165,9 @@ int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64
 int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                                 const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n);
 int sp_ecdsa_key_cache_info(size_t* capacity, size_t* used);
-/* Empties the cache after waiting for the device.  Every slot index handed out before the reset is
- * invalid afterwards (it may come to name another key): callers of sp_ecdsa_verify_keyed_dev must
- * register their keys again. */
+/* Empties the cache after waiting for the device and starts a new slot generation.  A slot handle is
+ * (generation << 24) | index; handles from before the reset are answered with SP_VERIFY_STALE_SLOT by
+ * sp_ecdsa_verify_keyed_dev (never with another key's verdict): callers register their keys again. */
 int sp_ecdsa_key_cache_reset(void);
 /* One signing attempt per item with caller-supplied nonce k (host RFC 6979, signature.py:117-134):
  * the body of the loop at signature.py:146-173. */

@@ -273,11 +273,22 @@ def commit_rows(columns):
 import hashlib as _hashlib
 
 
-def transcript_challenge(label, *values, modulus=P):
-    h = _hashlib.sha256(label.encode())
-    for v in values:
-        h.update(int(v).to_bytes(32, "big"))
-    return int.from_bytes(h.digest() + _hashlib.sha256(h.digest()).digest(), "big") % modulus
+class Transcript:
+    """Twin of starkperp.stark.Transcript: chained SHA-256 state, challenges drawn from it."""
+
+    def __init__(self, air, n, shift, seed, public_inputs=()):
+        self.state = _hashlib.sha256(b"starkperp/airfri/v2").digest()
+        self.absorb("statement:" + air, n, shift, seed, len(public_inputs), *public_inputs)
+
+    def absorb(self, label, *values):
+        h = _hashlib.sha256(self.state + label.encode())
+        for v in values:
+            h.update(int(v).to_bytes(32, "big"))
+        self.state = h.digest()
+
+    def challenge(self, label, index=0, modulus=P):
+        d = _hashlib.sha256(self.state + label.encode() + int(index).to_bytes(8, "big")).digest()
+        return int.from_bytes(d + _hashlib.sha256(d).digest(), "big") % modulus
 
 
 def _root_from_path(leaf, index, path, hash2):
@@ -300,8 +311,17 @@ def verify_proof(proof, hash2=R.pedersen_hash, final_log=6, air=None):
     n_layers = log_m - final_log
     if len(roots) != n_layers or len(final) != 1 << final_log:
         return False, "shape"
-    alphas = [transcript_challenge("alpha", seed, root_t, k) for k in range(spec["n_constraints"])]
-    betas = [transcript_challenge("beta", seed, roots[k], k + 1) for k in range(n_layers)]
+    # the challenges are re-derived from the chained transcript: statement, trace root, then every
+    # layer root in order, then the final layer
+    air_name = air or proof.get("air", "pedersen")
+    tr = Transcript(air_name, n, shift, seed, proof.get("public_inputs", ()))
+    tr.absorb("trace_root", root_t)
+    alphas = [tr.challenge("alpha", k) for k in range(spec["n_constraints"])]
+    betas = []
+    for k in range(n_layers):
+        tr.absorb("layer_root", roots[k])
+        betas.append(tr.challenge("beta", k + 1))
+    tr.absorb("final_layer", *final)
     per = periodic_lde(n, shift, air or proof.get("air", "pedersen"))
     w = root_of_unity(log_m)
     zinv = [pow((pow(shift, n, P) * pow(w, n * k, P) - 1) % P, -1, P) for k in range(BLOWUP)]
@@ -312,7 +332,7 @@ def verify_proof(proof, hash2=R.pedersen_hash, final_log=6, air=None):
     if not poly_degree_bound_check(final, fshift, (3 * n >> n_layers) - 1):
         return False, "final layer degree"
     for qi, q in enumerate(proof["queries"]):
-        j = transcript_challenge("query", seed, root_t, *roots, *final, qi, modulus=m // 2)
+        j = tr.challenge("query", qi, modulus=m // 2)
         if q["index"] != j:
             return False, "query index"
         # trace openings: rows j, j+4, j+m/2, j+m/2+4

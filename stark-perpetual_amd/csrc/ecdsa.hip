@@ -291,6 +291,11 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
 // the column addition detects Z3 == 0 and takes the doubling / infinity branch explicitly.
 constexpr int COMB_ENTRIES = 128;
 constexpr int COMB_ROW_POINTS = 15;  // Q_0, 2Q_0, Q_1, 2Q_1, ..., Q_6, 2Q_6, Q_7
+// A slot handle is (generation << 24) | index: sp_ecdsa_key_cache_reset starts a new generation, so a
+// handle from before the reset can never name another key's table - the kernel answers
+// SP_VERIFY_STALE_SLOT for it.  Generations run 1..255 and wrap (a handle would have to survive 255
+// resets to alias).
+constexpr uint32_t SLOT_INDEX_BITS = 24, SLOT_INDEX_MASK = (1u << SLOT_INDEX_BITS) - 1u;
 constexpr uint8_t KEY_EMPTY = 0, KEY_XONLY = 1, KEY_POINT = 2, KEY_INVALID_X = 3, KEY_OFF_CURVE = 4;
 
 __device__ __forceinline__ void st_aff(aff_packed* dst, const fe& x_m, const fe& y_m) {
@@ -479,14 +484,18 @@ ecdsa_verify_keyed_kernel(const uint64_t* __restrict__ pz, const uint64_t* __res
                           uint8_t* __restrict__ result, size_t n, const aff_packed* __restrict__ gen,
                           int wbits, int nwin, const aff_packed* __restrict__ key_tab,
                           const uint64_t* __restrict__ key_c, const uint8_t* __restrict__ key_flag,
-                          uint32_t n_slots) {
+                          uint32_t n_slots, uint32_t generation) {
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) e = n - 1;  // redundant copy of the last item, see ecdsa_verify_kernel
   verify_scalars v;
   const uint8_t code = verify_prepare(pz, pr, ps, e, v);
   if (code != VERIFY_CONTINUE) { result[e] = code; return; }
-  const uint32_t slot = slots[e];
-  const uint8_t flag = slot < n_slots ? key_flag[slot] : KEY_EMPTY;
+  const uint32_t handle = slots[e], slot = handle & SLOT_INDEX_MASK;
+  if ((handle >> SLOT_INDEX_BITS) != generation || slot >= n_slots) {  // from before a cache reset, or never handed out
+    result[e] = SP_VERIFY_STALE_SLOT;
+    return;
+  }
+  const uint8_t flag = key_flag[slot];
   if (flag == KEY_OFF_CURVE) { result[e] = SP_VERIFY_ASSERT_CURVE; return; }  // signature.py:241
   if (flag != KEY_XONLY && flag != KEY_POINT) { result[e] = SP_VERIFY_FALSE; return; }  // :232-235
   if (v.z_zero) { result[e] = SP_VERIFY_FALSE; return; }
@@ -610,7 +619,7 @@ static std::map<hipStream_t, sp::DeviceBuffer> g_verify_tab;
 // Key-table cache (see "Key tables" above): slot -> 128-entry comb table, curve-model constant c and
 // a flag, all in HBM; the host keeps the (qx, qy | x-only) -> slot map.
 struct KeyId {
-  std::array<uint64_t, 8> w;
+  std::array<uint64_t, 9> w;  // qx, qy (zero for an x-only key), has_y
   bool operator==(const KeyId& o) const { return w == o.w; }
 };
 struct KeyIdHash {
@@ -623,16 +632,37 @@ struct KeyIdHash {
 struct KeyCache {
   sp::DeviceBuffer tab, c, flag, stage;
   size_t capacity = 0, used = 0;
+  uint32_t generation = 1;
   std::unordered_map<KeyId, uint32_t, KeyIdHash> slot_of;
 };
 static KeyCache g_keys;
 static std::unordered_map<KeyId, uint8_t, KeyIdHash> g_seen_keys;  // unregistered keys met before (verify policy)
+// value mod p of a 256-bit little-endian integer (host; at most 31 subtractions, keys are < p in practice)
+static void reduce_mod_p(const uint64_t* in, uint64_t* out) {
+  static const uint64_t P[4] = {1ull, 0ull, 0ull, 0x0800000000000011ull};
+  for (int i = 0; i < 4; ++i) out[i] = in[i];
+  for (;;) {
+    bool ge = true;
+    for (int i = 3; i >= 0; --i) {
+      if (out[i] != P[i]) { ge = out[i] > P[i]; break; }
+    }
+    if (!ge) return;
+    unsigned __int128 borrow = 0;
+    for (int i = 0; i < 4; ++i) {
+      const unsigned __int128 d = (unsigned __int128)out[i] - P[i] - borrow;
+      out[i] = (uint64_t)d;
+      borrow = (d >> 64) & 1;
+    }
+  }
+}
+// Identity of a key in the cache: coordinates reduced mod p (x and x + p are the same key to every
+// kernel) and an explicit point / x-only flag (no sentinel y that a caller's point key could collide with).
 static KeyId key_id(const uint64_t* qx, const uint64_t* qy) {
   KeyId k;
-  for (int i = 0; i < 4; ++i) {
-    k.w[i] = qx[i];
-    k.w[4 + i] = qy ? qy[i] : ~(uint64_t)0;  // no curve point has y = 2^256 - 1: marks an x-only key
-  }
+  reduce_mod_p(qx, &k.w[0]);
+  if (qy) reduce_mod_p(qy, &k.w[4]);
+  else for (int i = 0; i < 4; ++i) k.w[4 + i] = 0;
+  k.w[8] = qy ? 1 : 0;
   return k;
 }
 namespace sp {
@@ -695,6 +725,7 @@ static int key_cache_ready() {
     const long long v = atoll(env);
     if (v > 0) cap = (size_t)v;
   }
+  if (cap > SLOT_INDEX_MASK) cap = SLOT_INDEX_MASK;  // a slot handle carries 24 index bits
   SP_HIP(g_keys.tab.reserve(cap * COMB_ENTRIES * sizeof(aff_packed)));
   SP_HIP(g_keys.c.reserve(cap * 32));
   SP_HIP(g_keys.flag.reserve(cap));
@@ -769,7 +800,7 @@ int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uin
       fh.push_back(qy ? 1 : 0);
       fs.push_back(slot);
     }
-    slots[i] = it->second;
+    slots[i] = (g_keys.generation << SLOT_INDEX_BITS) | it->second;
   }
   rc = build_key_tables(fx, fy, fh, fs);
   if (rc != SP_OK) {  // leave no slot behind whose table was never built
@@ -793,6 +824,7 @@ int sp_ecdsa_key_cache_reset(void) {
   SP_HIP(hipDeviceSynchronize());
   g_keys.slot_of.clear();
   g_keys.used = 0;
+  g_keys.generation = g_keys.generation % 255u + 1u;
   if (g_keys.capacity) SP_HIP(hipMemset(g_keys.flag.ptr, 0, g_keys.capacity));
   return SP_OK;
 }
@@ -806,7 +838,8 @@ int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64
   if (g_keys.capacity == 0) { set_error("no key has been registered"); return SP_ERR_BAD_ARGUMENT; }
   hipLaunchKernelGGL(ecdsa_verify_keyed_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z,
                      r, s, slots, result, n, c.gen, c.wbits, c.nwin, (const aff_packed*)g_keys.tab.ptr,
-                     (const uint64_t*)g_keys.c.ptr, (const uint8_t*)g_keys.flag.ptr, (uint32_t)g_keys.used);
+                     (const uint64_t*)g_keys.c.ptr, (const uint8_t*)g_keys.flag.ptr, (uint32_t)g_keys.used,
+                     g_keys.generation);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }

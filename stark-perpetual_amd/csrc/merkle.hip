@@ -40,6 +40,15 @@ void release_merkle_state() {
 
 using namespace sp;
 
+// host-side range check of a caller's felt (signature.py:307: hash inputs are in [0, p))
+static bool felt_below_p(const uint64_t* v) {
+  static const uint64_t P[4] = {1ull, 0ull, 0ull, 0x0800000000000011ull};
+  for (int i = 3; i >= 0; --i) {
+    if (v[i] != P[i]) return v[i] < P[i];
+  }
+  return false;
+}
+
 // empty-subtree roots: empties[k+1] = H(empties[k], empties[k]); 64 sequential hashes the first
 // time a given empty leaf is seen, then served from the host-side cache (65 felts per leaf value)
 static int empty_roots(const uint64_t* empty_leaf, const Scratch& s, const std::vector<uint64_t>** out) {
@@ -69,6 +78,7 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
                                      uint8_t* status) {
   SP_REQUIRE_READY();
   if (height > 64) { set_error("height must be <= 64"); return SP_ERR_BAD_ARGUMENT; }
+  if (!felt_below_p(empty_leaf)) { set_error("empty leaf must be a field element (< p)"); return SP_ERR_BAD_ARGUMENT; }
   for (size_t i = 0; i < n; ++i) {
     if (i > 0 && keys[i] <= keys[i - 1]) { set_error("keys must be strictly increasing"); return SP_ERR_BAD_ARGUMENT; }
     if (height < 64 && (keys[i] >> height) != 0) { set_error("key out of range for height"); return SP_ERR_BAD_ARGUMENT; }
@@ -243,6 +253,9 @@ extern "C" {
 int sp_tree_create(unsigned height, const uint64_t* empty_leaf, int* tree) {
   SP_REQUIRE_READY();
   if (height < 1 || height > 64) { set_error("height must be in 1..64"); return SP_ERR_BAD_ARGUMENT; }
+  // an out-of-range empty leaf would poison the cached empty-subtree roots (their chain flags
+  // SP_HASH_OUT_OF_RANGE once, later calls hit the cache and never see the flag again)
+  if (!felt_below_p(empty_leaf)) { set_error("empty leaf must be a field element (< p)"); return SP_ERR_BAD_ARGUMENT; }
   ctx_lock lk(ctx().mu);
   SparseTree t;
   t.height = height;

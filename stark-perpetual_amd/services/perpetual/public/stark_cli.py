@@ -24,7 +24,7 @@ if _PKG_ROOT not in sys.path:
     sys.path.insert(0, _PKG_ROOT)
 
 from starkperp.perpetual_messages import get_price_msg  # noqa: E402
-from starkperp.signature import FIELD_PRIME, private_to_stark_key, sign  # noqa: E402
+from starkperp.signature import EC_ORDER, FIELD_PRIME, private_to_stark_key, sign  # noqa: E402
 
 
 def bounded_hex(bound):
@@ -49,7 +49,9 @@ def run(argv):
         sub.add_argument("-t", "--time", required=True, type=bounded_hex(2**32), help="The asset time")
         ns = sub.parse_args(rest)
         return hex(get_price_msg(ns.oracle, ns.asset, ns.time, ns.price))[2:]
-    sub.add_argument("-k", "--key", required=True, type=bounded_hex(FIELD_PRIME),
+    # The reference bounds --key by FIELD_PRIME (stark_cli.py:59-61); keys in [EC_ORDER, FIELD_PRIME) are not
+    # valid Stark private keys (signature.py:197-201) and the library rejects them, so the parser does too.
+    sub.add_argument("-k", "--key", required=True, type=bounded_hex(EC_ORDER),
                      help="The private key (hex string)")
     if args.method == "sign":
         sub.add_argument("-d", "--data", required=True, type=bounded_hex(FIELD_PRIME),

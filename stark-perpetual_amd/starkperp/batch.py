@@ -191,6 +191,7 @@ def merkle_sparse_root(height, modifications, empty_leaf=0):
 # ---- ECDSA ------------------------------------------------------------------------------------
 VERIFY_FALSE, VERIFY_TRUE = 0, 1
 VERIFY_ASSERT_S, VERIFY_ASSERT_R, VERIFY_ASSERT_W, VERIFY_ASSERT_MSG, VERIFY_ASSERT_CURVE = 2, 3, 4, 5, 6
+VERIFY_STALE_SLOT = 7  # sp_ecdsa_verify_keyed_dev: slot handle from before a key-cache reset
 SIGN_OK, SIGN_RETRY, SIGN_BAD_INPUT = 0, 1, 2
 _TWO251 = 2**251
 
@@ -286,6 +287,8 @@ def raise_for_verify_code(code, msg_hash, r, s):
         raise AssertionError("msg_hash = %s" % msg_hash)
     if code == VERIFY_ASSERT_CURVE:
         raise AssertionError()
+    if code == VERIFY_STALE_SLOT:
+        raise _lib.StarkPerpError("key slot handle is stale (from before a key-cache reset) or was never handed out")
 
 
 def verify_many(msg_hashes, rs, ss, public_keys):
@@ -333,6 +336,11 @@ def sign_many(msg_hashes, priv_keys, seeds=None):
     seeds = [None] * n if seeds is None else list(seeds)
     for z in msg_hashes:
         assert 0 <= z < _TWO251, "Message not signable."
+    # The reference's sign() has no range check on the private key (signature.py:137-173); keys outside
+    # [1, EC_ORDER) are meaningless there (0 signs with the point at infinity, larger values alias
+    # key mod N with a different nonce).  Here they are rejected up front, never reduced silently.
+    for d in priv_keys:
+        assert 0 < d < EC_ORDER, "private key must be in [1, EC_ORDER), got %s" % hex(d)
     if n == 0:
         return []
     out = [None] * n
@@ -344,7 +352,7 @@ def sign_many(msg_hashes, priv_keys, seeds=None):
         r, s, st = new_felts(m), new_felts(m), new_bytes(m)
         seed_arr = (ctypes.c_uint64 * m)(*[seeds[i] or 0 for i in on_device])
         _lib.check(lib.sp_ecdsa_sign_rfc6979_batch(pack_felts([msg_hashes[i] for i in on_device]),
-                                                   pack_felts([priv_keys[i] % 2**256 for i in on_device]),
+                                                   pack_felts([priv_keys[i] for i in on_device]),
                                                    seed_arr, r, s, st, m), "sp_ecdsa_sign_rfc6979_batch")
         rs, ss = unpack_felts(r, m), unpack_felts(s, m)
         for j, i in enumerate(on_device):

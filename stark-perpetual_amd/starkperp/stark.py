@@ -192,11 +192,23 @@ def prove_commitments(xs, ys, alphas, betas, final_log=6, shift=FIELD_GEN):
 import hashlib as _hashlib
 
 
-def transcript_challenge(label: str, *values: int, modulus: int = FIELD_PRIME) -> int:
-    h = _hashlib.sha256(label.encode())
-    for v in values:
-        h.update(int(v).to_bytes(32, "big"))
-    return int.from_bytes(h.digest() + _hashlib.sha256(h.digest()).digest(), "big") % modulus
+class Transcript:
+    """Running SHA-256 Fiat-Shamir transcript: every challenge depends on the statement and on EVERY
+    commitment absorbed before it (state <- SHA256(state || label || values))."""
+
+    def __init__(self, air: str, n: int, shift: int, seed: int, public_inputs=()):
+        self.state = _hashlib.sha256(b"starkperp/airfri/v2").digest()
+        self.absorb("statement:" + air, n, shift, seed, len(public_inputs), *public_inputs)
+
+    def absorb(self, label: str, *values: int):
+        h = _hashlib.sha256(self.state + label.encode())
+        for v in values:
+            h.update(int(v).to_bytes(32, "big"))
+        self.state = h.digest()
+
+    def challenge(self, label: str, index: int = 0, modulus: int = FIELD_PRIME) -> int:
+        d = _hashlib.sha256(self.state + label.encode() + int(index).to_bytes(8, "big")).digest()
+        return int.from_bytes(d + _hashlib.sha256(d).digest(), "big") % modulus
 
 
 def _path_indices(n_leaves: int, idx: int):
@@ -217,29 +229,39 @@ def _gather_felts(t, indices):
 
 
 def prove(xs, ys, n_queries: int = 8, seed: int = 0, final_log: int = 6, shift: int = FIELD_GEN):
-    """Proof that the trace of the hashes (xs[i], ys[i]) satisfies the Pedersen-step AIR."""
+    """Benchmark-grade argument (NOT a sound proof system) that the trace of the hashes (xs[i], ys[i])
+    satisfies the Pedersen-step AIR: see prove_trace for what is and is not bound."""
     return prove_trace(pedersen_trace(xs, ys), "pedersen", n_queries, seed, final_log, shift)
 
 
 def prove_ec_ladders(ms, qxs, qys, n_queries: int = 8, seed: int = 0, final_log: int = 6,
                      shift: int = FIELD_GEN):
-    """Proof that k scalar multiplications m * Q + SHIFT_POINT were carried out step by step as
-    mimic_ec_mult_air does (the EC-ladder AIR)."""
+    """Benchmark-grade argument (NOT a sound proof system) that k scalar multiplications
+    m * Q + SHIFT_POINT were carried out step by step as mimic_ec_mult_air does (the EC-ladder AIR)."""
     return prove_trace(ec_ladder_trace(ms, qxs, qys), "ec_ladder", n_queries, seed, final_log, shift)
 
 
 def prove_trace(trace, air: str, n_queries: int = 8, seed: int = 0, final_log: int = 6,
-                shift: int = FIELD_GEN):
+                shift: int = FIELD_GEN, public_inputs=()):
     """Commitments to the trace LDE, the composition column and every FRI layer, the final layer in
-    the clear, and for each query the openings a verifier needs (oracle/stark_ref.verify_proof)."""
+    the clear, and for each query the openings a verifier needs (oracle/stark_ref.verify_proof).
+
+    What this is: the prover-side workload of BASELINE.json configs[3] made checkable end to end.  The
+    Fiat-Shamir transcript is chained (statement, then every commitment in order; alpha, every beta and
+    the query positions are drawn from it).  What it is not: a sound, complete STARK - no boundary
+    constraint binds the hash inputs / outputs (or `public_inputs`, which are only absorbed), there is
+    no zero knowledge, and the default 8 queries at blowup 4 give about 16 bits.  The reference has no
+    prover; this path is build-defined and benchmark-grade."""
     P = FIELD_PRIME
     spec = AIRS[air]
     n = trace.shape[1]
     M = n << BLOWUP_LOG
+    tr = Transcript(air, n, shift, seed, public_inputs)
     trace_lde = lde(trace)
     lv_trace = commit_rows(trace_lde)
     root_t = root_of(lv_trace)
-    alphas = [transcript_challenge("alpha", seed, root_t, k) for k in range(spec["n_constraints"])]
+    tr.absorb("trace_root", root_t)
+    alphas = [tr.challenge("alpha", k) for k in range(spec["n_constraints"])]
     per = periodic_lde(n, shift, trace.device, air)
     comp = air_eval(trace_lde, per, n, alphas, shift, air)
     layers, level_bufs, roots = [comp], [], []
@@ -249,16 +271,18 @@ def prove_trace(trace, air: str, n_queries: int = 8, seed: int = 0, final_log: i
         lv = commit_rows(cur.unsqueeze(0))
         level_bufs.append(lv)
         roots.append(root_of(lv))
-        beta = transcript_challenge("beta", seed, roots[-1], len(roots))
+        tr.absorb("layer_root", roots[-1])
+        beta = tr.challenge("beta", len(roots))
         nxt = fri_fold(cur, beta, s)
         s = s * s % P
         layers.append(nxt)
         if nxt.shape[0] <= (1 << final_log):
             break
     final = tensor_to_felts(layers[-1])
+    tr.absorb("final_layer", *final)
     queries = []
     for q in range(n_queries):
-        j = transcript_challenge("query", seed, root_t, *roots, *final, q, modulus=M // 2)
+        j = tr.challenge("query", q, modulus=M // 2)
         entry = {"index": j, "trace": [], "layers": []}
         for pos in (j, j + M // 2):
             for row in (pos, (pos + (1 << BLOWUP_LOG)) % M):
@@ -275,5 +299,5 @@ def prove_trace(trace, air: str, n_queries: int = 8, seed: int = 0, final_log: i
                              "path": _gather_felts(lv, _path_indices(mk, pos))})
             entry["layers"].append(pair)
         queries.append(entry)
-    return {"n": n, "air": air, "seed": seed, "shift": shift, "trace_root": root_t, "layer_roots": roots,
-            "final_layer": final, "queries": queries}
+    return {"n": n, "air": air, "seed": seed, "shift": shift, "public_inputs": list(public_inputs),
+            "trace_root": root_t, "layer_roots": roots, "final_layer": final, "queries": queries}

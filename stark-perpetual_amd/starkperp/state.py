@@ -193,8 +193,16 @@ class LibrarySparseTree:
 
     def close(self):
         if self._handle is not None:
-            self._lib.check(self._lib.ensure_init().sp_tree_destroy(self._handle), "sp_tree_destroy")
-            self._handle = None
+            handle, self._handle = self._handle, None
+            lib = self._lib.load()
+            if lib.sp_is_initialised():  # after sp_shutdown the library has already dropped every tree
+                self._lib.check(lib.sp_tree_destroy(handle), "sp_tree_destroy")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter teardown / library already gone
+            pass
 
 
 def hash_position_updates(updates: Sequence[Tuple[int, Position, Position]]):
@@ -254,7 +262,10 @@ class SharedState:
         """shared_state_apply_state_updates (state/state.cairo:135-186): squash, hash the previous
         and new positions (hash_position_updates), check the previous leaves against the tree,
         merkle-multi-update both trees.  Returns ((old_pos_root, new_pos_root), (old_ord, new_ord))."""
+        # Every precondition first - the Cairo twin fails the whole batch, so nothing may be written
+        # before both access lists have been squashed and checked against both trees.
         pos = squash_updates(position_accesses)
+        orders = squash_updates(order_accesses)
         prev_h = self._position_hashes([p for _, p, _ in pos])
         changed = [i for i, (_, p, q) in enumerate(pos) if p != q]
         new_h = list(prev_h)
@@ -262,9 +273,29 @@ class SharedState:
             new_h[i] = hv
         assert self.positions.get_many([key for key, _, _ in pos]) == list(prev_h), \
             "previous position does not match the tree"
-        pos_roots = self.positions.update({k: hv for (k, _, _), hv in zip(pos, new_h)})
-        orders = squash_updates(order_accesses)
         assert self.orders.get_many([key for key, _, _ in orders]) == [prev for _, prev, _ in orders], \
             "previous order state does not match the tree"
-        ord_roots = self.orders.update({k: new for k, _, new in orders})
+        for key, _, new in orders:
+            assert 0 <= key < (1 << self.orders.height) and 0 <= new < batch.FIELD_PRIME, \
+                "order leaf out of range"
+        pos_roots = self.positions.update({k: hv for (k, _, _), hv in zip(pos, new_h)})
+        try:
+            ord_roots = self.orders.update({k: new for k, _, new in orders})
+        except BaseException:
+            # data-dependent failure inside the second update (an unhashable node): put the previous
+            # position leaves back so that the two roots still describe one batch boundary
+            self.positions.update({k: hv for (k, _, _), hv in zip(pos, prev_h)})
+            raise
         return pos_roots, ord_roots
+
+    def close(self):
+        """Releases the library-side trees (no-op for the host-bookkeeping variant)."""
+        for tree in (self.positions, self.orders):
+            if hasattr(tree, "close"):
+                tree.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -137,6 +137,49 @@ def test_invalid_keys_and_cache_bookkeeping(batch):
     assert batch.verify_codes([z], [r], [s], [q[0]], key_tables=True) == [1]
 
 
+def test_stale_and_foreign_slot_handles_are_refused(batch):
+    """A slot handle carries the cache generation: after sp_ecdsa_key_cache_reset an old handle must not
+    verify against whatever key took its index, and an x-only registration does not alias a
+    point key whose y happens to be the old sentinel, nor does x + p get a second slot."""
+    import ctypes
+    import torch
+    from starkperp import _lib, stark
+    batch.key_cache_reset()
+    d1, d2 = 777, 778
+    q1, q2 = R.private_key_to_ec_point_on_stark_curve(d1), R.private_key_to_ec_point_on_stark_curve(d2)
+    z = 0x4321
+    r, s = R.sign(z, d1)
+    (slot1,) = batch.register_keys([q1[0]])
+    assert slot1 >> 24 != 0
+
+    def keyed(slot):
+        lib = _lib.ensure_init()
+        dz, dr, ds = (stark.felts_to_tensor([v]) for v in (z, r, s))
+        dslot = torch.tensor([slot], dtype=torch.int32, device="cuda")
+        res = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.sp_ecdsa_verify_keyed_dev(dz.data_ptr(), dr.data_ptr(), ds.data_ptr(), dslot.data_ptr(),
+                                                 res.data_ptr(), 1, None), "keyed")
+        torch.cuda.synchronize()
+        return int(res[0])
+
+    assert keyed(slot1) == 1
+    assert keyed(slot1 + 1) == batch.VERIFY_STALE_SLOT          # an index nobody was given
+    batch.key_cache_reset()
+    (slot2,) = batch.register_keys([q2[0]])                      # another key now owns index 0
+    assert slot2 & 0xFFFFFF == slot1 & 0xFFFFFF and slot2 != slot1
+    assert keyed(slot1) == batch.VERIFY_STALE_SLOT               # never q2's verdict
+    assert keyed(slot2) == 0
+    # identity of a key: reduced coordinates, explicit x-only flag
+    lib = _lib.ensure_init()
+    slots = (ctypes.c_uint32 * 2)()
+    _lib.check(lib.sp_ecdsa_register_keys(_lib.pack_felts([q1[0], q1[0] + P]), None, 2, slots), "register")
+    assert slots[0] == slots[1]
+    sentinel_y = 2**256 - 1
+    _lib.check(lib.sp_ecdsa_register_keys(_lib.pack_felts([q1[0]]), _lib.pack_felts([sentinel_y]), 1, slots), "register")
+    assert slots[0] != slots[1]                                  # a point key, not the x-only slot
+    batch.key_cache_reset()
+
+
 def test_full_cache_is_reported_and_the_host_entry_point_falls_back():
     """A 4-slot cache (STARKPERP_KEY_CACHE_SLOTS, read when the cache is first used - hence the
     subprocess): registering a fifth key fails with SP_ERR_CACHE_FULL and registers nothing, the

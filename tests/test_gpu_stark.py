@@ -178,6 +178,47 @@ def test_full_size_pipeline_properties(stark):
     assert not S.poly_degree_bound_check(stark.tensor_to_felts(layer), s, 47)
 
 
+def test_configs4_trace_of_2p24_rows_on_one_gpu(stark):
+    """BASELINE.json configs[4] at its full size on ONE GPU: 2^24 trace rows (32 768 hashes), LDE to
+    2^26 points, both commitments, composition and all 20 folds with their commitments.  Size-independent
+    checks: the final layer of the valid trace has degree < 48, the committed trace holds the
+    reference's hash of the first input pair, and the trace commitment is the root the level buffer
+    ends in (re-derived from two sibling nodes through the scalar hash)."""
+    import torch
+    m = 1 << 15
+    g = torch.Generator().manual_seed(19)
+    xs = torch.randint(0, 2**62, (m, 4), dtype=torch.int64, generator=g)
+    ys = torch.randint(0, 2**62, (m, 4), dtype=torch.int64, generator=g)
+    xs[:, 3] &= (1 << 58) - 1
+    ys[:, 3] &= (1 << 58) - 1
+    xs, ys = xs.cuda(), ys.cuda()
+    rng = random.Random(20)
+    alphas = [rng.randrange(P) for _ in range(S.N_CONSTRAINTS)]
+    betas = [rng.randrange(P) for _ in range(20)]
+    n = 512 * m
+    trace = stark.pedersen_trace(xs, ys)
+    x0, y0 = stark.tensor_to_felts(xs[:1])[0], stark.tensor_to_felts(ys[:1])[0]
+    assert stark.tensor_to_felts(trace[1][511:512])[0] == R.pedersen_hash(x0, y0)
+    trace_lde = stark.lde(trace)
+    del trace
+    lv = stark.commit_rows(trace_lde)
+    top = stark.tensor_to_felts(lv[-3:])
+    from starkperp import signature
+    assert signature.pedersen_hash(top[0], top[1]) == top[2]
+    del lv
+    comp = stark.air_eval(trace_lde, stark.periodic_lde(n), n, alphas)
+    del trace_lde
+    roots = [stark.root_of(stark.commit_rows(comp.unsqueeze(0)))]
+    layer, s = comp, S.GEN
+    for k in range(20):
+        layer = stark.fri_fold(layer, betas[k], s)
+        s = s * s % P
+        if layer.shape[0] > 64:
+            roots.append(stark.root_of(stark.commit_rows(layer.unsqueeze(0))))
+    assert layer.shape[0] == 64 and len(roots) == 20 and len(set(roots)) == 20
+    assert S.poly_degree_bound_check(stark.tensor_to_felts(layer), s, 47)
+
+
 def test_prove_then_verify_small(stark):
     """GPU prover -> CPU verifier round trip on a 1024-row trace, plus tampering."""
     import copy
@@ -196,6 +237,17 @@ def test_prove_then_verify_small(stark):
     assert not S.verify_proof(bad)[0]
     bad = copy.deepcopy(proof)
     bad["final_layer"][5] ^= 1
+    assert not S.verify_proof(bad)[0]
+    # the transcript is chained: changing an EARLIER commitment moves every later challenge, so a proof
+    # whose first layer root (or statement) is swapped no longer opens at the drawn query positions
+    bad = copy.deepcopy(proof)
+    bad["layer_roots"][0] ^= 1
+    assert not S.verify_proof(bad)[0]
+    bad = copy.deepcopy(proof)
+    bad["seed"] += 1
+    assert not S.verify_proof(bad)[0]
+    bad = copy.deepcopy(proof)
+    bad["public_inputs"] = [1]
     assert not S.verify_proof(bad)[0]
 
 

@@ -68,3 +68,37 @@ def test_shared_state_updates_with_oracle_hash():
     assert st.orders_root == R.merkle_multi_update_sparse(6, {9: 25, 1: 6})
     with pytest.raises(AssertionError):
         st.apply_state_updates([(3, p1, p1)], [])
+
+
+def test_apply_state_updates_is_all_or_nothing():
+    """state/state.cairo:135-186 fails the WHOLE batch: a bad orders list (inconsistent accesses, a stale
+    previous value, an out-of-range leaf) must leave the positions root where it was, and a failure
+    inside the second tree update rolls the first one back."""
+    import pytest
+    from starkperp.state import SharedState
+    ph = lambda ps: [R.position_hash(p[0], p[1], list(p[2])) for p in ps]
+    st = SharedState(8, 6, hash_many=oracle_hash_many, position_hashes=ph)
+    empty = (0, 0, ())
+    p1 = (123, 50, ((7, 1, -2),))
+    st.apply_state_updates([(3, empty, p1)], [(9, 0, 10)])
+    roots = (st.positions_root, st.orders_root)
+    p2 = (123, 40, ((7, 1, 3),))
+    for bad_orders in ([(9, 10, 11), (9, 99, 12)],          # inconsistent chain of accesses
+                       [(9, 7, 11)],                         # previous value is not what the tree holds
+                       [(9, 10, R.FIELD_PRIME)],             # unhashable-range leaf
+                       [(1 << 6, 0, 1)]):                    # key outside the tree
+        with pytest.raises(AssertionError):
+            st.apply_state_updates([(3, p1, p2)], bad_orders)
+        assert (st.positions_root, st.orders_root) == roots
+    # a failure raised by the second update itself: the first update is undone
+    real_update = st.orders.update
+
+    def failing_update(mods):
+        raise AssertionError("Unhashable input.")
+    st.orders.update = failing_update
+    with pytest.raises(AssertionError):
+        st.apply_state_updates([(3, p1, p2)], [(9, 10, 11)])
+    st.orders.update = real_update
+    assert (st.positions_root, st.orders_root) == roots
+    st.apply_state_updates([(3, p1, p2)], [(9, 10, 11)])
+    assert st.positions_root != roots[0] and st.orders_root != roots[1]
