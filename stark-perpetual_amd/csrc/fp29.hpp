@@ -181,6 +181,22 @@ SP_HD fe fe_weak_reduce(const fe& a) {
   return fe_carry(r);
 }
 
+// value / 2 mod p for N-form input with value in (-p, 2p); output N-form with value in (-p, p].
+// Adds p when the value is odd (p is odd), then shifts the 261-bit limb string right by one.
+SP_HD fe fe_half(const fe& a_in) {
+  fe a = fe_carry(a_in);
+  const int32_t odd = a.l[0] & 1;
+  a.l[0] += odd;        // + p = (1, 0, 0, 0, 0, 0, P6, 0, P8): limb 0 becomes even, may reach 2^29
+  a.l[6] += odd * P6;
+  a.l[8] += odd * P8;
+  a = fe_carry(a);
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = (int32_t)(((uint32_t)a.l[i] >> 1) | (((uint32_t)a.l[i + 1] & 1u) << (LB - 1)));
+  r.l[8] = a.l[8] >> 1;  // arithmetic: the top limb carries the sign
+  return r;
+}
+
 // ---- column products ----
 struct cols {
   int64_t c[17];
@@ -283,6 +299,16 @@ SP_HD fe fe_mul_add_mul(const fe& a, const fe& b, const fe& c, const fe& d) {
   cols_zero(t);
   cols_mac(t, a, b);
   cols_mac(t, c, d);
+  return fe_reduce(t);
+}
+
+// a*b + c*d + e*f with a single reduction (all six operands N-form: 27 * 2^58 < 2^63)
+SP_HD fe fe_mul3_add(const fe& a, const fe& b, const fe& c, const fe& d, const fe& e, const fe& f) {
+  cols t;
+  cols_zero(t);
+  cols_mac(t, a, b);
+  cols_mac(t, c, d);
+  cols_mac(t, e, f);
   return fe_reduce(t);
 }
 

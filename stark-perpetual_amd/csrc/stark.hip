@@ -5,10 +5,15 @@
 // (pedersen_params.json:20-21) and the AIR's step relation (signature.py:305-317,
 // math_utils.py:64-67) are the reference's.
 //
-// Data layout in HBM: a column is a contiguous array of 32-byte felts (plain integers at the C
-// ABI; Montgomery form between the passes of one transform).  Algorithmic bytes: an NTT pass reads
-// and writes each felt once (64 B per element per pass); 2^22 points take 3 passes
-// (9 + 2 strided stages, then 11 stages on a contiguous 2048-point tile in LDS).
+// Data layout in HBM: a column is a contiguous array of 32-byte felts, plain integers everywhere
+// (C ABI and between passes).  No kernel converts its operands to Montgomery form: every
+// multiplication in a transform, a fold or the composition has at least one CONSTANT factor (twiddle,
+// coset power, 1/n, alpha, 1/Z) and the constants are kept in Montgomery form, so
+// fe_mul(plain, constant R) = plain * constant - the R of the reduction cancels against the R of the
+// constant (round 1 paid 13 of ~45 multiplications per composition point, 3 of 6 per fold and 2 per
+// transform element for conversions).  Algorithmic bytes: an NTT pass reads and writes each felt once
+// (64 B per element per pass); 2^22 points take 3 passes (9 + 2 strided stages, then 11 stages on a
+// contiguous 2048-point tile in LDS).
 #include <cstring>
 #include <map>
 #include <vector>
@@ -20,6 +25,10 @@ namespace sp {
 
 constexpr int TILE_LOG = 11;
 constexpr int TILE = 1 << TILE_LOG;  // 2048 felts = 72 KiB of LDS as 9 x int32 planes
+#ifndef SP_NTT_THREADS
+#define SP_NTT_THREADS 512
+#endif
+constexpr int NTT_THREADS = SP_NTT_THREADS;  // two blocks per CU (LDS): 512 threads = 4 waves per SIMD to cover the per-stage barriers
 
 __device__ __forceinline__ fe lds_get(const int32_t* lds, int e) {
   fe v;
@@ -38,11 +47,17 @@ __device__ __forceinline__ fe ld_fe_packed(const uint64_t* p) { return fe_unpack
 //   DIF (forward half of a natural->bit-reversed transform): a' = a + b, b' = (a - b) w
 //   DIT (bit-reversed->natural):                             a' = a + w b, b' = a - w b
 // with w = omega_{2h}^(index mod h) = tw[(index mod h) << (log_tw - 1 - t - log_lo)].
-__global__ void __launch_bounds__(256)
+// pad_log_b > 0 (first pass of the big transform of an LDE): `in` is the coefficient array of the small
+// transform (2^pad_log_n felts per column, bit-reversed order); slot e of the tile stands for
+// coef[idx >> pad_log_b] * G[bitrev(idx >> pad_log_b)] when the low pad_log_b bits of idx are zero and
+// for 0 otherwise (zero padding in bit-reversed positions), and the first pad_log_b DIT stages - which
+// only copy that value over its 2^pad_log_b slots (a + w * 0) - are skipped: the padded column is
+// never written to HBM.
+__global__ void __launch_bounds__(NTT_THREADS)
 ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int log_e, int log_t,
                 int log_lo, int nst, int t_first, int dit, const uint64_t* __restrict__ tw, int log_tw,
-                int in_plain, int out_plain, int use_scale, fe scale, size_t in_col_stride,
-                size_t out_col_stride) {
+                int use_scale, fe scale, size_t in_col_stride, size_t out_col_stride,
+                const uint64_t* __restrict__ pad_G, int pad_log_b, int pad_log_n) {
   __shared__ int32_t lds[NL * TILE];
   in += 4 * in_col_stride * blockIdx.y;    // grid.y = column: independent columns share one launch
   out += 4 * out_col_stride * blockIdx.y;
@@ -53,18 +68,34 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
   const size_t high = blockIdx.x / low_blocks;
   const size_t lowb = blockIdx.x % low_blocks;
   const size_t base = (high << (log_t + log_lo)) | (lowb << log_c);
-  for (int e = threadIdx.x; e < E; e += 256) {
-    const int k = e >> log_c, c = e & (C - 1);
-    const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
-    fe v = ld_fe_packed(in + 4 * idx);
-    if (in_plain) v = fe_to_mont(v);
-    lds_put(lds, e, v);
+  int s_begin = 0;
+  if (pad_log_b > 0) {  // contiguous tile (log_lo == 0, log_c == 0): one coefficient fills 2^pad_log_b slots
+    const int B = 1 << pad_log_b;
+    for (int g = threadIdx.x; g < (E >> pad_log_b); g += NTT_THREADS) {
+      const size_t j = (base >> pad_log_b) + (size_t)g;
+      const size_t c = pad_log_n ? (__brevll((unsigned long long)j) >> (64 - pad_log_n)) : 0;
+      const fe v = fe_mul(ld_fe_packed(in + 4 * j), ld_fe_packed(pad_G + 4 * c));
+      for (int q = 0; q < B; ++q) lds_put(lds, (g << pad_log_b) + q, v);
+    }
+    s_begin = pad_log_b < nst ? pad_log_b : nst;
+  } else {
+    for (int e = threadIdx.x; e < E; e += NTT_THREADS) {
+      const int k = e >> log_c, c = e & (C - 1);
+      const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
+      lds_put(lds, e, ld_fe_packed(in + 4 * idx));
+    }
   }
   __syncthreads();
-  for (int s = 0; s < nst; ++s) {
+  for (int s = s_begin; s < nst; ++s) {
     const int t = dit ? (t_first + s) : (t_first - s);
     const int tmask = (1 << t) - 1;
-    for (int p = threadIdx.x; p < E / 2; p += 256) {
+    // Sums stay lazy for one stage: a value that skipped its reduction has limbs < 2 * 2^29, the next
+    // stage either multiplies it by a twiddle (18 * 2^58 per column, fine) or adds one more N-form
+    // product to it (3 * 2^29 per limb) and reduces.  The last stage always reduces (fe_canon below
+    // wants a value in (-p, 2p)).
+    // DIT only: in a DIF stage both operands of the next butterfly may be unreduced sums.
+    const bool red = !dit || (((s - s_begin) & 1) != 0) || (s + 1 == nst);
+    for (int p = threadIdx.x; p < E / 2; p += NTT_THREADS) {
       const int c = p & (C - 1), kk = p >> log_c;
       const int k0 = ((kk >> t) << (t + 1)) | (kk & tmask);
       const int e0 = (k0 << log_c) | c, e1 = e0 + (1 << (t + log_c));
@@ -73,22 +104,23 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
       const fe a = lds_get(lds, e0), b = lds_get(lds, e1);
       if (dit) {
         const fe wb = fe_mul(b, w);
-        lds_put(lds, e0, fe_weak_reduce(fe_add(a, wb)));
-        lds_put(lds, e1, fe_weak_reduce(fe_sub(a, wb)));
+        const fe u = fe_add(a, wb), v = fe_sub(a, wb);
+        lds_put(lds, e0, red ? fe_weak_reduce(u) : u);
+        lds_put(lds, e1, red ? fe_weak_reduce(v) : v);
       } else {
-        lds_put(lds, e0, fe_weak_reduce(fe_add(a, b)));
+        const fe u = fe_add(a, b);
+        lds_put(lds, e0, red ? fe_weak_reduce(u) : u);
         lds_put(lds, e1, fe_mul(fe_sub(a, b), w));
       }
     }
     __syncthreads();
   }
-  for (int e = threadIdx.x; e < E; e += 256) {
+  for (int e = threadIdx.x; e < E; e += NTT_THREADS) {
     const int k = e >> log_c, c = e & (C - 1);
     const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
     fe v = lds_get(lds, e);
     if (use_scale) v = fe_mul(v, scale);
-    v = out_plain ? fe_from_mont(v) : fe_canon(v);
-    st_u256(out + 4 * idx, fe_pack(v));
+    st_u256(out + 4 * idx, fe_pack(fe_canon(v)));
   }
 }
 
@@ -113,25 +145,16 @@ bitrev_copy_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, 
   st_u256(out + 4 * i, ld_u256(in + 4 * r));
 }
 
-// LDE glue: coefficients in bit-reversed order (Montgomery) -> zero-padded, coset-shifted input of
-// the big DIT transform.  out[(j << log_b) + 0] = coef[j] * G[bitrev_n(j)], other slots 0.
+// out[j] = coef[j] * G[bitrev(j)] (an LDE without blowup: only the coset shift)
 __global__ void __launch_bounds__(256)
-lde_pad_kernel(const uint64_t* __restrict__ coef, uint64_t* __restrict__ out, int log_n, int log_b,
-               const uint64_t* __restrict__ G) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >> (log_n + log_b)) return;
-  coef += ((size_t)4 << log_n) * blockIdx.y;            // grid.y = column
-  out += ((size_t)4 << (log_n + log_b)) * blockIdx.y;
-  u256 v;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) v.w[q] = 0;
-  if ((i & (((size_t)1 << log_b) - 1)) == 0) {
-    const size_t j = i >> log_b;
-    const size_t c = log_n ? (__brevll((unsigned long long)j) >> (64 - log_n)) : 0;
-    const fe prod = fe_mul(ld_fe_packed(coef + 4 * j), ld_fe_packed(G + 4 * c));
-    v = fe_pack(fe_canon(fe_mul(prod, FE_ONE_M)));
-  }
-  st_u256(out + 4 * i, v);
+scale_copy_kernel(const uint64_t* __restrict__ coef, uint64_t* __restrict__ out, int log_n,
+                  const uint64_t* __restrict__ G) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >> log_n) return;
+  coef += ((size_t)4 << log_n) * blockIdx.y;
+  out += ((size_t)4 << log_n) * blockIdx.y;
+  const size_t c = log_n ? (__brevll((unsigned long long)j) >> (64 - log_n)) : 0;
+  st_u256(out + 4 * j, fe_pack(fe_canon(fe_mul(ld_fe_packed(coef + 4 * j), ld_fe_packed(G + 4 * c)))));
 }
 
 // ---- Pedersen-step AIR --------------------------------------------------------------------------
@@ -379,11 +402,14 @@ ec_ladder_trace_kernel(const uint64_t* __restrict__ pm, const uint64_t* __restri
 }
 
 struct EcAirParams {
-  fe alpha[12];
-  fe zinv[4];
-  fe shift_x, shift_y;
+  fe alpha[12];  // Montgomery
+  fe zinv[4];    // R * Montgomery form of 1 / (x^n - 1) for i mod 4 (absorbs the one R the selectors leave)
+  fe shift_x, shift_y;  // plain
 };
 
+// Operands are PLAIN felts.  Only what is multiplied by another variable is converted (b, la, ld, qx:
+// four conversions instead of fifteen); products with one Montgomery factor are plain again, the
+// alphas are Montgomery constants, and the single 1/R left by `selector * (...)` is absorbed by zinv.
 __global__ void __launch_bounds__(256)
 air_eval_ec_ladder_kernel(const uint64_t* __restrict__ trace /* [7][M] plain */,
                           const uint64_t* __restrict__ per /* [3][1024] plain */, size_t M, EcAirParams prm,
@@ -391,27 +417,29 @@ air_eval_ec_ladder_kernel(const uint64_t* __restrict__ trace /* [7][M] plain */,
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
   const size_t in = (i + 4) & (M - 1);
-  auto col = [&](int c, size_t r) { return fe_to_mont(ld_fe_packed(trace + 4 * ((size_t)c * M + r))); };
-  auto pcol = [&](int c) { return fe_to_mont(ld_fe_packed(per + 4 * ((size_t)c * 1024 + (i & 1023)))); };
+  auto col = [&](int c, size_t r) { return ld_fe_packed(trace + 4 * ((size_t)c * M + r)); };
+  auto pcol = [&](int c) { return ld_fe_packed(per + 4 * ((size_t)c * 1024 + (i & 1023))); };
   const fe m = col(0, i), px = col(1, i), py = col(2, i), qx = col(3, i), qy = col(4, i), la = col(5, i),
            ld = col(6, i);
   const fe m_n = col(0, in), px_n = col(1, in), py_n = col(2, in), qx_n = col(3, in), qy_n = col(4, in);
   const fe step = pcol(0), first = pcol(1), z251 = pcol(2);
+  const fe one = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
   const fe b = fe_carry(fe_sub(m, fe_dbl(m_n)));
-  const fe nb = fe_carry(fe_sub(FE_ONE_M, b));
+  const fe bM = fe_to_mont(b), laM = fe_to_mont(la), ldM = fe_to_mont(ld), qxM = fe_to_mont(qx);
+  const fe nbM = fe_carry(fe_sub(FE_ONE_M, bM));
   fe c[9];
-  c[0] = fe_mul(b, fe_carry(fe_sub(b, FE_ONE_M)));
+  c[0] = fe_mul(bM, fe_carry(fe_sub(b, one)));
   // doubling: ld 2 qy - 3 qx^2 - 1 ; qx' - ld^2 + 2 qx ; qy' - ld (qx - qx') + qy
-  const fe qxx = fe_sqr(qx);
-  c[1] = fe_carry(fe_sub(fe_sub(fe_mul(ld, fe_carry(fe_dbl(qy))), fe_carry(fe_add(fe_dbl(qxx), qxx))), FE_ONE_M));
-  c[2] = fe_carry(fe_add(fe_sub(qx_n, fe_sqr(ld)), fe_dbl(qx)));
-  c[3] = fe_carry(fe_add(fe_sub(qy_n, fe_mul(ld, fe_sub(qx, qx_n))), qy));
+  const fe qxx = fe_mul(qxM, qx);
+  c[1] = fe_carry(fe_sub(fe_sub(fe_mul(ldM, fe_carry(fe_dbl(qy))), fe_carry(fe_add(fe_dbl(qxx), qxx))), one));
+  c[2] = fe_carry(fe_add(fe_sub(qx_n, fe_mul(ldM, ld)), fe_dbl(qx)));
+  c[3] = fe_carry(fe_add(fe_sub(qy_n, fe_mul(ldM, fe_sub(qx, qx_n))), qy));
   // addition (gated by b): la (px - qx) - (py - qy) ; px' - la^2 + px + qx ; py' - la (px - px') + py
-  c[4] = fe_mul(b, fe_carry(fe_sub(fe_mul(la, fe_sub(px, qx)), fe_sub(py, qy))));
-  c[5] = fe_mul(b, fe_carry(fe_add(fe_sub(px_n, fe_sqr(la)), fe_add(px, qx))));
-  c[6] = fe_mul(b, fe_carry(fe_add(fe_sub(py_n, fe_mul(la, fe_sub(px, px_n))), py)));
-  c[7] = fe_mul(nb, fe_carry(fe_sub(px_n, px)));
-  c[8] = fe_mul(nb, fe_carry(fe_sub(py_n, py)));
+  c[4] = fe_mul(bM, fe_carry(fe_sub(fe_mul(laM, fe_sub(px, qx)), fe_sub(py, qy))));
+  c[5] = fe_mul(bM, fe_carry(fe_add(fe_sub(px_n, fe_mul(laM, la)), fe_add(px, qx))));
+  c[6] = fe_mul(bM, fe_carry(fe_add(fe_sub(py_n, fe_mul(laM, fe_sub(px, px_n))), py)));
+  c[7] = fe_mul(nbM, fe_carry(fe_sub(px_n, px)));
+  c[8] = fe_mul(nbM, fe_carry(fe_sub(py_n, py)));
   fe acc_step = fe_mul(prm.alpha[0], c[0]);
 #pragma unroll
   for (int k = 1; k < 9; ++k) acc_step = fe_weak_reduce(fe_add(acc_step, fe_mul(prm.alpha[k], c[k])));
@@ -420,68 +448,70 @@ air_eval_ec_ladder_kernel(const uint64_t* __restrict__ trace /* [7][M] plain */,
                                    fe_carry(fe_sub(py, prm.shift_y)));
   acc = fe_weak_reduce(fe_add(acc, fe_mul(first, firsts)));
   acc = fe_weak_reduce(fe_add(acc, fe_mul(prm.alpha[11], fe_mul(z251, m))));
-  st_u256(out + 4 * i, fe_pack(fe_from_mont(fe_mul(acc, prm.zinv[i & 3]))));
+  st_u256(out + 4 * i, fe_pack(fe_canon(fe_mul(acc, prm.zinv[i & 3]))));
 }
 
 struct AirParams {
   fe alpha[11];  // Montgomery
-  fe zinv[4];    // 1 / (x^n - 1) for i mod 4, Montgomery
-  fe shift_x, shift_y;
+  fe zinv[4];    // R * Montgomery form of 1 / (x^n - 1) for i mod 4 (absorbs the one R the selectors leave)
+  fe shift_x, shift_y;  // plain
 };
 
 // Composition column on the LDE coset: sum_k alpha_k C_k(x) / Z_H(x).  Reads the four trace columns
-// at i and i + blowup (the next trace row) and six periodic tables at i mod 2048.
+// at i and i + blowup (the next trace row) and six periodic tables at i mod 2048 - all PLAIN felts.
+// Only b and lambda (the two variables that multiply other variables) are converted to Montgomery
+// form: 2 conversions instead of the 13 + 1 of round 1 (see the file comment).
 __global__ void __launch_bounds__(256)
 air_eval_kernel(const uint64_t* __restrict__ trace /* [4][M] plain */, const uint64_t* __restrict__ per /* [6][2048] plain */,
                 size_t M, AirParams prm, uint64_t* __restrict__ out /* [M] plain */) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
   const size_t in = (i + 4) & (M - 1);
-  auto col = [&](int c, size_t r) { return fe_to_mont(ld_fe_packed(trace + 4 * ((size_t)c * M + r))); };
-  auto pcol = [&](int c) { return fe_to_mont(ld_fe_packed(per + 4 * ((size_t)c * 2048 + (i & 2047)))); };
+  auto col = [&](int c, size_t r) { return ld_fe_packed(trace + 4 * ((size_t)c * M + r)); };
+  auto pcol = [&](int c) { return ld_fe_packed(per + 4 * ((size_t)c * 2048 + (i & 2047))); };
   const fe s = col(0, i), px = col(1, i), py = col(2, i), lam = col(3, i);
   const fe s_n = col(0, in), px_n = col(1, in), py_n = col(2, in);
   const fe cx = pcol(0), cy = pcol(1), step = pcol(2), mid = pcol(3), end = pcol(4), z252 = pcol(5);
+  const fe one = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
   const fe b = fe_carry(fe_sub(s, fe_dbl(s_n)));
-  const fe nb = fe_carry(fe_sub(FE_ONE_M, b));
+  const fe bM = fe_to_mont(b), lamM = fe_to_mont(lam);
+  const fe nbM = fe_carry(fe_sub(FE_ONE_M, bM));
   const fe dxn = fe_carry(fe_sub(px_n, px));
   const fe dyn = fe_carry(fe_sub(py_n, py));
-  fe c[11];
-  c[0] = fe_mul(b, fe_carry(fe_sub(b, FE_ONE_M)));
-  c[1] = fe_mul(b, fe_carry(fe_sub(fe_mul(lam, fe_sub(px, cx)), fe_sub(py, cy))));
-  c[2] = fe_mul(b, fe_carry(fe_sub(fe_sub(fe_sqr(lam), px), fe_add(cx, px_n))));
-  c[3] = fe_mul(b, fe_carry(fe_sub(fe_mul(lam, fe_sub(px, px_n)), fe_add(py, py_n))));
-  c[4] = fe_mul(nb, dxn);
-  c[5] = fe_mul(nb, dyn);
-  // step selector multiplies the first six
-  fe acc_step = fe_mul(prm.alpha[0], c[0]);
-#pragma unroll
-  for (int k = 1; k < 6; ++k) acc_step = fe_weak_reduce(fe_add(acc_step, fe_mul(prm.alpha[k], c[k])));
-  fe acc = fe_mul(step, acc_step);
+  // step rows: bM (alpha0 (b - 1) + alpha1 X1 + alpha2 X2 + alpha3 X3) + nbM (alpha4 dx' + alpha5 dy'): sums
+  // of products share one reduction (fe_mul3_add / fe_mul_add_mul), and the common factors bM, nbM
+  // are applied once - about 20 multiplication-equivalents per point instead of 27
+  const fe X1 = fe_carry(fe_sub(fe_mul(lamM, fe_sub(px, cx)), fe_sub(py, cy)));
+  const fe X2 = fe_carry(fe_sub(fe_sub(fe_mul(lamM, lam), px), fe_add(cx, px_n)));
+  const fe X3 = fe_carry(fe_sub(fe_mul(lamM, fe_sub(px, px_n)), fe_add(py, py_n)));
+  const fe in1 = fe_carry(fe_add(fe_mul(prm.alpha[0], fe_carry(fe_sub(b, one))),
+                                 fe_mul3_add(prm.alpha[1], X1, prm.alpha[2], X2, prm.alpha[3], X3)));
+  const fe in2 = fe_mul_add_mul(prm.alpha[4], dxn, prm.alpha[5], dyn);
+  const fe acc_step = fe_mul_add_mul(bM, in1, nbM, in2);
   const fe mids = fe_mul_add_mul(prm.alpha[6], dxn, prm.alpha[7], dyn);
-  acc = fe_weak_reduce(fe_add(acc, fe_mul(mid, mids)));
   const fe ends = fe_mul_add_mul(prm.alpha[8], fe_carry(fe_sub(px_n, prm.shift_x)), prm.alpha[9],
                                  fe_carry(fe_sub(py_n, prm.shift_y)));
-  acc = fe_weak_reduce(fe_add(acc, fe_mul(end, ends)));
+  fe acc = fe_mul3_add(step, acc_step, mid, mids, end, ends);
   acc = fe_weak_reduce(fe_add(acc, fe_mul(prm.alpha[10], fe_mul(z252, s))));
-  const fe q = fe_mul(acc, prm.zinv[i & 3]);
-  st_u256(out + 4 * i, fe_pack(fe_from_mont(q)));
+  st_u256(out + 4 * i, fe_pack(fe_canon(fe_mul(acc, prm.zinv[i & 3]))));
 }
 
 // FRI fold: g[i] = (f[i] + f[i+M/2]) / 2 + beta (f[i] - f[i+M/2]) / (2 x_i),  x_i = shift w_M^i.
-// tw_inv holds w^{-i} (table for size 2^log_tw); c1 = 1/2, c2 = beta / (2 shift), Montgomery.
+// tw_inv holds w^{-i} (table for size 2^log_tw); c1 = 1/2, c2 = beta / (2 shift); table and constants
+// in Montgomery form, the layer values plain: two multiplications and one halving per output.
 __global__ void __launch_bounds__(256)
 fri_fold_kernel(const uint64_t* __restrict__ f, uint64_t* __restrict__ g, int log_m,
                 const uint64_t* __restrict__ tw_inv, int log_tw, fe c1, fe c2) {
   const size_t half = (size_t)1 << (log_m - 1);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= half) return;
-  const fe a = fe_to_mont(ld_fe_packed(f + 4 * i));
-  const fe b = fe_to_mont(ld_fe_packed(f + 4 * (i + half)));
+  const fe a = ld_fe_packed(f + 4 * i);
+  const fe b = ld_fe_packed(f + 4 * (i + half));
   const fe winv = ld_fe_packed(tw_inv + 4 * (i << (log_tw - log_m)));
   const fe odd = fe_mul(fe_mul(fe_sub(a, b), winv), c2);
-  const fe even = fe_mul(fe_carry(fe_add(a, b)), c1);
-  st_u256(g + 4 * i, fe_pack(fe_from_mont(fe_carry(fe_add(even, odd)))));
+  const fe even = fe_half(fe_add(a, b));  // c1 = 1/2: a shift instead of a multiplication
+  (void)c1;
+  st_u256(g + 4 * i, fe_pack(fe_canon(fe_carry(fe_add(even, odd)))));
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -562,18 +592,20 @@ static int get_twiddles(int log_n, int inverse, const uint64_t** out, hipStream_
   return SP_OK;
 }
 
-// Full transform of one column.  dit = 0: natural -> bit-reversed (DIF), dit = 1: bit-reversed ->
-// natural.  in/out may alias.  Montgomery/plain conversion happens in the first/last pass.
-static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse, int dit, int in_plain,
-                      int out_plain, int use_scale, fe scale, hipStream_t st, unsigned ncols = 1,
-                      size_t in_col_stride = 0, size_t out_col_stride = 0) {
+// Full transform of `ncols` columns.  dit = 0: natural -> bit-reversed (DIF), dit = 1: bit-reversed ->
+// natural.  in/out may alias.  Values are plain integers throughout (see the file comment).  With
+// pad_log_b > 0 (dit only) `in` is the bit-reversed coefficient array of 2^(log_n - pad_log_b) felts per
+// column and the zero-padded, coset-scaled input of the transform exists only in LDS.
+static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse, int dit, int use_scale,
+                      fe scale, hipStream_t st, unsigned ncols = 1, size_t in_col_stride = 0,
+                      size_t out_col_stride = 0, const uint64_t* pad_G = nullptr, int pad_log_b = 0) {
   const uint64_t* tw;
   int rc = get_twiddles(log_n, inverse, &tw, st);
   if (rc != SP_OK) return rc;
   if (log_n == 0) {
-    // single point: (optionally) scale and convert
-    hipLaunchKernelGGL(ntt_tile_kernel, dim3(1, ncols), dim3(256), 0, st, in, out, 0, 0, 0, 0, 0, dit, tw, 1,
-                       in_plain, out_plain, use_scale, scale, in_col_stride, out_col_stride);
+    // single point: (optionally) scale
+    hipLaunchKernelGGL(ntt_tile_kernel, dim3(1, ncols), dim3(NTT_THREADS), 0, st, in, out, 0, 0, 0, 0, 0, dit, tw, 1,
+                       use_scale, scale, in_col_stride, out_col_stride, (const uint64_t*)nullptr, 0, 0);
     SP_HIP(hipGetLastError());
     return SP_OK;
   }
@@ -604,15 +636,17 @@ static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse,
     for (auto it = strided.rbegin(); it != strided.rend(); ++it) plan.push_back(*it);
     plan.push_back(loc);
   }
+  if (pad_log_b > 0 && (!dit || pad_log_b > local)) { set_error("LDE padding needs a DIT transform"); return SP_ERR_BAD_ARGUMENT; }
   const uint64_t* src = in;
   size_t src_stride = in_col_stride;
   for (size_t pi = 0; pi < plan.size(); ++pi) {
     const Pass& ps = plan[pi];
     const bool first = pi == 0, last = pi + 1 == plan.size();
     const unsigned blocks = (unsigned)(((size_t)1 << log_n) >> ps.log_e);
-    hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks, ncols), dim3(256), 0, st, src, out, ps.log_e, ps.log_t,
-                       ps.log_lo, ps.nst, ps.t_first, dit, tw, log_n, first ? in_plain : 0,
-                       last ? out_plain : 0, last ? use_scale : 0, scale, src_stride, out_col_stride);
+    const int pb = first ? pad_log_b : 0;
+    hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks, ncols), dim3(NTT_THREADS), 0, st, src, out, ps.log_e, ps.log_t,
+                       ps.log_lo, ps.nst, ps.t_first, dit, tw, log_n, last ? use_scale : 0, scale, src_stride,
+                       out_col_stride, pb ? pad_G : (const uint64_t*)nullptr, pb, pb ? log_n - pad_log_b : 0);
     src = out;
     src_stride = out_col_stride;
   }
@@ -641,7 +675,7 @@ int sp_ntt_dev(const uint64_t* in, uint64_t* out, unsigned log_n, int inverse, v
     fe nm = fe_to_mont(fe{{(int32_t)(n & LMASK), (int32_t)(n >> LB), 0, 0, 0, 0, 0, 0, 0}});
     scale = fe_inv(nm);
   }
-  int rc = ntt_column(in, tmp, (int)log_n, inverse, 0, 1, 1, inverse, scale, st);
+  int rc = ntt_column(in, tmp, (int)log_n, inverse, 0, inverse, scale, st);
   if (rc != SP_OK) return rc;
   hipLaunchKernelGGL(bitrev_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp, out,
                      (int)log_n);
@@ -677,11 +711,16 @@ int sp_lde_dev(const uint64_t* in, uint64_t* out, unsigned ncols, unsigned log_n
   uint64_t* coef = (uint64_t*)work.ptr;
   if (ncols > 65535) { set_error("too many columns"); return SP_ERR_BAD_ARGUMENT; }
   if (ncols > 0) {
-    int rc = ntt_column(in, coef, (int)log_n, 1, 0, 1, 0, 0, FE_ONE_M, st, ncols, n, n);  // -> bit-reversed coefficients
+    int rc = ntt_column(in, coef, (int)log_n, 1, 0, 0, FE_ONE_M, st, ncols, n, n);  // -> bit-reversed coefficients
     if (rc != SP_OK) return rc;
-    hipLaunchKernelGGL(lde_pad_kernel, dim3((unsigned)((m + 255) / 256), ncols), dim3(256), 0, st, coef, out,
-                       (int)log_n, (int)log_blowup, G);
-    rc = ntt_column(out, out, (int)(log_n + log_blowup), 0, 1, 0, 1, 0, FE_ONE_M, st, ncols, m, m);
+    if (log_blowup > 0 && (int)log_blowup <= ((int)(log_n + log_blowup) < TILE_LOG ? (int)(log_n + log_blowup) : TILE_LOG)) {
+      // coset scaling + zero padding happen inside the first pass of the big transform (LDS only)
+      rc = ntt_column(coef, out, (int)(log_n + log_blowup), 0, 1, 0, FE_ONE_M, st, ncols, n, m, G, (int)log_blowup);
+    } else {  // no blowup: scale while copying, then transform in place
+      hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)((n + 255) / 256), ncols), dim3(256), 0, st, coef, out,
+                         (int)log_n, G);
+      rc = ntt_column(out, out, (int)log_n, 0, 1, 0, FE_ONE_M, st, ncols, m, m);
+    }
     if (rc != SP_OK) return rc;
   }
   SP_HIP(hipGetLastError());
@@ -760,11 +799,11 @@ int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, uns
   const fe w4 = h_root_of_unity(2);
   fe wk = FE_ONE_M;
   for (int k = 0; k < 4; ++k) {
-    prm.zinv[k] = fe_inv(fe_carry(fe_sub(fe_mul(sn, wk), FE_ONE_M)));
+    prm.zinv[k] = fe_mul(fe_inv(fe_carry(fe_sub(fe_mul(sn, wk), FE_ONE_M))), FE_R2);  // zinv * R^2
     wk = fe_mul(wk, w4);
   }
-  prm.shift_x = fe_to_mont(fe_unpack(PT_SHIFT_X));
-  prm.shift_y = fe_to_mont(fe_unpack(PT_SHIFT_Y));
+  prm.shift_x = fe_unpack(PT_SHIFT_X);
+  prm.shift_y = fe_unpack(PT_SHIFT_Y);
   hipLaunchKernelGGL(air_eval_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      trace_lde, periodic_lde, M, prm, out);
   SP_HIP(hipGetLastError());
@@ -805,11 +844,11 @@ int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodi
   const fe w4 = h_root_of_unity(2);
   fe wk = FE_ONE_M;
   for (int k = 0; k < 4; ++k) {
-    prm.zinv[k] = fe_inv(fe_carry(fe_sub(fe_mul(sn, wk), FE_ONE_M)));
+    prm.zinv[k] = fe_mul(fe_inv(fe_carry(fe_sub(fe_mul(sn, wk), FE_ONE_M))), FE_R2);  // zinv * R^2
     wk = fe_mul(wk, w4);
   }
-  prm.shift_x = fe_to_mont(fe_unpack(PT_SHIFT_X));
-  prm.shift_y = fe_to_mont(fe_unpack(PT_SHIFT_Y));
+  prm.shift_x = fe_unpack(PT_SHIFT_X);
+  prm.shift_y = fe_unpack(PT_SHIFT_Y);
   hipLaunchKernelGGL(air_eval_ec_ladder_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, trace_lde, periodic_lde, M, prm, out);
   SP_HIP(hipGetLastError());

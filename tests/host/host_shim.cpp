@@ -23,6 +23,10 @@ void t_fn_inv_fermat(const uint32_t* a, uint32_t* out) { from_mn(fn_inv_fermat(t
 void t_fe_inv_gcd(const uint32_t* a, uint32_t* out) { from_m(fe_inv_gcd(to_m(a)), out); }
 void t_fe_inv_gcd_var(const uint32_t* a, uint32_t* out) { from_m(fe_inv_gcd_var(to_m(a)), out); }
 void t_fe_inv_plain_gcd_var(const uint32_t* a, uint32_t* out) { store_plain(fe_inv_plain_gcd_var(load_plain(a)), out); }
+void t_fe_half(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  // half of (a - b) as plain integers: exercises negative and lazy inputs
+  store_plain(fe_canon(fe_half(fe_sub(load_plain(a), load_plain(b)))), out);
+}
 void t_fe_inv_plain_gcd(const uint32_t* a, uint32_t* out) { store_plain(fe_inv_plain_gcd(load_plain(a)), out); }
 int t_fe_is_qr(const uint32_t* a) { return fe_is_qr(to_m(a)) ? 1 : 0; }
 // (a - b) * (c + d) - e*f : exercises lazy add/sub feeding products

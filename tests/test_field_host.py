@@ -189,3 +189,15 @@ def test_jacobian_ladder(shim):
         q = rand_point(rng)
         shim.t_jac_mul(W(q[0]), W(q[1]), W(k), x, y)
         assert (I(x), I(y)) == R.ec_mult(k, q)
+
+
+def test_fe_half(shim):
+    """fe_half (the 1/2 of the FRI fold without a multiplication): (a - b) / 2 mod p for a, b < p."""
+    rng = random.Random(12)
+    out = (ctypes.c_uint32 * 8)()
+    inv2 = pow(2, -1, P)
+    pairs = [(0, 0), (1, 0), (0, 1), (P - 1, 0), (0, P - 1), (P - 1, P - 2), (2**251, 1), (5, 2**200)]
+    pairs += [(rng.randrange(P), rng.randrange(P)) for _ in range(2000)]
+    for a, b in pairs:
+        shim.t_fe_half(W(a), W(b), out)
+        assert I(out) == (a - b) * inv2 % P, (hex(a), hex(b))
