@@ -4,20 +4,28 @@ bench.py - headline benchmark of the MI355X hot path (contract: see the build br
 
 A "step" is one rebuild of a 2^16-leaf Pedersen Merkle tree per GPU (BASELINE.json configs[1]:
 "2^16-leaf position-tree Merkle rebuild"), inputs resident in HBM.  Steps are independent, so the K
-steps are advanced in lockstep groups of (by default) 32 trees per library call - the upper levels
-of one rebuild are latency-bound and would leave most of the chip idle.  With N > 1 ranks every
-step is a tree of N * 2^16 leaves: each rank rebuilds its own 2^16-leaf subtree (no data-path
-collective), the N sub-roots are exchanged with one RCCL all_gather (N x 32 bytes per tree) and the
-log2(N) top levels are hashed on every rank - weak scaling.
+steps are advanced as lockstep forests (sp_merkle_forest_dev: one launch per level serves every
+tree of the call) - the upper levels of one rebuild are latency-bound and would leave most of the
+chip idle.  With N > 1 ranks every step is a tree of N * 2^16 leaves: each rank rebuilds its own
+2^16-leaf subtree (no data-path collective), the N sub-roots are exchanged with one RCCL all_gather
+(N x 32 bytes per tree) and the log2(N) top levels are hashed on every rank - weak scaling.
 
-    python bench.py --gpus 1 --steps 64 --warmup 16
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `value` = Pedersen hashes/s over the whole job.  `roofline` is for
-the dominant kernel (ped_accumulate_kernel), timed with HIP events on its own stream inside the
-timed region; `cpu_baseline` is the oracle (pure-Python restatement of the reference algorithm)
-timed on the host cores of this box on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.  `value` = Pedersen hashes/s over the whole job.
+  roofline      the dominant kernel (ped_accumulate_kernel, the one-lane-per-hash bulk launches) against
+                the roofline that binds it - VALU issue - from HIP events around those launches inside
+                the timed region; the HBM fraction the contract names is the secondary `hbm` field;
+                `traffic` = HBM bytes per launch from rocprofv3 PMC passes, with the configuration
+                they were collected on.
+  airfri        the second half of BASELINE.json's metric: 2^20-row AIR+FRI commit jobs per second
+                (configs[3]), per-phase times with each phase's dominant kernel and HBM fraction, its own
+                roofline and a CPU baseline (oracle/stark_ref.py, build-defined, parity unpinned).
+  cpu_baseline  the oracle (pure-Python restatement of the reference algorithm) on the host cores, a
+                bounded sample of the same tree; cpu_baseline_c the same algorithm in C on the whole tree;
+                cpu_baseline_opt an optimised CPU comparator (windowed tables + batched affine additions).
 """
 import argparse
 import ctypes
@@ -96,6 +104,66 @@ def cpu_baseline_c(leaf_ints, gpu_root):
             "root_matches_gpu": levels[-1][0] == gpu_root}
 
 
+def cpu_baseline_opt(leaf_ints, gpu_root):
+    """Third CPU baseline, the one a CPU library would ship: the same function
+    with 8-bit fixed-base window tables and batched affine additions (one shared inversion per window and
+    256 hashes; last section of oracle/starkref.c), OpenMP over the host cores, the WHOLE 2^16-leaf rebuild
+    repeated until about two seconds have passed."""
+    from oracle import cref
+    levels, reps, dt = cref.opt_merkle_timed(leaf_ints, 2.0)
+    return {"value": reps * (len(leaf_ints) - 1) / dt, "unit": "hashes/s", "cores": cref.max_threads(),
+            "kind": "port", "algorithm": "optimised comparator: fixed-base 8-bit windows (63 table additions per "
+                                         "hash) + Montgomery's trick over 256 hashes, affine coordinates",
+            "sample": "%d complete 2^16-leaf rebuilds (65535 hashes each) in %.2f s inside the C library (window "
+                      "table built and leaves marshalled before the clock starts)" % (reps, dt),
+            "root_matches_gpu": levels[-1][0] == gpu_root}
+
+
+def cpu_airfri_baseline(log_rows=10):
+    """CPU side of the `airfri` object: the same commit job at 2^log_rows rows with oracle/stark_ref.py
+    (plain-Python NTT / composition / folds over Python ints) and the C oracle's Pedersen hash for the
+    commitments.  Build-defined like the GPU job (the reference has no prover): parity unpinned."""
+    import random
+    from oracle import cref, stark_ref as S
+    P = S.P
+    rng = random.Random(31)
+    m = (1 << log_rows) // S.ROWS_PER_HASH
+    inputs = [(rng.randrange(P), rng.randrange(P)) for _ in range(m)]
+    trace = S.pedersen_trace(inputs)  # witness generation: input preparation, as on the GPU side
+    n = len(trace[0])
+    alphas = [rng.randrange(P) for _ in range(S.N_CONSTRAINTS)]
+    log_lde = log_rows + 2
+    betas = [rng.randrange(P) for _ in range(log_lde - 6)]
+
+    def commit(columns):
+        leaves = list(columns[0])
+        for col in columns[1:]:
+            leaves = cref.pedersen_hash_many(leaves, list(col))[0]
+        return cref.merkle_levels(leaves)[-1][0]
+
+    t0 = time.time()
+    t_lde = [S.lde(col) for col in trace]
+    roots = [commit(t_lde)]
+    comp = S.composition_on_coset(t_lde, S.periodic_lde(n), n, alphas)
+    roots.append(commit([comp]))
+    layer, sh = comp, S.GEN
+    for k in range(log_lde - 6):
+        layer = S.fri_fold(layer, betas[k], sh)
+        sh = sh * sh % P
+        if len(layer) > 64:
+            roots.append(commit([layer]))
+    dt = time.time() - t0
+    hashes = 4 * (1 << log_lde) + (1 << log_lde) + sum((1 << k) for k in range(7, log_lde))
+    return {"value": 1.0 / dt, "unit": "commits/s of a 2^%d-row job" % log_rows, "cores": cref.max_threads(),
+            "kind": "port", "parity": "build-defined, parity unpinned (the reference has no prover; BASELINE.md 3.5)",
+            "sample": "one 2^%d-row job (LDE x4, 2 + %d commitments, composition, %d folds; %d Pedersen hashes "
+                      "through oracle/starkref.c with OpenMP, transforms in plain Python) in %.1f s"
+                      % (log_rows, log_lde - 7, log_lde - 6, hashes, dt),
+            "seconds": dt,
+            "scaled_to_2p20_rows": {"commits_per_sec": 1.0 / (dt * (1 << (20 - log_rows))),
+                                    "how": "work is linear in the rows up to log factors: x %d" % (1 << (20 - log_rows))}}
+
+
 def combine_check(slot, world, _lib):
     """N > 1: the job root of tree 0 of the last call issued on stream 0, recomputed from the gathered
     sub-roots (rank order) through the library's host-pointer tree entry point - a check of the
@@ -112,43 +180,74 @@ def combine_check(slot, world, _lib):
         return None
 
 
-def valu_issue(bulk_hashes_per_sec, window_bits, workload="2^22 independent hashes (bulk_pedersen_hashes_per_sec)"):
-    """The roofline that actually bounds the hash kernels: wave64 VALU
-    instructions issued per second against 1024 SIMDs x one instruction per 4 cycles.  Instruction
-    counts per hash are the SQ_INSTS_VALU measurements in profiles/r01_valu_issue.json; None when
-    there is no measurement for this window width."""
-    try:
-        m = json.load(open(os.path.join(ROOT, "profiles", "r01_valu_issue.json")))
-        w = m["window_bits"][str(window_bits)]
-    except Exception:
-        return None
-    per_hash = w["accumulate_instr_per_hash"] + w["finish_instr_per_hash"]
-    achieved = bulk_hashes_per_sec * per_hash / 64.0
-    peak = m["simds"] * m["nominal_clock_ghz"] * 1e9 / m["cycles_per_wave64_valu_instr"]
-    return {"bound": "valu_issue", "workload": workload,
-            "instr_per_hash": per_hash, "achieved": achieved, "peak": peak, "unit": "wave64 VALU instr/s",
-            "frac": achieved / peak,
-            "note": "peak at the nominal 2.4 GHz; the chip runs this kernel at about 1.9 GHz "
-                    "(GRBM_GUI_ACTIVE), where the measured issue interval is 4.2 cycles per SIMD"}
+VALU_PEAK_SIMDS, VALU_NOMINAL_GHZ, VALU_CYCLES_PER_INSTR = 1024, 2.4, 4.0
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py: separate --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE runs of this bench, FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md).  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        return json.load(open(path))["accumulate_kernels"]["hbm_bytes_per_launch"]
-    except Exception:
+def _valu_counts(window_bits):
+    """SQ_INSTS_VALU per hash of the bulk kernels (rocprofv3 --pmc, profiles/r0N_valu_issue.json, newest
+    first); None when there is no measurement for this window width."""
+    for name in ("r02_valu_issue.json", "r01_valu_issue.json"):
+        try:
+            m = json.load(open(os.path.join(ROOT, "profiles", name)))
+            w = m["window_bits"][str(window_bits)]
+            return w["accumulate_instr_per_hash"], w["finish_instr_per_hash"], name
+        except Exception:
+            continue
+    return None
+
+
+def valu_peak():
+    return VALU_PEAK_SIMDS * VALU_NOMINAL_GHZ * 1e9 / VALU_CYCLES_PER_INSTR
+
+
+VALU_PEAK_NOTE = ("peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 integer VALU instruction: the issue interval "
+                  "measured on this chip (profiles/r01_valu_rate_ubench.txt: 4.2-5.3 cycles for v_mad_u64_u32, "
+                  "v_add_co, v_mul_lo at 4 waves per SIMD; nothing integer below 4).  MI355X_MICROARCH.md quotes "
+                  "2 cycles for a wave64 v_fma_f32 on the SIMD-32; priced against that figure every VALU "
+                  "fraction here halves (frac_at_2_cycle_peak).  The chip sustains about 1.9 of the nominal "
+                  "2.4 GHz under this kernel (GRBM_GUI_ACTIVE)")
+
+
+def valu_issue(hashes_per_sec, window_bits, workload, include_finish=True):
+    """The roofline that binds the hash kernels: wave64 VALU instructions issued per
+    second against the chip's issue peak."""
+    c = _valu_counts(window_bits)
+    if c is None:
         return None
+    per_hash = c[0] + (c[1] if include_finish else 0)
+    achieved = hashes_per_sec * per_hash / 64.0
+    peak = valu_peak()
+    return {"bound": "valu_issue", "workload": workload, "instr_per_hash": per_hash,
+            "instr_source": "profiles/" + c[2], "achieved": achieved, "peak": peak,
+            "unit": "wave64 VALU instr/s", "frac": achieved / peak, "frac_at_2_cycle_peak": achieved / (2 * peak)}
+
+
+def pmc_traffic(kernel, this_config, files=("r02_pmc_traffic.json", "r01_pmc_traffic.json")):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE runs, tools/pmc_traffic.py; units and gfx950 calibration in its docstring), and
+    the configuration those passes ran - traffic is only comparable with this run when they agree."""
+    for name in files:
+        try:
+            m = json.load(open(os.path.join(ROOT, "profiles", name)))
+            k = m["kernels"][kernel]
+            cfg = m.get("config", "bench.py r01 default: --steps 128 --warmup 16, 64 trees per call, 2 streams, "
+                                  "26-bit windows (NOT this run's configuration)")
+            return {"bytes_per_launch": k.get("hbm_bytes_per_launch_fetch_doubled", k["hbm_bytes_per_launch"]),
+                    "fetch_size_doubled_for_coalesced_reads": "hbm_bytes_per_launch_fetch_doubled" in k,
+                    "fetch_bytes_per_launch": k["fetch_bytes_per_launch"],
+                    "write_bytes_per_launch": k["write_bytes_per_launch"], "launches_profiled": k["launches"],
+                    "source": "profiles/" + name, "collected_on": cfg,
+                    "same_configuration_as_this_run": m.get("config_key") == this_config}
+        except Exception:
+            continue
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--trees-per-call", type=int, default=64,
                     help="independent 2^16-leaf rebuilds advanced in lockstep by one library call "
                          "(sp_merkle_forest_dev: one launch pair per level serves all of them; the upper "
@@ -179,6 +278,8 @@ def main():
                          "treating it as input preparation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-airfri", action="store_true",
+                    help="merkle workload: skip the `airfri` object (the 2^20-row AIR+FRI half of the metric)")
     args = ap.parse_args()
 
     import torch
@@ -304,9 +405,35 @@ def main():
     value = hashes_per_step * args.steps / elapsed
 
     if rank == 0:
-        avg_launch_s = (k_ms.value / 1e3) / max(k_launches.value, 1)
-        bytes_per_launch = ALGO_BYTES_PER_HASH * k_units.value / max(k_launches.value, 1)
-        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        wbits = int(lib.sp_window_bits())
+        n_l = max(int(k_launches.value), 1)
+        avg_launch_s = (k_ms.value / 1e3) / n_l
+        hashes_per_launch = k_units.value / n_l
+        kernel_rate = hashes_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0  # hashes/s inside the bulk launches
+        hbm_gbs = ALGO_BYTES_PER_HASH * kernel_rate / 1e9
+        config_key = "merkle:steps=%d:calls=%s:streams=%d:w=%d" % (args.steps, ",".join(map(str, timed_plan)),
+                                                                  n_streams, wbits)
+        roof = valu_issue(kernel_rate, wbits, "inside the ped_accumulate_kernel launches of the timed region "
+                                              "(HIP events around each of them)", include_finish=False) or {
+            "bound": "valu_issue", "achieved": None, "peak": valu_peak(), "unit": "wave64 VALU instr/s", "frac": None}
+        roof.update({
+            "kernel": "ped_accumulate_kernel (one lane per hash: every level of more than 65 536 hashes; %.0f %% of "
+                      "the hashes of this run)" % (100.0 * k_units.value / max(hashes_per_step * args.steps / max(world, 1), 1)),
+            "peak_basis": VALU_PEAK_NOTE,
+            "launches": int(k_launches.value), "hashes_per_launch": hashes_per_launch,
+            "avg_launch_us": avg_launch_s * 1e6,
+            "timing": "HIP events around every ped_accumulate_kernel launch inside the timed region, on the "
+                      "stream it is launched on (sp_profile_begin/_end)",
+            "traffic": pmc_traffic("sp::ped_accumulate_kernel", config_key),
+            "hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm_gbs / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_hash": ALGO_BYTES_PER_HASH,
+                    "note": "the roofline the contract names; this kernel is integer-ALU bound (about 31 k VALU "
+                            "instructions per 96 algorithmic bytes), so the HBM fraction says nothing about it"},
+            "whole_region": valu_issue(value / max(world, 1), wbits,
+                                       "every kernel of the timed region: hashes/s per GPU over the wall time "
+                                       "(latency-bound upper levels included)"),
+        })
         result = {
             "metric": "pedersen_hashes_per_sec",
             "value": value,
@@ -328,31 +455,19 @@ def main():
                 "trees_per_call": B,
                 "streams": n_streams,
                 "timed_calls": timed_plan,
-                "window_bits": int(lib.sp_window_bits()),
+                "ms_per_step_note": "steps advance in lockstep: ms_per_step is wall time / steps, not the latency "
+                                    "of one rebuild (extra.single_tree_rebuild_ms_one_stream has that)",
+                "window_bits": wbits,
                 "table_mib": lib.sp_table_bytes() / 2**20,
                 "combine": "none" if world == 1 else "all_gather of %d sub-roots (RCCL) + %d top hashes" % (
                     world, world - 1),
             },
-            "roofline": {
-                "kernel": "ped_accumulate_kernel / ped_accumulate_split_kernel<L> (the window-table summation)",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_per_launch(),
-                "launches": int(k_launches.value),
-                "avg_launch_us": avg_launch_s * 1e6,
-                "timing": "HIP events around every launch inside the timed region",
-                "valu_issue": valu_issue(value / max(world, 1), int(lib.sp_window_bits()),
-                                         "this run: hashes/s per GPU over the whole timed region"),
-                "note": "integer-ALU bound kernel (DESIGN.md section 4): 31-38e3 VALU instructions per hash at the "
-                        "VALU issue limit (extra.valu_issue has that roofline); the HBM fraction is reported "
-                        "because the contract asks for it",
-            },
+            "roofline": roof,
         }
         if world > 1:
             result["combine_matches_recomputed"] = combine_check(slots[0], world, _lib)
+        if world == 1 and not args.no_airfri:
+            result["airfri"] = airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline)
         if world == 1 and not args.no_extras:
             result["extra"] = extras(torch, lib, _lib, dev, stream)
         if world == 1 and not args.no_cpu_baseline:
@@ -368,9 +483,11 @@ def main():
                 len(cpu_out))
             base["matches_gpu"] = gpu_l1 == cpu_out
             result["cpu_baseline"] = base
-            result["cpu_baseline_c"] = cpu_baseline_c(leaf_ints, _lib.unpack_felts(
+            gpu_root = _lib.unpack_felts(
                 (ctypes.c_uint64 * 4).from_buffer_copy(
-                    levels[levels.shape[0] - B : levels.shape[0] - B + 1].cpu().numpy().astype("<i8").tobytes()), 1)[0])
+                    levels[levels.shape[0] - B : levels.shape[0] - B + 1].cpu().numpy().astype("<i8").tobytes()), 1)[0]
+            result["cpu_baseline_c"] = cpu_baseline_c(leaf_ints, gpu_root)
+            result["cpu_baseline_opt"] = cpu_baseline_opt(leaf_ints, gpu_root)
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()
@@ -477,20 +594,142 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
                                    "GPU)" % (args.log_rows, log_lde - 6, log_lde - 7),
                        "rows_per_gpu": 512 * m, "pedersen_hashes_per_job": hashes, "streams": n_streams,
                        "combine": "none" if world == 1 else "all_gather of 17 roots per rank + top hashes"},
-            "roofline": {
-                "kernel": "ped_accumulate_kernel / ped_accumulate_split_kernel<L> (commit trees and row chains)",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "launches": int(k_launches.value), "hashes_in_timed_launches": int(k_units.value),
-                "avg_launch_us": avg_launch_s * 1e6,
-                "timing": "HIP events around every launch inside the timed region",
-                "note": "integer-ALU bound kernel, see the headline workload's roofline / extra.valu_issue",
-            },
-            "cpu_baseline": None,
+            "roofline": dict(
+                valu_issue((k_units.value / max(k_launches.value, 1)) / avg_launch_s if avg_launch_s > 0 else 0.0,
+                           int(lib.sp_window_bits()), "inside the ped_accumulate_kernel launches of the timed region",
+                           include_finish=False) or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None},
+                kernel="ped_accumulate_kernel (row chains and commit-tree levels above 65 536 hashes)",
+                peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value),
+                hashes_in_timed_launches=int(k_units.value), avg_launch_us=avg_launch_s * 1e6,
+                timing="HIP events around every ped_accumulate_kernel launch inside the timed region",
+                traffic=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
+                hbm={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS}),
+            "cpu_baseline": (cpu_airfri_baseline(10) if (world == 1 and not args.no_cpu_baseline) else None),
         }))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def airfri_object(torch, lib, _lib, dev, with_cpu):
+    """BASELINE.json configs[3], the second half of the metric: one 2^20-row Pedersen-step trace ->
+    4-column LDE to 2^22 -> commit -> composition -> commit -> 16 folds with 15 layer commits (25.2 M
+    Pedersen hashes).  Inputs (the witness) resident in HBM.  commits_per_sec times independent jobs
+    alternating over three streams, exactly what `--workload airfri` times per GPU."""
+    import random
+    from starkperp import stark
+    m = 2048
+    n_rows, n_lde, cols = 512 * m, 4 * 512 * m, 4
+    xs, ys = seeded_felts(torch, m, 11, dev), seeded_felts(torch, m, 12, dev)
+    rng = random.Random(13)
+    P = stark.FIELD_PRIME
+    alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
+    betas = [rng.randrange(P) for _ in range(16)]
+    trace = stark.pedersen_trace(xs, ys)  # witness generation is input preparation
+    per = stark.periodic_lde(n_rows, stark.FIELD_GEN, dev)
+    torch.cuda.synchronize()
+
+    def timed(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    def job():
+        t_lde = stark.lde(trace)
+        stark.commit_rows(t_lde)
+        comp = stark.air_eval(t_lde, per, n_rows, alphas)
+        stark.commit_rows(comp.unsqueeze(0))
+        layer, sh, k = comp, stark.FIELD_GEN, 0
+        while layer.shape[0] > 64:
+            layer = stark.fri_fold(layer, betas[k], sh)
+            sh = sh * sh % P
+            k += 1
+            if layer.shape[0] > 64:
+                stark.commit_rows(layer.unsqueeze(0))
+
+    hashes = 4 * n_lde + n_lde + sum((1 << k) for k in range(7, 22))
+    out = {"workload": "2^20-row trace, blowup 4, 11 constraints, folds down to 64 points (BASELINE.json configs[3])",
+           "pedersen_hashes_per_job": hashes, "data": "synthetic", "dtype": "u32x9 (29-bit limbs) mod p"}
+    # one job after the other on one stream, with HIP events around the bulk hash launches
+    job()
+    torch.cuda.synchronize()
+    _lib.check(lib.sp_profile_begin(3 * 64), "profile_begin")
+    t_seq = timed(job, 2)
+    k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)), "profile_end")
+    out["seconds_per_job_one_stream"] = t_seq
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+
+    def pipelined(njobs):
+        for i in range(njobs):
+            with torch.cuda.stream(streams[i % 3]):
+                job()
+        torch.cuda.synchronize()
+
+    pipelined(3)
+    t0 = time.perf_counter()
+    pipelined(9)
+    out["commits_per_sec"] = 9 / (time.perf_counter() - t0)
+    out["commits_per_sec_note"] = "9 independent jobs alternating over 3 streams (tree tops of one job beside the row " \
+                                  "hashing of the next); one job at a time: %.1f commits/s" % (1.0 / t_seq)
+    out["witness_generation_seconds"] = timed(lambda: stark.pedersen_trace(xs, ys), 2)
+    t_lde = stark.lde(trace)
+    comp = stark.air_eval(t_lde, per, n_rows, alphas)
+    phase_s = {
+        "lde_4cols_2p20_to_2p22": timed(lambda: stark.lde(trace), 3),
+        "commit_trace_lde_4cols_2p22_rows": timed(lambda: stark.commit_rows(t_lde), 2),
+        "air_eval_2p22_points": timed(lambda: stark.air_eval(t_lde, per, n_rows, alphas), 3),
+        "commit_composition_2p22_rows": timed(lambda: stark.commit_rows(comp.unsqueeze(0)), 2),
+        "fri_fold_first_layer_2p22": timed(lambda: stark.fri_fold(comp, betas[0], stark.FIELD_GEN), 5),
+    }
+    # algorithmic bytes (SURVEY 8(d)): an NTT pass reads and writes each felt once; the 2^20-point inverse
+    # transform takes 2 passes, the 2^22-point forward one 3, the first of which reads the 2^20 coefficients
+    # (coset scaling and zero padding happen in LDS) and writes 2^22 points; composition: 7 trace + 6
+    # periodic reads and one write of 32 B per point; fold: 32 B read, 16 B written per input point; commit
+    # of M rows of W felts: 32 W M read, 32 (2 M) written
+    algo = {
+        "lde_4cols_2p20_to_2p22": cols * (2 * 64 * n_rows + 32 * n_rows + 32 * n_lde + 2 * 64 * n_lde),
+        "commit_trace_lde_4cols_2p22_rows": 32 * cols * n_lde + 64 * n_lde,
+        "air_eval_2p22_points": (7 + 6 + 1) * 32 * n_lde,
+        "commit_composition_2p22_rows": 32 * n_lde + 64 * n_lde,
+        "fri_fold_first_layer_2p22": (32 + 16) * n_lde,
+    }
+    dominant = {"lde_4cols_2p20_to_2p22": ("ntt_tile_kernel", "valu (one 174-instruction multiplication per butterfly "
+                                           "and 64 B; 0.30 of 8 TB/s would be 100 % VALU issue)"),
+                "commit_trace_lde_4cols_2p22_rows": ("ped_accumulate_kernel", "valu_issue"),
+                "air_eval_2p22_points": ("air_eval_kernel", "valu"),
+                "commit_composition_2p22_rows": ("ped_accumulate_kernel", "valu_issue"),
+                "fri_fold_first_layer_2p22": ("fri_fold_kernel", "valu / hbm")}
+    out["phases"] = {k: {"seconds": phase_s[k], "dominant_kernel": dominant[k][0], "bound": dominant[k][1],
+                         "algorithmic_bytes": algo[k], "hbm_gb_per_s": algo[k] / phase_s[k] / 1e9,
+                         "hbm_frac_of_8_tb_per_s": algo[k] / phase_s[k] / 1e9 / HBM_PEAK_GBS,
+                         "traffic_per_launch_of_dominant_kernel": pmc_traffic(
+                             "sp::" + dominant[k][0], "airfri", ("r02_pmc_traffic_airfri.json",))} for k in phase_s}
+    n_l = max(int(k_launches.value), 1)
+    rate = (k_units.value / n_l) / ((k_ms.value / 1e3) / n_l) if k_ms.value > 0 else 0.0
+    roof = valu_issue(rate, int(lib.sp_window_bits()),
+                      "inside the ped_accumulate_kernel launches of three sequential jobs (HIP events)",
+                      include_finish=False) or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None}
+    roof.update({"kernel": "ped_accumulate_kernel (row chains and the tree levels above 65 536 hashes: %.0f %% of the "
+                           "job's hashes)" % (100.0 * k_units.value / (3.0 * hashes)),
+                 "launches": int(k_launches.value), "avg_launch_us": (k_ms.value / n_l) * 1e3,
+                 "traffic": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
+                 "hbm": {"achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}})
+    out["roofline"] = roof
+    stark.prove(xs, ys, n_queries=8, seed=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stark.prove(xs, ys, n_queries=8, seed=1)
+    torch.cuda.synchronize()
+    out["prove_seconds_own_witness_8_queries"] = time.perf_counter() - t0
+    out["cpu_baseline"] = cpu_airfri_baseline(10) if with_cpu else None
+    return out
 
 
 def extras(torch, lib, _lib, dev, stream):
@@ -523,7 +762,8 @@ def extras(torch, lib, _lib, dev, stream):
     out["bulk_pedersen_hashes_per_sec"] = n / s
     out["bulk_pedersen_batch"] = n
     del x, y, o
-    out["valu_issue"] = valu_issue(n / s, int(lib.sp_window_bits()))
+    out["valu_issue"] = valu_issue(n / s, int(lib.sp_window_bits()),
+                                   "2^22 independent hashes, accumulate + finish kernels (bulk_pedersen_hashes_per_sec)")
 
     # BASELINE.json configs[0]: the reference's scalar API, one call at a time through the import overlay
     # (host-inclusive latency per call; the reference itself: 11 ms / 16 ms / 60 ms per hash / sign / verify)
@@ -638,84 +878,6 @@ def extras(torch, lib, _lib, dev, stream):
     out["ecdsa_sign_sample_matches_host_nonces"] = bool(
         signed[:64] == _batch._sign_many_host_nonces(zv[:64], dsk[:64], [None] * 64))
 
-    # BASELINE.json configs[3]: 2^20-row trace -> LDE -> commit -> AIR -> commit -> FRI (+commits)
-    import random
-    from starkperp import stark
-    m = 2048
-    xs, ys = seeded_felts(torch, m, 11, dev), seeded_felts(torch, m, 12, dev)
-    rng = random.Random(13)
-    P = stark.FIELD_PRIME
-    alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
-    betas = [rng.randrange(P) for _ in range(16)]
-    trace = stark.pedersen_trace(xs, ys)          # witness generation, outside the timed job
-    per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
-    torch.cuda.synchronize()
-    out["witness_generation_seconds_2p20_rows"] = timed(lambda: stark.pedersen_trace(xs, ys), 2)
-
-    def job():
-        t_lde = stark.lde(trace)
-        stark.commit_rows(t_lde)
-        comp = stark.air_eval(t_lde, per, 512 * m, alphas)
-        stark.commit_rows(comp.unsqueeze(0))
-        layer, sh, k = comp, stark.FIELD_GEN, 0
-        while layer.shape[0] > 64:
-            layer = stark.fri_fold(layer, betas[k], sh)
-            sh = sh * sh % P
-            k += 1
-            if layer.shape[0] > 64:
-                stark.commit_rows(layer.unsqueeze(0))
-
-    s = timed(job, 2)
-    out["air_fri_commit_seconds_2p20_rows"] = s
-    out["air_fri_commits_per_sec"] = 1.0 / s
-    # independent jobs alternating over two streams (what `--workload airfri` times): the
-    # latency-bound tree tops of one job overlap the row hashing of the next
-    side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-
-    def pipelined(njobs):
-        for i in range(njobs):
-            with torch.cuda.stream(side[i % 2]):
-                job()
-        torch.cuda.synchronize()
-
-    pipelined(2)
-    t0 = time.perf_counter()
-    pipelined(8)
-    out["air_fri_commits_per_sec_jobs_on_two_streams"] = 8 / (time.perf_counter() - t0)
-
-    def phase(fn):
-        return timed(fn, 2)
-
-    t_lde = stark.lde(trace)
-    out["phase_seconds"] = {
-        "lde_4cols_2p20_to_2p22": phase(lambda: stark.lde(trace)),
-        "commit_trace_lde_4cols_2p22_rows": phase(lambda: stark.commit_rows(t_lde)),
-        "air_eval_2p22_points": phase(lambda: stark.air_eval(t_lde, per, 512 * m, alphas)),
-        "fri_fold_first_layer_2p22": phase(
-            lambda: stark.fri_fold(t_lde[0], betas[0], stark.FIELD_GEN)),
-    }
-    # the full prover on top of the commit job: witness generation, Fiat-Shamir challenges derived from
-    # the roots (so nothing overlaps inside a proof), eight queries with all their Merkle openings
-    stark.prove(xs, ys, n_queries=8, seed=0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    stark.prove(xs, ys, n_queries=8, seed=1)
-    torch.cuda.synchronize()
-    out["prove_seconds_2p20_rows_8_queries"] = time.perf_counter() - t0
-    # BASELINE.json configs[3] asks for the HBM fraction of the streaming phases: algorithmic bytes
-    # (64 B per element per NTT pass, 2 + 3 passes at 2^20 / 2^22 with 2048-felt tiles; the
-    # pad reads 32 B per coefficient and writes 32 B per LDE point; AIR: 7 trace + 6 periodic reads and
-    # one write of 32 B per point; fold: 32 B read, 16 B written per input point) over the measured time
-    n_rows, n_lde, cols = 512 * m, 4 * 512 * m, 4
-    algo = {
-        "lde_4cols_2p20_to_2p22": cols * (2 * 64 * n_rows + 32 * n_rows + 32 * n_lde + 3 * 64 * n_lde),
-        "air_eval_2p22_points": (7 + 6 + 1) * 32 * n_lde,
-        "fri_fold_first_layer_2p22": (32 + 16) * n_lde,
-    }
-    out["phase_hbm"] = {
-        k: {"algorithmic_bytes": b, "achieved_gb_per_s": b / out["phase_seconds"][k] / 1e9,
-            "frac_of_8_tb_per_s": b / out["phase_seconds"][k] / 1e9 / HBM_PEAK_GBS}
-        for k, b in algo.items()}
     return out
 
 

@@ -48,6 +48,55 @@ def pedersen_hash_many(xs, ys):
     return _unpack(out, n), list(bytes(st))
 
 
+def opt_pedersen_hash_many(xs, ys):
+    """The optimised comparator (windowed tables + batched affine additions): same outputs."""
+    n = len(xs)
+    out = (ctypes.c_uint64 * (4 * n))()
+    st = (ctypes.c_uint8 * n)()
+    lib().cref_opt_pedersen_batch(_pack(xs), _pack(ys), out, st, ctypes.c_size_t(n))
+    return _unpack(out, n), list(bytes(st))
+
+
+def opt_merkle_levels(leaves):
+    n = len(leaves)
+    height = n.bit_length() - 1
+    assert n == 1 << height
+    buf = (ctypes.c_uint64 * (4 * (2 * n - 1)))()
+    ctypes.memmove(buf, _pack(leaves), 32 * n)
+    lib().cref_opt_merkle_build(buf, ctypes.c_uint(height))
+    flat = _unpack(buf, 2 * n - 1)
+    levels, off, width = [], 0, n
+    while width >= 1:
+        levels.append(flat[off : off + width])
+        off += width
+        width //= 2
+    return levels
+
+
+def opt_merkle_timed(leaves, min_seconds=2.0, max_reps=256):
+    """Repeats the optimised rebuild on one marshalled buffer (the leaves stay in place, the upper levels
+    are overwritten): returns (levels, repetitions, seconds inside the C library)."""
+    import time
+    n = len(leaves)
+    height = n.bit_length() - 1
+    assert n == 1 << height
+    buf = (ctypes.c_uint64 * (4 * (2 * n - 1)))()
+    ctypes.memmove(buf, _pack(leaves), 32 * n)
+    lib().cref_opt_merkle_build(buf, ctypes.c_uint(height))  # builds the window table on first use
+    reps, t0, dt = 0, time.time(), 0.0
+    while dt < min_seconds and reps < max_reps:
+        lib().cref_opt_merkle_build(buf, ctypes.c_uint(height))
+        reps += 1
+        dt = time.time() - t0
+    flat = _unpack(buf, 2 * n - 1)
+    levels, off, width = [], 0, n
+    while width >= 1:
+        levels.append(flat[off : off + width])
+        off += width
+        width //= 2
+    return levels, reps, dt
+
+
 def merkle_levels(leaves):
     n = len(leaves)
     height = n.bit_length() - 1

@@ -10,6 +10,9 @@
  * Parity status: PINNED by tests/test_oracle_c.py against the reference-generated goldens
  * (tests/golden/g1, g2, g4, g6_c2) - the same vectors that pin oracle/ref_py.py.
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The last section of the file is the OPTIMISED CPU comparator (windowed fixed-base tables + batched
+ * affine additions): same function, a tuned algorithm, pinned by the same goldens - it exists so that
+ * the GPU numbers are also compared with a CPU implementation nobody would call naive.
  *
  * Build: gcc -O3 -fopenmp -shared -fPIC oracle/starkref.c -o oracle/_build/libstarkref.so
  * Felts are 4 x uint64 little-endian, plain integers.
@@ -283,6 +286,143 @@ void cref_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* s, 
     result[i] = (uint8_t)verify_point(&a, &b, &c, &q);
   }
 }
+/* =============================================================================================
+ * Optimised CPU comparator: the SAME function pedersen_hash(x, y), computed
+ * the way a tuned CPU library would - NOT the reference's algorithm.  Fixed-base 8-bit windows over the
+ * 504-bit string x || y (63 windows x 255 precomputed affine sums of the reference's per-bit points,
+ * 1 MiB, built once from CONST_POINTS) and batched affine additions: BATCH hashes advance window by
+ * window in lockstep and share ONE modular inversion per window (Montgomery's trick: 3 multiplications
+ * per addition for the shared inversion + 3 for the chord rule, instead of the ~250 inversions per
+ * hash of the naive path above).  Checked against the same reference goldens (tests/test_oracle_c.py).
+ * A window value of 0 skips its addition; an x-collision (acc.x == entry.x, where the reference would
+ * raise "Unhashable input." or a windowed sum happens to meet the partial sum) falls back to the
+ * naive loop for that hash, whose verdict is the reference's.
+ * ============================================================================================= */
+#define OPT_WINDOWS 63
+#define OPT_BATCH 256
+static point* OPT_TABLE = 0; /* [63][256], entry 0 unused; Montgomery form */
+static u256 MONT_ONE;
+static void to_mont(u256* r, const u256* a) { mont_mul(r, a, &MP.r2, &MP); }
+static void from_mont(u256* r, const u256* a) { const u256 one = {{1, 0, 0, 0}}; mont_mul(r, a, &one, &MP); }
+extern void* malloc(unsigned long);
+static void opt_init(void) {
+  init_tables();
+  if (OPT_TABLE) return;
+#pragma omp critical
+  {
+    if (!OPT_TABLE) {
+      point* tab = (point*)malloc(sizeof(point) * OPT_WINDOWS * 256);
+      const u256 one = {{1, 0, 0, 0}};
+      to_mont(&MONT_ONE, &one);
+      for (int g = 0; g < OPT_WINDOWS; ++g) {
+        point* row = tab + 256 * g;
+        for (int v = 1; v < 256; ++v) {
+          const int low = v & (v - 1);            /* v without its lowest set bit */
+          const int bit = __builtin_ctz(v);
+          const point* c = &CONST_POINTS[2 + 8 * g + bit];
+          if (low == 0) row[v] = *c;
+          else ec_add(&row[v], &row[low], c);      /* distinct multiples of independent points: no collision */
+        }
+      }
+      for (int i = 0; i < OPT_WINDOWS * 256; ++i) {
+        if ((i & 255) == 0) continue;
+        to_mont(&tab[i].x, &tab[i].x); to_mont(&tab[i].y, &tab[i].y);
+      }
+      OPT_TABLE = tab;
+    }
+  }
+}
+/* n <= OPT_BATCH hashes in lockstep; inputs already range-checked by the caller (status 0) */
+static void opt_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n) {
+  point acc[OPT_BATCH];
+  u256 dx[OPT_BATCH], pre[OPT_BATCH];
+  const point* ent[OPT_BATCH];
+  uint8_t bits[OPT_BATCH][64];
+  point shift_m;
+  to_mont(&shift_m.x, &CONST_POINTS[0].x); to_mont(&shift_m.y, &CONST_POINTS[0].y);
+  for (size_t i = 0; i < n; ++i) {
+    acc[i] = shift_m;
+    /* the 504-bit string x || y (x: 252 bits), one byte per window */
+    uint64_t w[8];
+    memcpy(w, x + 4 * i, 32);
+    uint64_t yw[4]; memcpy(yw, y + 4 * i, 32);
+    /* string = x | (y << 252) */
+    uint64_t str[8] = {w[0], w[1], w[2], w[3] | (yw[0] << 60), (yw[0] >> 4) | (yw[1] << 60), (yw[1] >> 4) | (yw[2] << 60),
+                       (yw[2] >> 4) | (yw[3] << 60), yw[3] >> 4};
+    memcpy(bits[i], str, 64);
+  }
+  for (int g = 0; g < OPT_WINDOWS; ++g) {
+    /* pass 1: denominators and their running product */
+    u256 run = MONT_ONE;
+    for (size_t i = 0; i < n; ++i) {
+      const int v = bits[i][g];
+      ent[i] = v ? &OPT_TABLE[256 * g + v] : 0;
+      if (status[i] || !ent[i]) { ent[i] = 0; continue; }
+      submod(&dx[i], &ent[i]->x, &acc[i].x, &P);
+      if (is_zero(&dx[i])) { status[i] = 3; ent[i] = 0; continue; }  /* collision: redo this hash naively */
+      pre[i] = run;
+      mont_mul(&run, &run, &dx[i], &MP);
+    }
+    /* one inversion for the whole batch (plain inverse of the Montgomery value, then back to Montgomery) */
+    u256 plain, inv;
+    from_mont(&plain, &run);
+    if (!invmod(&inv, &plain, &P)) continue;  /* nothing to add in this window */
+    to_mont(&inv, &inv);
+    /* pass 2: individual inverses, chord rule */
+    for (size_t k = n; k-- > 0;) {
+      if (!ent[k]) continue;
+      u256 idx, lam, t, yy;
+      mont_mul(&idx, &inv, &pre[k], &MP);
+      mont_mul(&inv, &inv, &dx[k], &MP);
+      submod(&t, &ent[k]->y, &acc[k].y, &P);
+      mont_mul(&lam, &t, &idx, &MP);
+      mont_mul(&t, &lam, &lam, &MP);
+      submod(&t, &t, &acc[k].x, &P); submod(&t, &t, &ent[k]->x, &P);
+      submod(&yy, &acc[k].x, &t, &P); mont_mul(&yy, &lam, &yy, &MP); submod(&yy, &yy, &acc[k].y, &P);
+      acc[k].x = t; acc[k].y = yy;
+    }
+  }
+  for (size_t i = 0; i < n; ++i) {
+    u256 o = {{0, 0, 0, 0}};
+    if (status[i] == 0) from_mont(&o, &acc[i].x);
+    else if (status[i] == 3) {
+      u256 a, b; memcpy(&a, x + 4 * i, 32); memcpy(&b, y + 4 * i, 32);
+      status[i] = (uint8_t)pedersen_one(&a, &b, &o);
+    }
+    memcpy(out + 4 * i, &o, 32);
+  }
+}
+void cref_opt_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n) {
+  opt_init();
+  const long nb = (long)((n + OPT_BATCH - 1) / OPT_BATCH);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (long b = 0; b < nb; ++b) {
+    const size_t lo = (size_t)b * OPT_BATCH, cnt = n - lo < OPT_BATCH ? n - lo : OPT_BATCH;
+    for (size_t i = 0; i < cnt; ++i) {
+      u256 a, c; memcpy(&a, x + 4 * (lo + i), 32); memcpy(&c, y + 4 * (lo + i), 32);
+      status[lo + i] = (cmp(&a, &P) >= 0 || cmp(&c, &P) >= 0) ? 1 : 0;
+    }
+    opt_batch(x + 4 * lo, y + 4 * lo, out + 4 * lo, status + lo, cnt);
+  }
+}
+extern void free(void*);
+/* full rebuild with the optimised hash; levels: 2^(height+1) - 1 felts, leaves first */
+void cref_opt_merkle_build(uint64_t* levels, unsigned height) {
+  opt_init();
+  uint64_t* cur = levels;
+  for (size_t n = (size_t)1 << height; n > 1; n >>= 1) {
+    uint64_t* nxt = cur + 4 * n;
+    const size_t m = n / 2;
+    uint64_t* xs = (uint64_t*)malloc(64 * m + 64);
+    uint64_t* ys = xs + 4 * m;
+    uint8_t* st = (uint8_t*)malloc(m + 1);
+    for (size_t i = 0; i < m; ++i) { memcpy(xs + 4 * i, cur + 8 * i, 32); memcpy(ys + 4 * i, cur + 8 * i + 4, 32); }
+    cref_opt_pedersen_batch(xs, ys, nxt, st, m);
+    free(xs); free(st);
+    cur = nxt;
+  }
+}
+
 int cref_max_threads(void) {
 #ifdef _OPENMP
   extern int omp_get_max_threads(void);

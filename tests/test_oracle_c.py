@@ -54,3 +54,25 @@ def test_verify_point_key_cases():
     for c, code in zip(cases, codes):
         got = {0: "false", 1: "true"}.get(code) or names[code]
         assert got == c["expect"], c["label"]
+
+
+def test_optimised_comparator_matches_the_reference_goldens():
+    """The optimised CPU comparator (windowed tables + batched affine additions, last section of
+    oracle/starkref.c) computes the same function: all 1024 + 36 reference hashes, the range check, the
+    reference's own two KATs, and the complete 2^16-leaf tree level by level."""
+    g = load("g1_pedersen.json")
+    pairs = wl.pedersen_pairs(g["n"], seed=g["seed"])
+    out, st = cref.opt_pedersen_hash_many([p[0] for p in pairs], [p[1] for p in pairs])
+    assert not any(st) and out == [h(v) for v in g["all"]]
+    xs, ys, exp = zip(*[(h(a), h(b), h(o)) for a, b, o in g["edge"]])
+    out, st = cref.opt_pedersen_hash_many(xs, ys)
+    assert not any(st) and out == list(exp)
+    out, st = cref.opt_pedersen_hash_many([P, 1, 5], [0, P + 5, 6])
+    assert st == [1, 1, 0] and out[2] == R.pedersen_hash(5, 6)
+    k = load("reference_kats.json")
+    for case in k["hash_test"].values():
+        assert cref.opt_pedersen_hash_many([h(case["input_1"])], [h(case["input_2"])])[0] == [h(case["output"])]
+    t = load("g6_c2_tree.json")
+    levels = cref.opt_merkle_levels(wl.leaves(1 << 16, seed=t["seed"]))
+    assert levels[-1][0] == h(t["root"])
+    assert [wl.digest_felts(l) for l in levels] == t["level_digests"]

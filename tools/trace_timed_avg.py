@@ -11,7 +11,7 @@ import sys
 
 def main():
     path, n = sys.argv[1], int(sys.argv[2])
-    rows = [r for r in csv.DictReader(open(path)) if "ped_accumulate" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "ped_accumulate_kernel(" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
     print("accumulate launches in trace: %d, average %.1f us" % (len(us), sum(us) / len(us)))
