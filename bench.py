@@ -495,21 +495,28 @@ def main():
 
 
 def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
-    """configs[3]/[4]: every rank proves the commitments of its own 2^20-row segment (disjoint trace
-    row ranges); the 17 commitment roots per rank are exchanged with one all_gather (17 x 32 B per
-    rank) and combined into 17 job-level roots by hashing the log2(N) top levels on every rank."""
+    """configs[3] (N = 1: independent 2^k-row jobs alternating over streams) and configs[4] (N > 1: ONE
+    trace of N * 2^k rows sharded over the ranks by starkperp.sharded_prover - LDE units spread over the
+    ranks, one bulk all-to-all into LDE-row shards with a halo, per-shard commits + all_gather of N
+    sub-roots, a two-peer exchange per fold; every root equals the single-GPU root of the same trace)."""
     import random
     from starkperp import stark
     if not 10 <= args.log_rows <= 24:
         raise SystemExit("--log-rows must be in 10..24")
-    m = 1 << (args.log_rows - 9)  # 512 trace rows per hash
-    log_lde = args.log_rows + 2
+    total_log_rows = args.log_rows + (world.bit_length() - 1)
+    if world > 1 and (world & (world - 1) or total_log_rows > 25):
+        raise SystemExit("the sharded job needs a power-of-two world and at most 2^25 rows in all")
+    m = 1 << (total_log_rows - 9)  # 512 trace rows per hash; N > 1: the WHOLE trace (every rank holds its inputs)
+    log_lde = total_log_rows + 2
     P = stark.FIELD_PRIME
-    xs, ys = seeded_felts(torch, m, 11 + 100 * rank, dev), seeded_felts(torch, m, 12 + 100 * rank, dev)
+    xs, ys = seeded_felts(torch, m, 11, dev), seeded_felts(torch, m, 12, dev)
     rng = random.Random(13)
     alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
     betas = [rng.randrange(P) for _ in range(log_lde - 6)]
     trace = stark.pedersen_trace(xs, ys)  # witness generation is input preparation
+    if world > 1:
+        return run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, trace, alphas, betas,
+                                  total_log_rows)
     per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
     n_roots = 2 + (log_lde - 7)  # trace, composition, every FRI layer above 64 points
     # Independent jobs alternate over the streams: the latency-bound tree tops of one job overlap
@@ -520,8 +527,6 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
         slots.append({
             "stream": torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream(device=dev),
             "roots": torch.zeros((n_roots, 4), dtype=torch.int64, device=dev),
-            "gathered": torch.zeros((max(world, 1) * n_roots, 4), dtype=torch.int64, device=dev),
-            "tops": torch.zeros((n_roots, 2 * max(world, 1) - 1, 4), dtype=torch.int64, device=dev),
         })
     job_counter = [0]
 
@@ -529,7 +534,7 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
         sl = slots[job_counter[0] % n_streams]
         job_counter[0] += 1
         with torch.cuda.stream(sl["stream"]):
-            roots_dev, gathered, tops = sl["roots"], sl["gathered"], sl["tops"]
+            roots_dev = sl["roots"]
             k = 0
             job_trace = stark.pedersen_trace(xs, ys) if args.with_witness else trace
             t_lde = stark.lde(job_trace)
@@ -543,14 +548,6 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
                 j += 1
                 if layer.shape[0] > 64:
                     roots_dev[k] = stark.commit_rows(layer.unsqueeze(0))[-1]; k += 1
-            if world > 1:
-                dist.all_gather_into_tensor(gathered, roots_dev)
-                g = gathered.reshape(world, n_roots, 4)
-                height = world.bit_length() - 1
-                for c in range(n_roots):
-                    tops[c, :world] = g[:, c]
-                    _lib.check(lib.sp_merkle_build_dev(tops[c].data_ptr(), height, None,
-                                                       sl["stream"].cuda_stream), "combine")
 
     def fence():
         torch.cuda.synchronize()
@@ -610,6 +607,92 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, trace, alphas, betas, total_log_rows):
+    from starkperp import sharded_prover
+    ops = sharded_prover.GpuOps(dev)
+    log_lde = total_log_rows + 2
+    n_roots = 2 + (log_lde - 7)
+    out = {}
+
+    def step():
+        out["roots"], out["final"] = sharded_prover.commit_job(ops, dist, trace, alphas, betas)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.check(lib.sp_profile_begin(args.steps * 40 * (n_roots + 4)), "profile_begin")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)), "profile_end")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist.get_backend() == "gloo":
+        t = t.cpu()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    same = None
+    if rank == 0 and total_log_rows <= 24:
+        # the whole trace once more on this GPU alone (outside the timed region): the sharded roots must be
+        # the single-GPU roots
+        n = trace.shape[1]
+        t_lde = stark.lde(trace)
+        ref = [stark.root_of(stark.commit_rows(t_lde))]
+        comp = stark.air_eval(t_lde, stark.periodic_lde(n, stark.FIELD_GEN, dev), n, alphas)
+        del t_lde
+        ref.append(stark.root_of(stark.commit_rows(comp.unsqueeze(0))))
+        layer, sh, k = comp, stark.FIELD_GEN, 0
+        while layer.shape[0] > 64:
+            layer = stark.fri_fold(layer, betas[k], sh)
+            sh = sh * sh % stark.FIELD_PRIME
+            k += 1
+            if layer.shape[0] > 64:
+                ref.append(stark.root_of(stark.commit_rows(layer.unsqueeze(0))))
+        same = bool(ref == out["roots"] and stark.tensor_to_felts(layer) == out["final"])
+    if rank == 0:
+        n_l = max(int(k_launches.value), 1)
+        avg_launch_s = (k_ms.value / 1e3) / n_l
+        rate = (k_units.value / n_l) / avg_launch_s if avg_launch_s > 0 else 0.0
+        lde_bytes = 4 * (4 << total_log_rows) * 32
+        print(json.dumps({
+            "metric": "air_fri_commits_per_sec", "value": world * args.steps / elapsed,
+            "unit": "2^%d-row commits/s (one step = ONE proof of %d x 2^%d rows)" % (args.log_rows, world, args.log_rows),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32x9 (29-bit limbs) mod p", "data": "synthetic",
+            "config": {"workload": "ONE 2^%d-row Pedersen-step trace sharded over %d GPUs (BASELINE.json configs[4] "
+                                   "shape; 2^24 rows = --log-rows 21 on 8 GPUs): 16 LDE units spread over the ranks, "
+                                   "all-to-all into LDE-row shards + halo, per-shard commits, sharded folds"
+                                   % (total_log_rows, world),
+                       "rows_total": 1 << total_log_rows, "rows_per_gpu": 1 << args.log_rows,
+                       "exchange": {"lde_all_to_all_bytes_total": lde_bytes,
+                                    "per_commit": "all_gather of %d x 32 B sub-roots + %d top hashes on every rank"
+                                                  % (world, world - 1),
+                                    "per_fold": "two-peer exchange, the layer crosses the links once",
+                                    "backend": dist.get_backend()}},
+            "sharded_roots_match_single_gpu": same,
+            "roofline": dict(
+                valu_issue(rate, int(lib.sp_window_bits()), "inside the ped_accumulate_kernel launches of the timed "
+                           "region on rank 0", include_finish=False)
+                or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None},
+                kernel="ped_accumulate_kernel (row chains and commit-tree levels above 65 536 hashes)",
+                peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value), avg_launch_us=avg_launch_s * 1e6,
+                traffic=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
+                hbm={"bound": "hbm", "achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}),
+            "cpu_baseline": None,
+        }))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def airfri_object(torch, lib, _lib, dev, with_cpu):

@@ -202,6 +202,13 @@ int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes,
  * 4 * 2^log_n felts; periodic_lde: 6 tables of 2048 felts; alphas_host: 11 felts. */
 int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
                     const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream);
+/* Row shard of the same column for one rank of a multi-GPU job (SURVEY 8(e) "AIR eval": LDE-row shards
+ * with a halo of one trace row): n_points LDE points from global index row0 (a multiple of 4); the four
+ * columns are col_stride felts apart and hold n_points + 4 rows, the last four received from the owner of
+ * the following rows.  log_n is the global trace length. */
+int sp_air_eval_shard_dev(const uint64_t* trace_lde, size_t col_stride, size_t n_points, size_t row0,
+                          const uint64_t* periodic_lde, unsigned log_n, const uint64_t* alphas_host,
+                          const uint64_t* shift_host, uint64_t* out, void* stream);
 /* EC-ladder AIR (one mimic_ec_mult_air instance = 256 rows, signature.py:176-190): witness columns
  * m, px, py, qx, qy, la, ld for n_ladders scalar multiplications m * (qx, qy) + SHIFT_POINT
  * (cols = 7 columns of 256 * n_ladders felts), and its composition column (12 constraints,
@@ -215,6 +222,11 @@ int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodi
  * g(x^2) = (f(x) + f(-x)) / 2 + beta (f(x) - f(-x)) / (2 x). */
 int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uint64_t* beta_host,
                     const uint64_t* shift_host, void* stream);
+/* Row shard of one fold: out[i] = fold(fa[i], fb[i]) for the global positions i0 .. i0 + count of a layer of
+ * 2^log_m points; fa = f[i0 ..], fb = f[i0 + 2^(log_m - 1) ..] (the second array comes from the rank that
+ * owns the upper half of the layer). */
+int sp_fri_fold_shard_dev(const uint64_t* fa, const uint64_t* fb, uint64_t* out, unsigned log_m, size_t i0,
+                          size_t count, const uint64_t* beta_host, const uint64_t* shift_host, void* stream);
 /* Commit (build-defined): Pedersen-Merkle tree over the rows of a column-major table of
  * n_rows (a power of two) x n_cols felts; leaf = left-fold chain of the row's felts (one column: the
  * felt itself).  levels receives 2 n_rows - 1 felts, leaves first, root last.  Passing a status

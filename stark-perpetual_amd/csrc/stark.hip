@@ -461,14 +461,18 @@ struct AirParams {
 // at i and i + blowup (the next trace row) and six periodic tables at i mod 2048 - all PLAIN felts.
 // Only b and lambda (the two variables that multiply other variables) are converted to Montgomery
 // form: 2 conversions instead of the 13 + 1 of round 1 (see the file comment).
+// Row shards (multi-GPU): the kernel evaluates `M` points whose global index starts at row0;
+// the columns are `col_stride` felts apart and, when wrap == 0, carry a halo of one trace row (4 LDE
+// rows) after the M points (received from the rank that owns the next rows).
 __global__ void __launch_bounds__(256)
-air_eval_kernel(const uint64_t* __restrict__ trace /* [4][M] plain */, const uint64_t* __restrict__ per /* [6][2048] plain */,
-                size_t M, AirParams prm, uint64_t* __restrict__ out /* [M] plain */) {
+air_eval_kernel(const uint64_t* __restrict__ trace /* [4][col_stride] plain */, const uint64_t* __restrict__ per /* [6][2048] plain */,
+                size_t M, size_t col_stride, size_t row0, int wrap, AirParams prm, uint64_t* __restrict__ out /* [M] plain */) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
-  const size_t in = (i + 4) & (M - 1);
-  auto col = [&](int c, size_t r) { return ld_fe_packed(trace + 4 * ((size_t)c * M + r)); };
-  auto pcol = [&](int c) { return ld_fe_packed(per + 4 * ((size_t)c * 2048 + (i & 2047))); };
+  const size_t in = wrap ? ((i + 4) & (M - 1)) : i + 4;
+  const size_t gi = row0 + i;  // global LDE index: periodic tables and 1 / Z_H repeat with it
+  auto col = [&](int c, size_t r) { return ld_fe_packed(trace + 4 * ((size_t)c * col_stride + r)); };
+  auto pcol = [&](int c) { return ld_fe_packed(per + 4 * ((size_t)c * 2048 + (gi & 2047))); };
   const fe s = col(0, i), px = col(1, i), py = col(2, i), lam = col(3, i);
   const fe s_n = col(0, in), px_n = col(1, in), py_n = col(2, in);
   const fe cx = pcol(0), cy = pcol(1), step = pcol(2), mid = pcol(3), end = pcol(4), z252 = pcol(5);
@@ -493,21 +497,22 @@ air_eval_kernel(const uint64_t* __restrict__ trace /* [4][M] plain */, const uin
                                  fe_carry(fe_sub(py_n, prm.shift_y)));
   fe acc = fe_mul3_add(step, acc_step, mid, mids, end, ends);
   acc = fe_weak_reduce(fe_add(acc, fe_mul(prm.alpha[10], fe_mul(z252, s))));
-  st_u256(out + 4 * i, fe_pack(fe_canon(fe_mul(acc, prm.zinv[i & 3]))));
+  st_u256(out + 4 * i, fe_pack(fe_canon(fe_mul(acc, prm.zinv[gi & 3]))));
 }
 
 // FRI fold: g[i] = (f[i] + f[i+M/2]) / 2 + beta (f[i] - f[i+M/2]) / (2 x_i),  x_i = shift w_M^i.
 // tw_inv holds w^{-i} (table for size 2^log_tw); c1 = 1/2, c2 = beta / (2 shift); table and constants
 // in Montgomery form, the layer values plain: two multiplications and one halving per output.
+// Row shards: `fa` / `fb` hold f at global indices i0 .. i0 + count and i0 + M/2 .. (the second array comes
+// from the rank that owns the upper half of the layer); a whole layer is fa = f, fb = f + M/2, i0 = 0.
 __global__ void __launch_bounds__(256)
-fri_fold_kernel(const uint64_t* __restrict__ f, uint64_t* __restrict__ g, int log_m,
-                const uint64_t* __restrict__ tw_inv, int log_tw, fe c1, fe c2) {
-  const size_t half = (size_t)1 << (log_m - 1);
+fri_fold_kernel(const uint64_t* __restrict__ fa, const uint64_t* __restrict__ fb, uint64_t* __restrict__ g,
+                int log_m, size_t i0, size_t count, const uint64_t* __restrict__ tw_inv, int log_tw, fe c1, fe c2) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= half) return;
-  const fe a = ld_fe_packed(f + 4 * i);
-  const fe b = ld_fe_packed(f + 4 * (i + half));
-  const fe winv = ld_fe_packed(tw_inv + 4 * (i << (log_tw - log_m)));
+  if (i >= count) return;
+  const fe a = ld_fe_packed(fa + 4 * i);
+  const fe b = ld_fe_packed(fb + 4 * i);
+  const fe winv = ld_fe_packed(tw_inv + 4 * ((i0 + i) << (log_tw - log_m)));
   const fe odd = fe_mul(fe_mul(fe_sub(a, b), winv), c2);
   const fe even = fe_half(fe_add(a, b));  // c1 = 1/2: a shift instead of a multiplication
   (void)c1;
@@ -779,11 +784,9 @@ int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes,
   return SP_OK;
 }
 
-int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
-                    const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream) {
-  SP_REQUIRE_READY();
-  ctx_lock lk(ctx().mu);
-  const size_t n = (size_t)1 << log_n, M = 4 * n;
+static int air_eval_launch(const uint64_t* trace_lde, size_t col_stride, size_t n_points, size_t row0, int wrap,
+                           const uint64_t* periodic_lde, unsigned log_n, const uint64_t* alphas_host,
+                           const uint64_t* shift_host, uint64_t* out, void* stream) {
   AirParams prm;
   for (int k = 0; k < 11; ++k) {
     u256 a;
@@ -804,10 +807,34 @@ int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, uns
   }
   prm.shift_x = fe_unpack(PT_SHIFT_X);
   prm.shift_y = fe_unpack(PT_SHIFT_Y);
-  hipLaunchKernelGGL(air_eval_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     trace_lde, periodic_lde, M, prm, out);
+  hipLaunchKernelGGL(air_eval_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     trace_lde, periodic_lde, n_points, col_stride, row0, wrap, prm, out);
   SP_HIP(hipGetLastError());
   return SP_OK;
+}
+
+int sp_air_eval_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
+                    const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  const size_t M = (size_t)4 << log_n;
+  return air_eval_launch(trace_lde, M, M, 0, 1, periodic_lde, log_n, alphas_host, shift_host, out, stream);
+}
+
+// Row shard of the composition column (multi-GPU): n_points LDE points starting at global index row0 (a
+// multiple of 4); the four trace columns are col_stride felts apart and hold n_points + 4 rows (the last
+// four = the halo received from the owner of the next rows).  log_n is the GLOBAL trace length.
+int sp_air_eval_shard_dev(const uint64_t* trace_lde, size_t col_stride, size_t n_points, size_t row0,
+                          const uint64_t* periodic_lde, unsigned log_n, const uint64_t* alphas_host,
+                          const uint64_t* shift_host, uint64_t* out, void* stream) {
+  SP_REQUIRE_READY();
+  if ((row0 & 3) != 0 || col_stride < n_points + 4 || row0 + n_points > ((size_t)4 << log_n)) {
+    set_error("bad composition shard");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  ctx_lock lk(ctx().mu);
+  return air_eval_launch(trace_lde, col_stride, n_points, row0, 0, periodic_lde, log_n, alphas_host, shift_host, out,
+                         stream);
 }
 
 int sp_ec_ladder_trace_dev(const uint64_t* m, const uint64_t* qx, const uint64_t* qy, size_t n_ladders,
@@ -855,11 +882,8 @@ int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodi
   return SP_OK;
 }
 
-int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uint64_t* beta_host,
-                    const uint64_t* shift_host, void* stream) {
-  SP_REQUIRE_READY();
-  if (log_m < 1 || log_m > 26) { set_error("bad layer size"); return SP_ERR_BAD_ARGUMENT; }
-  ctx_lock lk(ctx().mu);
+static int fri_fold_launch(const uint64_t* fa, const uint64_t* fb, uint64_t* out, unsigned log_m, size_t i0,
+                           size_t count, const uint64_t* beta_host, const uint64_t* shift_host, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const uint64_t* tw;
   int rc = get_twiddles((int)log_m, 1, &tw, st);
@@ -870,11 +894,30 @@ int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uin
   const fe two = fe_to_mont(fe{{2, 0, 0, 0, 0, 0, 0, 0, 0}});
   const fe c1 = fe_inv(two);
   const fe c2 = fe_mul(fe_to_mont(fe_unpack(b)), fe_inv(fe_mul(two, fe_to_mont(fe_unpack(s)))));
-  const size_t half = (size_t)1 << (log_m - 1);
-  hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, in, out,
-                     (int)log_m, tw, (int)log_m, c1, c2);
+  if (count == 0) return SP_OK;
+  hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, fa, fb, out,
+                     (int)log_m, i0, count, tw, (int)log_m, c1, c2);
   SP_HIP(hipGetLastError());
   return SP_OK;
+}
+
+int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uint64_t* beta_host,
+                    const uint64_t* shift_host, void* stream) {
+  SP_REQUIRE_READY();
+  if (log_m < 1 || log_m > 26) { set_error("bad layer size"); return SP_ERR_BAD_ARGUMENT; }
+  ctx_lock lk(ctx().mu);
+  const size_t half = (size_t)1 << (log_m - 1);
+  return fri_fold_launch(in, in + 4 * half, out, log_m, 0, half, beta_host, shift_host, stream);
+}
+
+// Row shard of one fold (multi-GPU): out[i] = fold(fa[i], fb[i]) for the global positions i0 .. i0 + count of a
+// layer of 2^log_m points; fa holds f[i0 ..], fb holds f[i0 + 2^(log_m - 1) ..].
+int sp_fri_fold_shard_dev(const uint64_t* fa, const uint64_t* fb, uint64_t* out, unsigned log_m, size_t i0,
+                          size_t count, const uint64_t* beta_host, const uint64_t* shift_host, void* stream) {
+  SP_REQUIRE_READY();
+  if (log_m < 1 || log_m > 30 || i0 + count > ((size_t)1 << (log_m - 1))) { set_error("bad fold shard"); return SP_ERR_BAD_ARGUMENT; }
+  ctx_lock lk(ctx().mu);
+  return fri_fold_launch(fa, fb, out, log_m, i0, count, beta_host, shift_host, stream);
 }
 
 }  // extern "C"

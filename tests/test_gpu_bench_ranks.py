@@ -37,3 +37,5 @@ def test_two_ranks_share_one_gpu(workload, extra):
     if workload == "merkle":
         assert d["config"]["hashes_per_step"] == 2 * 65535 + 1
         assert d["combine_matches_recomputed"] is True
+    else:  # ONE 2^15-row proof over the two ranks: its roots are the single-GPU roots of the same trace
+        assert d["config"]["rows_total"] == 1 << 15 and d["sharded_roots_match_single_gpu"] is True

@@ -304,3 +304,25 @@ def test_ec_ladder_air_matches_oracle_and_proves(stark):
     assert ok, why
     proof["queries"][0]["trace"][1]["values"][6] ^= 1
     assert not S.verify_proof(proof)[0]
+
+
+def test_sharded_prover_on_one_rank_equals_the_plain_job(stark):
+    """starkperp.sharded_prover with the library's kernels (GpuOps) and no process group: LDE as 16 coset
+    units, row-shard assembly with the halo, sp_air_eval_shard_dev, sp_fri_fold_shard_dev - the roots and the
+    final layer must be those of stark.prove_commitments on the same trace (2^14 rows)."""
+    import torch
+    from starkperp import sharded_prover
+    m = 32
+    g = torch.Generator().manual_seed(29)
+    xs = torch.randint(0, 2**62, (m, 4), dtype=torch.int64, generator=g)
+    ys = torch.randint(0, 2**62, (m, 4), dtype=torch.int64, generator=g)
+    xs[:, 3] &= (1 << 58) - 1
+    ys[:, 3] &= (1 << 58) - 1
+    xs, ys = xs.cuda(), ys.cuda()
+    rng = random.Random(30)
+    alphas = [rng.randrange(P) for _ in range(S.N_CONSTRAINTS)]
+    betas = [rng.randrange(P) for _ in range(10)]
+    want_roots, want_final = stark.prove_commitments(xs, ys, alphas, betas)
+    roots, final = sharded_prover.commit_job(sharded_prover.GpuOps("cuda"), None, stark.pedersen_trace(xs, ys),
+                                             alphas, betas)
+    assert roots == want_roots and final == want_final
