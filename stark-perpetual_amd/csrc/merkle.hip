@@ -162,87 +162,250 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
 // tree (height 64) once per batch: old root and new root along the union of the touched paths, the
 // untouched siblings coming from the previous state (the `merkle_facts` store of main.cairo:61-64).
 // sp_merkle_sparse_root only covers the first batch (everything else empty).  A tree handle keeps
-// the state: per level a host map  node index -> value  for every node that differs from the
-// empty-subtree root of its level.  An update is ONE call: the host walks the induced subtree
-// (merkle_tree.py:18-26), looks the untouched siblings up, ships leaves + siblings + child-index
-// lists to the device, every level is one gathered launch (csrc/pedersen.hip), and the new node
-// values come back in one copy to refresh the store.
-struct FeltKey {
-  uint64_t w[4];
+// the state IN HBM: an open-addressing hash table (level, index) -> felt of every node that differs
+// from the empty-subtree root of its level.  An update ships the sorted keys and the new leaves
+// (40 B per leaf) and runs entirely on the device:
+//   per level   tree_level_kernel: from the level's sorted node indices builds the parents' indices
+//               (merkle_tree.py:18-26: parents = set(index // 2)), the child-index list of every parent
+//               and looks the untouched siblings up in the table;
+//               the gathered Pedersen launch of csrc/pedersen.hip hashes the level;
+//   at the end  one insert kernel writes the new leaves and every new node into the table - only if no
+//               input was out of range / unhashable, so a failed update leaves the tree as it was.
+// The host only counts the nodes per level (a function of the keys alone) to size the launches, and
+// keeps a copy of the current root.  Round 1 kept the node store in host maps: 12 ms per 4096-leaf update
+// of a height-64 tree, most of it map lookups / insertions and the 8 MB of values crossing PCIe.
+struct TreeSlot {       // 48 bytes
+  uint64_t index;
+  uint32_t level1;      // level + 1; 0 = never used
+  uint32_t state;       // 0 empty, 1 being written, 2 ready
+  uint64_t value[4];
 };
-// index -> felt, open addressing with linear probing (no allocation per node: an update inserts
-// ~ n * height nodes, and std::unordered_map's per-node malloc dominated the call)
-class NodeMap {
- public:
-  const FeltKey* find(uint64_t key) const {
-    if (slots_.empty()) return nullptr;
-    for (size_t i = mix(key) & mask_;; i = (i + 1) & mask_) {
-      const Slot& sl = slots_[i];
-      if (!sl.used) return nullptr;
-      if (sl.key == key) return &sl.value;
+__device__ __forceinline__ uint64_t tree_mix(uint64_t index, uint32_t level) {
+  uint64_t z = index + 0x9E3779B97F4A7C15ull * (uint64_t)(level + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// value of node (level, index) or nullptr when the node is still the empty-subtree root of its level
+__device__ __forceinline__ const uint64_t* tree_find(const TreeSlot* __restrict__ tab, uint64_t mask, uint32_t level,
+                                                     uint64_t index) {
+  for (uint64_t i = tree_mix(index, level) & mask;; i = (i + 1) & mask) {
+    const TreeSlot& sl = tab[i];
+    // lookups never run beside insertions (different launches of one stream): plain loads
+    const uint32_t st = sl.state;
+    if (st == 0) return nullptr;
+    if (st == 2 && sl.level1 == level + 1 && sl.index == index) return sl.value;
+  }
+}
+// Inserts or overwrites; the keys of one launch are distinct, so two lanes never claim the same key.
+__device__ __forceinline__ bool tree_put(TreeSlot* __restrict__ tab, uint64_t mask, uint32_t level, uint64_t index,
+                                         const uint64_t* value) {
+  for (uint64_t i = tree_mix(index, level) & mask;; i = (i + 1) & mask) {
+    TreeSlot& sl = tab[i];
+    // relaxed: a slot another lane is filling right now belongs to a different key (the keys of a launch
+    // are distinct), so whatever is read from it cannot match
+    uint32_t st = __hip_atomic_load(&sl.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st == 0) {
+      uint32_t expected = 0;
+      if (__hip_atomic_compare_exchange_strong(&sl.state, &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)) {
+        sl.index = index;
+        sl.level1 = level + 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sl.value[q] = value[q];
+        __hip_atomic_store(&sl.state, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // readers: later launches
+        return true;  // a slot that was empty: the table's entry count grows
+      }
+      st = expected;  // somebody else claimed it: a different key (keys are distinct), keep probing
+    }
+    if (st == 2 && sl.level1 == level + 1 && sl.index == index) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sl.value[q] = value[q];
+      return false;
     }
   }
-  void put(uint64_t key, const FeltKey& value) {
-    if ((count_ + 1) * 2 > slots_.size()) grow();
-    for (size_t i = mix(key) & mask_;; i = (i + 1) & mask_) {
-      Slot& sl = slots_[i];
-      if (!sl.used) { sl.used = true; sl.key = key; sl.value = value; ++count_; return; }
-      if (sl.key == key) { sl.value = value; return; }
-    }
-  }
-  size_t size() const { return count_; }
+}
 
- private:
-  struct Slot {
-    uint64_t key = 0;
-    FeltKey value{};
-    bool used = false;
-  };
-  static size_t mix(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (size_t)(z ^ (z >> 31));
-  }
-  void grow() {
-    std::vector<Slot> old;
-    old.swap(slots_);
-    slots_.assign(old.empty() ? 64 : old.size() * 2, Slot{});
-    mask_ = slots_.size() - 1;
-    count_ = 0;
-    for (const Slot& sl : old)
-      if (sl.used) put(sl.key, sl.value);
-  }
-  std::vector<Slot> slots_;
-  size_t mask_ = 0, count_ = 0;
+// Layout of one update in the work buffer (host-computed from the level counts, uploaded once).
+struct TreeLevels {
+  unsigned height;
+  unsigned cnt[66];       // nodes per level (level 0 = the new leaves)
+  int val_base[66];       // felts: where the values of level l start
+  int sib_base[66];       // felts: where the siblings of level l + 1's parents go (one slot per parent)
+  unsigned idx_off[66];   // idx: where the node indices of level l start
+  unsigned src_off[66];   // src: where the child lists of level l + 1 start
 };
+
+// ONE workgroup builds the structure of the whole update before any hash runs (it depends on the keys
+// and on the table only): for every level, from the sorted node indices, the parents' indices
+// (merkle_tree.py:18-26), every parent's child list (absolute positions in `felts`, -1 = the level's
+// empty-subtree root) and a copy of every untouched sibling found in the table at felts[sib_base + q].
+// Parent positions come from a ballot scan (two barriers per 1024 nodes).
+constexpr int TREE_PENDING = INT_MIN;
+__global__ void __launch_bounds__(1024)
+tree_structure_kernel(TreeLevels lv, uint64_t* __restrict__ idx_all, int2* __restrict__ src_all) {
+  __shared__ unsigned wave_tot[16];
+  __shared__ unsigned carry;
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (unsigned level = 0; level < lv.height; ++level) {
+    const uint64_t* idx = idx_all + lv.idx_off[level];
+    uint64_t* parent_idx = idx_all + lv.idx_off[level + 1];
+    int2* src = src_all + lv.src_off[level];
+    const unsigned cnt = lv.cnt[level];
+    const int val_base = lv.val_base[level];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (unsigned tile = 0; tile < cnt; tile += 1024) {
+      const unsigned j = tile + threadIdx.x;
+      const bool live = j < cnt;
+      const uint64_t me = live ? idx[j] : 0;
+      // a node opens a new parent unless its left neighbour in the array is its left sibling
+      const bool head = live && !((me & 1) && j > 0 && idx[j - 1] == me - 1);
+      const unsigned long long ballot = __ballot(head);
+      const unsigned before = __popcll(ballot & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_tot[wave] = __popcll(ballot);
+      __syncthreads();
+      unsigned off = carry;
+      for (unsigned w = 0; w < wave; ++w) off += wave_tot[w];
+      if (head) {
+        const unsigned q = off + before;
+        parent_idx[q] = me >> 1;
+        int2 s2;  // TREE_PENDING: the sibling comes from the table (tree_lookup_kernel fills it in)
+        if ((me & 1) == 0) {
+          s2.x = val_base + (int)j;
+          s2.y = (j + 1 < cnt && idx[j + 1] == me + 1) ? val_base + (int)j + 1 : TREE_PENDING;
+        } else {
+          s2.y = val_base + (int)j;
+          s2.x = TREE_PENDING;
+        }
+        src[q] = s2;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned tot = carry;
+        for (unsigned w = 0; w < 16; ++w) tot += wave_tot[w];
+        carry = tot;
+      }
+      __syncthreads();
+    }
+    __threadfence_block();  // parent_idx written by this block is read by it in the next level
+    __syncthreads();
+  }
+}
+
+// Every parent whose child list has a pending side: the untouched sibling from the table (copied to
+// felts[sib_base + q]) or -1 = the level's empty-subtree root.  One thread per parent of the update.
+__global__ void __launch_bounds__(256)
+tree_lookup_kernel(TreeLevels lv, const uint64_t* __restrict__ idx_all, const TreeSlot* __restrict__ tab, uint64_t mask,
+                   uint64_t* __restrict__ felts, int2* __restrict__ src_all, unsigned n_parents) {
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_parents) return;
+  unsigned level = 0;  // children's level: src_off is the running parent count
+  while (level + 1 < lv.height && g >= lv.src_off[level + 1]) ++level;
+  const unsigned q = g - lv.src_off[level];
+  int2 s2 = src_all[g];
+  if (s2.x != TREE_PENDING && s2.y != TREE_PENDING) return;
+  const uint64_t parent = idx_all[lv.idx_off[level + 1] + q];
+  const bool left = s2.x == TREE_PENDING;
+  const uint64_t* sib = tree_find(tab, mask, level, 2 * parent + (left ? 0 : 1));
+  const int pos = sib ? lv.sib_base[level] + (int)q : -1;
+  if (sib) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) felts[4 * (size_t)pos + w] = sib[w];
+  }
+  if (left) s2.x = pos; else s2.y = pos;
+  src_all[g] = s2;
+}
+
+// table[(level, idx)] = value for every node of the update, all levels in one launch
+__global__ void __launch_bounds__(256)
+tree_insert_kernel(TreeSlot* __restrict__ tab, uint64_t mask, TreeLevels lv, const uint64_t* __restrict__ idx_all,
+                   const uint64_t* __restrict__ felts, unsigned total, unsigned long long* __restrict__ fresh) {
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+  bool claimed = false;
+  if (g < total) {
+    unsigned level = 0;
+    while (level < lv.height && g >= lv.idx_off[level + 1]) ++level;  // idx_off is the running node count
+    const unsigned j = g - lv.idx_off[level];
+    claimed = tree_put(tab, mask, level, idx_all[g], felts + 4 * (size_t)(lv.val_base[level] + (int)j));
+  }
+  const unsigned long long b = __ballot(claimed);  // one atomic per wave for the entry counter
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(fresh, (unsigned long long)__popcll(b));
+}
+// out[j] = leaf (level 0) keys[j] or the empty leaf
+__global__ void __launch_bounds__(256)
+tree_get_kernel(const TreeSlot* __restrict__ tab, uint64_t mask, const uint64_t* __restrict__ keys, unsigned cnt,
+                const uint64_t* __restrict__ empty_leaf, uint64_t* __restrict__ out) {
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cnt) return;
+  const uint64_t* v = tree_find(tab, mask, 0, keys[j]);
+  if (!v) v = empty_leaf;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) out[4 * (size_t)j + w] = v[w];
+}
+// rehash every ready slot of `old` into `tab`
+__global__ void __launch_bounds__(256)
+tree_rehash_kernel(const TreeSlot* __restrict__ old, uint64_t old_slots, TreeSlot* __restrict__ tab, uint64_t mask) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= old_slots) return;
+  const TreeSlot& sl = old[i];
+  if (sl.state == 2) (void)tree_put(tab, mask, sl.level1 - 1, sl.index, sl.value);
+}
+
 struct SparseTree {
   unsigned height = 0;
   uint64_t empty_leaf[4] = {0, 0, 0, 0};
-  std::vector<NodeMap> nodes;  // [level][index], level 0 = leaves
+  TreeSlot* table = nullptr;   // HBM
+  uint64_t slots = 0;          // power of two
+  uint64_t entries = 0;        // used slots as of the last read of d_entries
+  unsigned long long* d_entries = nullptr;  // device counter of claimed slots (insert kernels add to it)
+  bool has_root = false;
+  uint64_t root[4] = {0, 0, 0, 0};
 };
-// Runs fn(level) for level = 0..count-1 on a few host threads (levels touch disjoint node maps).
-template <typename F>
-static void for_levels_parallel(unsigned count, F fn) {
-  const unsigned workers = count < 8 ? count : 8;
-  if (workers <= 1) {
-    for (unsigned l = 0; l < count; ++l) fn(l);
-    return;
-  }
-  std::vector<std::thread> pool;
-  pool.reserve(workers);
-  for (unsigned w = 0; w < workers; ++w)
-    pool.emplace_back([=]() {
-      for (unsigned l = w; l < count; l += workers) fn(l);
-    });
-  for (auto& th : pool) th.join();
-}
 
 static std::map<int, SparseTree> g_trees;
 static int g_next_tree = 1;
 static DeviceBuffer g_tree_buf;
 
+static void tree_free(SparseTree& t) {
+  if (t.table) (void)hipFree(t.table);
+  if (t.d_entries) (void)hipFree(t.d_entries);
+  t.table = nullptr;
+  t.d_entries = nullptr;
+  t.slots = 0;
+}
+// room for `extra` more entries at a load factor of at most 1/2
+static int tree_reserve(SparseTree& t, uint64_t extra) {
+  if (!t.d_entries) {
+    SP_HIP(hipMalloc(&t.d_entries, sizeof(unsigned long long)));
+    SP_HIP(hipMemset(t.d_entries, 0, sizeof(unsigned long long)));
+  }
+  if (t.slots && 2 * (t.entries + extra) > t.slots) {  // would not fit by the last known count: refresh it
+    unsigned long long used = 0;
+    SP_HIP(hipMemcpy(&used, t.d_entries, sizeof(used), hipMemcpyDeviceToHost));
+    t.entries = used;
+  }
+  uint64_t want = t.slots ? t.slots : ((uint64_t)1 << 16);
+  while (2 * (t.entries + extra) > want) want <<= 1;
+  if (want == t.slots) return SP_OK;
+  TreeSlot* fresh = nullptr;
+  SP_HIP(hipMalloc(&fresh, want * sizeof(TreeSlot)));
+  SP_HIP(hipMemsetAsync(fresh, 0, want * sizeof(TreeSlot), 0));
+  if (t.table) {
+    hipLaunchKernelGGL(tree_rehash_kernel, dim3((unsigned)((t.slots + 255) / 256)), dim3(256), 0, 0, t.table, t.slots,
+                       fresh, want - 1);
+    SP_HIP(hipGetLastError());
+    SP_HIP(hipDeviceSynchronize());
+    (void)hipFree(t.table);
+  }
+  t.table = fresh;
+  t.slots = want;
+  return SP_OK;
+}
+
 namespace sp {
 void release_tree_state() {
+  for (auto& kv : g_trees) tree_free(kv.second);
   g_trees.clear();
   g_tree_buf.release();
 }
@@ -260,9 +423,8 @@ int sp_tree_create(unsigned height, const uint64_t* empty_leaf, int* tree) {
   SparseTree t;
   t.height = height;
   std::memcpy(t.empty_leaf, empty_leaf, 32);
-  t.nodes.resize(height + 1);
   const int id = g_next_tree++;
-  g_trees.emplace(id, std::move(t));
+  g_trees.emplace(id, t);
   *tree = id;
   return SP_OK;
 }
@@ -270,7 +432,11 @@ int sp_tree_create(unsigned height, const uint64_t* empty_leaf, int* tree) {
 int sp_tree_destroy(int tree) {
   SP_REQUIRE_READY();
   ctx_lock lk(ctx().mu);
-  if (g_trees.erase(tree) == 0) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
+  auto it = g_trees.find(tree);
+  if (it == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
+  SP_HIP(hipDeviceSynchronize());
+  tree_free(it->second);
+  g_trees.erase(it);
   return SP_OK;
 }
 
@@ -280,8 +446,8 @@ int sp_tree_root(int tree, uint64_t* root) {
   auto it = g_trees.find(tree);
   if (it == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
   SparseTree& t = it->second;
-  if (const FeltKey* top = t.nodes[t.height].find(0)) {
-    std::memcpy(root, top->w, 32);
+  if (t.has_root) {
+    std::memcpy(root, t.root, 32);
     return SP_OK;
   }
   Scratch s;
@@ -302,9 +468,23 @@ int sp_tree_get(int tree, const uint64_t* keys, size_t n, uint64_t* leaves) {
   const SparseTree& t = it->second;
   for (size_t i = 0; i < n; ++i) {
     if (t.height < 64 && (keys[i] >> t.height) != 0) { set_error("key out of range for height"); return SP_ERR_BAD_ARGUMENT; }
-    const FeltKey* leaf = t.nodes[0].find(keys[i]);
-    std::memcpy(leaves + 4 * i, leaf ? leaf->w : t.empty_leaf, 32);
   }
+  if (n == 0) return SP_OK;
+  if (!t.table) {
+    for (size_t i = 0; i < n; ++i) std::memcpy(leaves + 4 * i, t.empty_leaf, 32);
+    return SP_OK;
+  }
+  if (n > 0xffffffffull) { set_error("too many keys"); return SP_ERR_BAD_ARGUMENT; }
+  SP_HIP(g_tree_buf.reserve(n * 40 + 64));
+  uint64_t* d_keys = (uint64_t*)g_tree_buf.ptr;
+  uint64_t* d_emp = d_keys + n;
+  uint64_t* d_out = d_emp + 4;
+  SP_HIP(hipMemcpy(d_keys, keys, n * 8, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpy(d_emp, t.empty_leaf, 32, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(tree_get_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, t.table, t.slots - 1, d_keys,
+                     (unsigned)n, d_emp, d_out);
+  SP_HIP(hipGetLastError());
+  SP_HIP(hipMemcpy(leaves, d_out, n * 32, hipMemcpyDeviceToHost));
   return SP_OK;
 }
 
@@ -328,90 +508,52 @@ int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_
     std::memcpy(new_root, old_root, 32);
     return SP_OK;
   }
-  // ---- host: induced subtree, siblings from the store ----
-  // device felt buffer layout: [siblings][level 0 = new leaves][level 1][level 2]...; child indices
-  // are absolute positions in that buffer, -1 = the level's empty-subtree root
-  std::vector<uint64_t> sib;       // sibling values, 4 words each
-  std::vector<int2> src;           // all levels
-  std::vector<size_t> level_off, level_cnt;
-  std::vector<std::vector<uint64_t>> level_idx(1, std::vector<uint64_t>(keys, keys + n));
-  struct Pending { unsigned level; uint64_t child; bool left; size_t src_pos; };
-  std::vector<Pending> want;       // sibling slots to patch once the sibling count is known
-  for (unsigned l = 0; l < height; ++l) {
-    const std::vector<uint64_t>& idx = level_idx[l];
-    std::vector<uint64_t> nxt;
-    nxt.reserve(idx.size());
-    level_off.push_back(src.size());
-    const size_t m = idx.size();
-    for (size_t j = 0; j < m;) {
-      int2 s2;
-      const uint64_t parent = idx[j] >> 1;
-      if ((idx[j] & 1) == 0) {
-        s2.x = (int)j;  // relative to this level's array for now
-        if (j + 1 < m && idx[j + 1] == idx[j] + 1) { s2.y = (int)(j + 1); j += 2; }
-        else { s2.y = INT_MIN; want.push_back({l, idx[j] + 1, false, src.size()}); j += 1; }
-      } else {
-        s2.x = INT_MIN; s2.y = (int)j; want.push_back({l, idx[j] - 1, true, src.size()}); j += 1;
-      }
-      nxt.push_back(parent);
-      src.push_back(s2);
-    }
-    level_cnt.push_back(nxt.size());
-    level_idx.push_back(std::move(nxt));
-  }
-  // resolve siblings: stored value -> position in the sibling region, absent -> empty (-1).
-  // `want` is grouped by level (it was filled level by level): the lookups of different levels go to
-  // different node maps and run on a few host threads; placing the hits is serial and cheap.
-  std::vector<const FeltKey*> hit(want.size(), nullptr);
+  // ---- host: only the node COUNT of every level (merkle_tree.py:18-26 on the keys alone) ----
+  std::vector<size_t> cnt(height + 1);
+  cnt[0] = n;
   {
-    std::vector<size_t> first(height + 1, want.size());
-    for (size_t k = want.size(); k-- > 0;) first[want[k].level] = k;
-    for (unsigned l = height; l-- > 0;)
-      if (first[l] == want.size()) first[l] = first[l + 1];
-    const SparseTree* tree_c = &t;
-    for_levels_parallel(height, [&, tree_c](unsigned l) {
-      const NodeMap& lvl = tree_c->nodes[l];
-      for (size_t k = first[l]; k < first[l + 1]; ++k) hit[k] = lvl.find(want[k].child);
-    });
-  }
-  std::vector<int> sib_pos(want.size(), -1);
-  for (size_t k = 0; k < want.size(); ++k) {
-    if (hit[k]) {
-      sib_pos[k] = (int)(sib.size() / 4);
-      sib.insert(sib.end(), hit[k]->w, hit[k]->w + 4);
-    }
-  }
-  const size_t n_sib = sib.size() / 4;
-  size_t total_nodes = n;
-  for (size_t l = 0; l < level_cnt.size(); ++l) total_nodes += level_cnt[l];
-  if (n_sib + total_nodes >= (size_t)INT_MAX) { set_error("update too large"); return SP_ERR_BAD_ARGUMENT; }
-  // absolute positions: level l array starts at base[l]
-  std::vector<size_t> base(height + 1);
-  base[0] = n_sib;
-  for (unsigned l = 0; l < height; ++l) base[l + 1] = base[l] + (l == 0 ? n : level_cnt[l - 1]);
-  {
-    size_t k = 0;
+    std::vector<uint64_t> cur(keys, keys + n), nxt;
     for (unsigned l = 0; l < height; ++l) {
-      for (size_t q = level_off[l]; q < level_off[l] + level_cnt[l]; ++q) {
-        int2& s2 = src[q];
-        if (s2.x != INT_MIN) s2.x += (int)base[l];
-        if (s2.y != INT_MIN) s2.y += (int)base[l];
+      nxt.clear();
+      for (uint64_t v : cur) {
+        const uint64_t par = v >> 1;
+        if (nxt.empty() || nxt.back() != par) nxt.push_back(par);
       }
-    }
-    for (k = 0; k < want.size(); ++k) {
-      int2& s2 = src[want[k].src_pos];
-      (want[k].left ? s2.x : s2.y) = sib_pos[k];  // -1 = empty, else index into the sibling region
+      cnt[l + 1] = nxt.size();
+      cur.swap(nxt);
     }
   }
-  // ---- device ----
+  size_t total = 0;
+  for (unsigned l = 0; l <= height; ++l) total += cnt[l];
+  // felts: [level 0 values][siblings for level 1's parents][level 1 values][siblings ...] ...
+  TreeLevels lv;
+  std::memset(&lv, 0, sizeof(lv));
+  lv.height = height;
+  size_t felts = 0, idxs = 0, srcs = 0;
+  for (unsigned l = 0; l <= height; ++l) {
+    lv.cnt[l] = (unsigned)cnt[l];
+    lv.val_base[l] = (int)felts;
+    felts += cnt[l];
+    lv.idx_off[l] = (unsigned)idxs;
+    idxs += cnt[l];
+    if (l < height) {
+      lv.sib_base[l] = (int)felts;
+      felts += cnt[l + 1];
+      lv.src_off[l] = (unsigned)srcs;
+      srcs += cnt[l + 1];
+    }
+  }
+  if (felts >= (size_t)INT_MAX || total > 0x7fffffffull) { set_error("update too large"); return SP_ERR_BAD_ARGUMENT; }
+  rc = tree_reserve(t, total);
+  if (rc != SP_OK) return rc;
   const size_t emp_bytes = ((size_t)height + 1) * 32;
-  const size_t felt_bytes = (n_sib + total_nodes) * 32;
-  const size_t src_bytes = src.size() * sizeof(int2);
-  SP_HIP(g_tree_buf.reserve(emp_bytes + felt_bytes + src_bytes + 1024));
+  const size_t felt_bytes = felts * 32, idx_bytes = idxs * 8, src_bytes = srcs * sizeof(int2);
+  SP_HIP(g_tree_buf.reserve(emp_bytes + felt_bytes + idx_bytes + src_bytes + 1024));
   char* b = (char*)g_tree_buf.ptr;
   uint64_t* d_emp = (uint64_t*)b;
   uint64_t* d_felts = (uint64_t*)(b + emp_bytes);
-  int2* d_src = (int2*)(b + emp_bytes + felt_bytes);
+  uint64_t* d_idx = (uint64_t*)(b + emp_bytes + felt_bytes);
+  int2* d_src = (int2*)(b + emp_bytes + felt_bytes + idx_bytes);
   Scratch s;
   rc = get_scratch_public(n, s, 0);
   if (rc != SP_OK) return rc;
@@ -419,48 +561,34 @@ int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_
   const std::vector<uint64_t>* emp = nullptr;
   rc = empty_roots(t.empty_leaf, s, &emp);
   if (rc != SP_OK) return rc;
-  SP_HIP(hipMemcpy(d_emp, emp->data(), emp_bytes, hipMemcpyHostToDevice));
-  if (n_sib) SP_HIP(hipMemcpy(d_felts, sib.data(), n_sib * 32, hipMemcpyHostToDevice));
-  SP_HIP(hipMemcpy(d_felts + 4 * base[0], leaves, n * 32, hipMemcpyHostToDevice));
-  SP_HIP(hipMemcpy(d_src, src.data(), src_bytes, hipMemcpyHostToDevice));
+  SP_HIP(hipMemcpyAsync(d_emp, emp->data(), emp_bytes, hipMemcpyHostToDevice, 0));
+  SP_HIP(hipMemcpyAsync(d_felts, leaves, n * 32, hipMemcpyHostToDevice, 0));
+  SP_HIP(hipMemcpyAsync(d_idx, keys, n * 8, hipMemcpyHostToDevice, 0));
+  // ---- device: the structure of every level and the sibling lookups in one launch, then the hashes ----
+  hipLaunchKernelGGL(tree_structure_kernel, dim3(1), dim3(1024), 0, 0, lv, d_idx, d_src);
+  hipLaunchKernelGGL(tree_lookup_kernel, dim3((unsigned)((srcs + 255) / 256)), dim3(256), 0, 0, lv, d_idx, t.table,
+                     t.slots - 1, d_felts, d_src, (unsigned)srcs);
+  SP_HIP(hipGetLastError());
   for (unsigned l = 0; l < height; ++l) {
-    rc = enqueue_pedersen(d_felts, 1, d_emp + 4 * l, 1, d_felts + 4 * base[l + 1], 1, nullptr, s.flag, level_cnt[l],
-                          0, s, d_src + level_off[l]);
+    rc = enqueue_pedersen(d_felts, 1, d_emp + 4 * l, 1, d_felts + 4 * (size_t)lv.val_base[l + 1], 1, nullptr, s.flag,
+                          cnt[l + 1], 0, s, d_src + lv.src_off[l]);
     if (rc != SP_OK) return rc;
   }
-  SP_HIP(hipDeviceSynchronize());
   unsigned f = 0;
-  SP_HIP(hipMemcpy(&f, s.flag, sizeof(unsigned), hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpy(&f, s.flag, sizeof(unsigned), hipMemcpyDeviceToHost));  // waits for the stream
   if (status) *status = (uint8_t)f;
-  if (f != 0) {  // an input out of range or an unhashable pair: the tree is left as it was
+  if (f != 0) {  // an input out of range or an unhashable pair: nothing was written, the tree is as it was
     std::memcpy(new_root, old_root, 32);
     return SP_OK;
   }
-  std::vector<uint64_t> fresh((total_nodes - n) * 4);
-  SP_HIP(hipMemcpy(fresh.data(), d_felts + 4 * base[1], fresh.size() * 8, hipMemcpyDeviceToHost));
-  // ---- refresh the store (one node map per level: levels in parallel) ----
-  std::vector<size_t> fresh_off(height + 1, 0);
-  for (unsigned l = 0; l < height; ++l) fresh_off[l + 1] = fresh_off[l] + level_idx[l + 1].size();
-  for_levels_parallel(height + 1, [&](unsigned lvl_no) {
-    NodeMap& lvl = t.nodes[lvl_no];
-    if (lvl_no == 0) {
-      for (size_t i = 0; i < n; ++i) {
-        FeltKey v;
-        std::memcpy(v.w, leaves + 4 * i, 32);
-        lvl.put(keys[i], v);
-      }
-      return;
-    }
-    const std::vector<uint64_t>& idx = level_idx[lvl_no];
-    const uint64_t* vals = fresh.data() + 4 * fresh_off[lvl_no - 1];
-    for (size_t q = 0; q < idx.size(); ++q) {
-      FeltKey v;
-      std::memcpy(v.w, vals + 4 * q, 32);
-      lvl.put(idx[q], v);
-    }
-  });
-  const size_t pos = fresh_off[height];
-  std::memcpy(new_root, fresh.data() + 4 * (pos - 1), 32);
+  // ---- commit: every new node into the table, one launch ----
+  hipLaunchKernelGGL(tree_insert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, t.table, t.slots - 1, lv,
+                     d_idx, d_felts, (unsigned)total, t.d_entries);
+  SP_HIP(hipGetLastError());
+  SP_HIP(hipMemcpy(t.root, d_felts + 4 * (size_t)lv.val_base[height], 32, hipMemcpyDeviceToHost));
+  t.has_root = true;
+  t.entries += total;  // upper bound until tree_reserve reads the device counter again
+  std::memcpy(new_root, t.root, 32);
   return SP_OK;
 }
 
