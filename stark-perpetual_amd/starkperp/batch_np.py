@@ -1,0 +1,136 @@
+"""NumPy batch entry points: the same C-ABI calls as starkperp.batch with felts as `uint64[n, 4]`
+little-endian limb arrays (the ABI's own layout), so that a 4096-order batch does not pay a Python
+int <-> bytes conversion per field element (round 1: ~5 ms of the 17 ms host-inclusive C3 batch).
+Range errors are reported the way the list API reports them (AssertionError for what signature.py
+asserts); the arrays are handed to the library without a copy when they are C-contiguous uint64."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .batch import (EC_ORDER, FIELD_PRIME, HASH_OUT_OF_RANGE, HASH_UNHASHABLE, VERIFY_TRUE, _raise_hash_status,
+                    raise_for_verify_code)
+
+_P_LIMBS = np.array([(FIELD_PRIME >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+
+
+def felts_from_ints(values) -> np.ndarray:
+    """ints (0 <= v < 2^256) -> uint64[n, 4]."""
+    raw = b"".join([int(v).to_bytes(32, "little") for v in values])
+    return np.frombuffer(raw, dtype="<u8").reshape(len(values), 4).copy()
+
+
+def ints_from_felts(arr) -> list:
+    raw = np.ascontiguousarray(arr, dtype="<u8").tobytes()
+    return [int.from_bytes(raw[32 * i : 32 * i + 32], "little") for i in range(len(raw) // 32)]
+
+
+def _felts(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.ndim == 2 and a.shape[1] == 4 and (n is None or a.shape[0] == n), "felts are uint64[n, 4]"
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def pack_fields(n, fields) -> np.ndarray:
+    """Bit-packs 64-bit fields into felts: fields = [(uint64[n] values or an int, bit offset)], offsets
+    non-overlapping - the word layouts of perpetual_messages.py without big-integer arithmetic."""
+    out = np.zeros((n, 4), dtype=np.uint64)
+    for values, offset in fields:
+        v = np.broadcast_to(np.asarray(values, dtype=np.uint64), (n,))
+        k, sh = divmod(offset, 64)
+        out[:, k] |= v << np.uint64(sh)
+        if sh and k + 1 < 4:
+            out[:, k + 1] |= v >> np.uint64(64 - sh)
+    return out
+
+
+def pedersen_hash_many(x, y) -> np.ndarray:
+    """uint64[n, 4] x, y -> uint64[n, 4] hashes (signature.py:296-318 per row)."""
+    x = _felts(x)
+    n = x.shape[0]
+    y = _felts(y, n)
+    out = np.empty((n, 4), dtype=np.uint64)
+    if n == 0:
+        return out
+    st = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.ensure_init().sp_pedersen_batch(_ptr(x), _ptr(y), _ptr(out), _ptr(st), n), "sp_pedersen_batch")
+    bad = np.flatnonzero(st)
+    if bad.size:
+        _raise_hash_status(int(st[bad[0]]))
+    return out
+
+
+def pedersen_chains(words) -> np.ndarray:
+    """words uint64[depth, n, 4]: row i of the result = H(...H(H(w[0][i], w[1][i]), w[2][i])..., w[-1][i])."""
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    assert w.ndim == 3 and w.shape[2] == 4 and w.shape[0] >= 2
+    depth, n = w.shape[0], w.shape[1]
+    out = np.empty((n, 4), dtype=np.uint64)
+    if n == 0:
+        return out
+    st = np.zeros(1, dtype=np.uint8)
+    _lib.check(_lib.ensure_init().sp_pedersen_chains(_ptr(w), n, depth, _ptr(out), _ptr(st)), "sp_pedersen_chains")
+    if st[0]:
+        _raise_hash_status(HASH_UNHASHABLE if st[0] & 2 else HASH_OUT_OF_RANGE)
+    return out
+
+
+def verify_codes(z, r, s, qx, qy=None, key_tables=None) -> np.ndarray:
+    """Result codes (include/starkperp.h SP_VERIFY_*) of verify(z, r, s, key) per row; qy None = x-only
+    keys (signature.py:229-238).  key_tables as in starkperp.batch.verify_codes."""
+    z = _felts(z)
+    n = z.shape[0]
+    r, s, qx = _felts(r, n), _felts(s, n), _felts(qx, n)
+    qy = None if qy is None else _felts(qy, n)
+    res = np.zeros(n, dtype=np.uint8)
+    if n == 0:
+        return res
+    lib = _lib.ensure_init()
+    fn = lib.sp_ecdsa_verify_batch if key_tables is None else (
+        lib.sp_ecdsa_verify_batch_keyed if key_tables else None)
+    if fn is None:
+        raise ValueError("key_tables=False (forced ladder) is only offered by the list API")
+    _lib.check(fn(_ptr(z), _ptr(r), _ptr(s), _ptr(qx), None if qy is None else _ptr(qy), _ptr(res), n),
+               "sp_ecdsa_verify_batch")
+    return res
+
+
+def verify_many(z, r, s, qx, qy=None) -> np.ndarray:
+    """bool[n]; raises the reference's AssertionError for the first row that violates a pre-assert."""
+    codes = verify_codes(z, r, s, qx, qy)
+    bad = np.flatnonzero(codes > VERIFY_TRUE)
+    if bad.size:
+        i = int(bad[0])
+        zi, ri, si = (ints_from_felts(a[i : i + 1])[0] for a in (_felts(z), _felts(r), _felts(s)))
+        raise_for_verify_code(int(codes[i]), zi, ri, si)
+    return codes == VERIFY_TRUE
+
+
+def order_ids(message_hashes) -> np.ndarray:
+    """order/order.cairo:23-59: the 64 most significant bits of the 251-bit message hash, uint64[n]."""
+    h = _felts(message_hashes)
+    return (h[:, 2] >> np.uint64(59)) | (h[:, 3] << np.uint64(5))
+
+
+def limit_order_words(asset_sell, asset_buy, asset_fee, amount_sell, amount_buy, amount_fee, nonce, position_id,
+                      expiration_timestamp) -> np.ndarray:
+    """The five hash inputs of get_limit_order_msg_without_bounds (perpetual_messages.py:253-286) for n
+    orders: uint64[5, n, 4].  Assets are felts (uint64[n, 4]); amounts / position ids uint64[n]; nonce and
+    expiration below 2^32.  sell / buy are the caller's choice (is_buying_synthetic picks them)."""
+    a_s, a_b, a_f = _felts(asset_sell), _felts(asset_buy), _felts(asset_fee)
+    n = a_s.shape[0]
+    u = lambda v: np.broadcast_to(np.asarray(v, dtype=np.uint64), (n,))
+    assert int(u(nonce).max(initial=0)) < 2**32 and int(u(expiration_timestamp).max(initial=0)) < 2**32
+    word0 = pack_fields(n, [(u(nonce), 0), (u(amount_fee), 32), (u(amount_buy), 96), (u(amount_sell), 160)])
+    pos = u(position_id)
+    word1 = pack_fields(n, [(u(expiration_timestamp), 17), (pos, 49), (pos, 113), (pos, 177), (3, 241)])
+    return np.stack([a_s, a_b, a_f, word0, word1])
+
+
+def limit_order_msgs(*args) -> np.ndarray:
+    """Message hashes of n limit orders: four batched launches, arrays in and out."""
+    return pedersen_chains(limit_order_words(*args))

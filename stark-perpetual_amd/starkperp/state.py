@@ -191,6 +191,22 @@ class LibrarySparseTree:
             raise AssertionError("Unhashable input." if st[0] & 2 else "leaf out of range")
         return self._lib.unpack_felts(old, 1)[0], self._lib.unpack_felts(new, 1)[0]
 
+    def update_arrays(self, keys, leaves) -> Tuple[int, int]:
+        """The same update from NumPy arrays: keys uint64[n] (any order, distinct), leaves uint64[n, 4]."""
+        import numpy as np
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        leaves = np.ascontiguousarray(leaves, dtype=np.uint64)
+        assert keys.ndim == 1 and leaves.shape == (keys.shape[0], 4)
+        order = np.argsort(keys, kind="stable")
+        keys, leaves = np.ascontiguousarray(keys[order]), np.ascontiguousarray(leaves[order])
+        old, new, st = self._lib.new_felts(1), self._lib.new_felts(1), self._lib.new_bytes(1)
+        self._lib.check(self._lib.ensure_init().sp_tree_update(
+            self._handle, keys.ctypes.data_as(self._ct.c_void_p), leaves.ctypes.data_as(self._ct.c_void_p),
+            keys.shape[0], old, new, st), "sp_tree_update")
+        if st[0]:
+            raise AssertionError("Unhashable input." if st[0] & 2 else "leaf out of range")
+        return self._lib.unpack_felts(old, 1)[0], self._lib.unpack_felts(new, 1)[0]
+
     def close(self):
         if self._handle is not None:
             handle, self._handle = self._handle, None
