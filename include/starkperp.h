@@ -218,6 +218,16 @@ int sp_ec_ladder_trace_dev(const uint64_t* m, const uint64_t* qx, const uint64_t
 int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
                               const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out,
                               void* stream);
+/* ECDSA-verification AIR (what verify() mimics, signature.py:217-260): three linked EC ladders per
+ * signature - z G from MINUS_SHIFT_POINT, r Q and w B from SHIFT_POINT with B = zG + rQ (:252-254) - and
+ * x(wB - SHIFT_POINT) == r (:255); 1024 rows of ten columns m, px, py, qx, qy, la, ld, cx, cy, cr per
+ * signature (cols = 10 columns of 1024 * n_sigs felts).  w = s^-1 mod N is an input, as in the reference
+ * (:220: verify computes it before mimicking the AIR).  Composition: 26 constraints, periodic_lde = 12
+ * tables of 4096 felts. */
+int sp_ecdsa_trace_dev(const uint64_t* z, const uint64_t* r, const uint64_t* w, const uint64_t* qx,
+                       const uint64_t* qy, size_t n_sigs, uint64_t* cols, void* stream);
+int sp_air_eval_ecdsa_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
+                          const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream);
 /* One FRI fold of f on shift * <w_M> (M = 2^log_m) to g on shift^2 * <w_{M/2}>:
  * g(x^2) = (f(x) + f(-x)) / 2 + beta (f(x) - f(-x)) / (2 x). */
 int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uint64_t* beta_host,

@@ -198,7 +198,113 @@ def ec_ladder_constraint_values(cur, nxt, per, shift_point=None):
     ]
 
 
+# ---- the ECDSA-verification AIR: what verify() mimics, signature.py:217-260 -----------
+# One verification = 1024 rows of the ten columns m, px, py, qx, qy, la, ld, cx, cy, cr:
+#   rows   0..255   ladder z * G   from MINUS_SHIFT_POINT (signature.py:252)
+#   rows 256..511   ladder r * Q   from SHIFT_POINT       (:253)
+#   rows 512..767   ladder w * B   from SHIFT_POINT, B = zG + rQ (:254: the base point of this ladder is
+#                   tied to the two outputs by the chord rule at row 511)
+#   row  767        x(wB - SHIFT_POINT) == r              (:255)
+#   rows 768..1023  idle (keeps the period a power of two)
+# Every ladder is the EC-ladder AIR above (doubling on every row, chord step when the bit is set, m = 0
+# at row 251 - which is also the 251-bit range check of z, r and w, :225-227).  cx, cy carry the output of
+# ladder 0 through block 1; cr carries r from row 256 to row 767.  Q must be on the curve (:241).
+# w = s^-1 mod N (:220) is an INPUT of the AIR exactly as in the reference, whose `verify` computes it
+# before "mimicking the AIR"; ecdsa_instance() checks it natively.
+def ecdsa_instance(z, r, s, pubkey):
+    """(z, r, w, Q) of a signature the reference accepts; raises AssertionError otherwise."""
+    w = R.inv_mod_curve_size(s)
+    assert 1 <= r < 2**251 and 1 <= w < 2**251 and 0 < z < 2**251 and R.is_point_on_curve(*pubkey)
+    assert w * s % R.EC_ORDER == 1
+    assert R.verify(z, r, s, tuple(pubkey))
+    return z, r, w, tuple(pubkey)
+
+
+def ecdsa_trace(instances):
+    """instances: list of (z, r, w, (Qx, Qy)).  Returns 10 columns of 1024 rows each."""
+    cols = [[] for _ in range(10)]
+    shift, mshift = tuple(R.SHIFT_POINT), tuple(R.MINUS_SHIFT_POINT)
+    for z, r, w, q in instances:
+        lad0 = ec_ladder_trace([(z, tuple(R.EC_GEN))], mshift)
+        lad1 = ec_ladder_trace([(r, q)], shift)
+        zg = (lad0[1][251], lad0[2][251])
+        rq = (lad1[1][251], lad1[2][251])
+        b = R.ec_add(zg, rq)
+        lad2 = ec_ladder_trace([(w, b)], shift)
+        wb = (lad2[1][251], lad2[2][251])
+        lad1[5][255] = R.div_mod(rq[1] - zg[1], rq[0] - zg[0], P)            # slope of zG + rQ at row 511
+        lad2[5][255] = R.div_mod(wb[1] + shift[1], wb[0] - shift[0], P)      # slope of wB + (-shift) at row 767
+        assert (lad2[5][255] ** 2 - wb[0] - shift[0]) % P == r, "not a valid signature"
+        for block, lad in enumerate((lad0, lad1, lad2)):
+            for c in range(7):
+                cols[c] += lad[c]
+            cols[7] += [zg[0] if block == 1 else 0] * 256
+            cols[8] += [zg[1] if block == 1 else 0] * 256
+            cols[9] += [r if block in (1, 2) else 0] * 256
+        for c in range(10):
+            cols[c] += [0] * 256
+    return cols
+
+
+def ecdsa_periodic_columns():
+    """Period-1024 tables: step, first, start_y, z251, gbase, oncurve, carry_load, carry_hold, addb, rload,
+    rhold, fin."""
+    def rows(fn):
+        return [1 if fn(i) else 0 for i in range(1024)]
+    ladder = lambda i: i < 768
+    step = rows(lambda i: ladder(i) and i % 256 != 255)
+    first = rows(lambda i: ladder(i) and i % 256 == 0)
+    start_y = [0] * 1024
+    start_y[0], start_y[256], start_y[512] = R.MINUS_SHIFT_POINT[1], R.SHIFT_POINT[1], R.SHIFT_POINT[1]
+    return [step, first, start_y, rows(lambda i: ladder(i) and i % 256 == 251), rows(lambda i: i == 0),
+            rows(lambda i: i == 256), rows(lambda i: i == 255), rows(lambda i: 256 <= i < 511),
+            rows(lambda i: i == 511), rows(lambda i: i == 256), rows(lambda i: 256 <= i < 767), rows(lambda i: i == 767)]
+
+
+N_ECDSA_CONSTRAINTS = 26
+
+
+def ecdsa_constraint_values(cur, nxt, per):
+    sx, sy = R.SHIFT_POINT
+    gx, gy = R.EC_GEN
+    m, px, py, qx, qy, la, ld, cx, cy, cr = cur
+    m_n, px_n, py_n, qx_n, qy_n, _, _, cx_n, cy_n, cr_n = nxt
+    step, first, start_y, z251, gbase, oncurve, cload, chold, addb, rload, rhold, fin = per
+    b = (m - 2 * m_n) % P
+    nb = (1 - b) % P
+    return [
+        step * b * (b - 1) % P,
+        step * (ld * 2 * qy - 3 * qx * qx - R.ALPHA) % P,
+        step * (qx_n - ld * ld + 2 * qx) % P,
+        step * (qy_n - ld * (qx - qx_n) + qy) % P,
+        step * b * (la * (px - qx) - (py - qy)) % P,
+        step * b * (px_n - la * la + px + qx) % P,
+        step * b * (py_n - la * (px - px_n) + py) % P,
+        step * nb * (px_n - px) % P,
+        step * nb * (py_n - py) % P,
+        first * (px - sx) % P,
+        (first * py - start_y) % P,
+        z251 * m % P,
+        gbase * (qx - gx) % P,
+        gbase * (qy - gy) % P,
+        oncurve * (qy * qy - qx * qx * qx - R.ALPHA * qx - R.BETA) % P,
+        cload * (cx_n - px) % P,
+        cload * (cy_n - py) % P,
+        chold * (cx_n - cx) % P,
+        chold * (cy_n - cy) % P,
+        addb * (la * (px - cx) - (py - cy)) % P,
+        addb * (qx_n - la * la + px + cx) % P,
+        addb * (qy_n - la * (px - qx_n) + py) % P,
+        rload * (cr - m) % P,
+        rhold * (cr_n - cr) % P,
+        fin * (la * (px - sx) - (py + sy)) % P,
+        fin * (cr - la * la + px + sx) % P,
+    ]
+
+
 AIRS = {
+    "ecdsa": {"n_cols": 10, "period": 1024, "n_constraints": N_ECDSA_CONSTRAINTS,
+              "periodic": ecdsa_periodic_columns, "constraints": ecdsa_constraint_values},
     "pedersen": {"n_cols": 4, "period": 512, "n_constraints": N_CONSTRAINTS,
                  "periodic": periodic_columns, "constraints": constraint_values},
     "ec_ladder": {"n_cols": 7, "period": 256, "n_constraints": N_EC_LADDER_CONSTRAINTS,
@@ -305,6 +411,18 @@ def verify_proof(proof, hash2=R.pedersen_hash, final_log=6, air=None):
     to the final layer, and the degree bound of the final layer.  Returns (ok, reason)."""
     n, seed, shift = proof["n"], proof["seed"], proof["shift"]
     spec = AIRS[air or proof.get("air", "pedersen")]
+    if (air or proof.get("air")) == "ecdsa":
+        # the statement: (z, r, s, Qx, Qy) per signature with the pre-asserts of signature.py:219-241; w, the
+        # scalar of the third ladder, is s^-1 mod N (:220) and must pass :226
+        pub = proof.get("public_inputs", [])
+        if len(pub) != 5 * (n // 1024):
+            return False, "public inputs"
+        for k in range(n // 1024):
+            z, r, sig_s, qx, qy = pub[5 * k : 5 * k + 5]
+            if not (1 <= sig_s < R.EC_ORDER and 1 <= r < 2**251 and 0 < z < 2**251 and R.is_point_on_curve(qx, qy)):
+                return False, "public inputs"
+            if not 1 <= R.inv_mod_curve_size(sig_s) < 2**251:
+                return False, "public inputs"
     m = BLOWUP * n
     log_m = m.bit_length() - 1
     root_t, roots, final = proof["trace_root"], proof["layer_roots"], proof["final_layer"]

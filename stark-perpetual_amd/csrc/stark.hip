@@ -401,6 +401,245 @@ ec_ladder_trace_kernel(const uint64_t* __restrict__ pm, const uint64_t* __restri
   }
 }
 
+// ---- ECDSA-verification AIR (what verify() mimics, signature.py:217-260) --------------
+// Ten columns m, px, py, qx, qy, la, ld, cx, cy, cr; 1024 rows per verification: three EC ladders
+// (z G from -SHIFT, r Q from +SHIFT, w B from +SHIFT with B = zG + rQ) in rows 0..767, the last 256 rows
+// idle (oracle/stark_ref.py ecdsa_trace is the definition).  Witness generation, one thread per
+// verification: the ladder code of ec_ladder_trace_kernel run three times in a loop (the third ladder's
+// base point is the sum of the first two outputs), then the two linking slopes and the carry columns.
+__global__ void __launch_bounds__(64)
+ecdsa_trace_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr, const uint64_t* __restrict__ pw,
+                   const uint64_t* __restrict__ pqx, const uint64_t* __restrict__ pqy, size_t K, aff_packed shift,
+                   aff_packed gen, uint64_t* __restrict__ cols /* [10][1024 K] plain */, int32_t* __restrict__ sc) {
+  const size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= K) return;
+  const size_t n = 1024 * K;
+  const size_t plane = (size_t)256 * NL * K;
+  int32_t *qX = sc, *qY = sc + plane, *qZ = sc + 2 * plane, *pX = sc + 3 * plane, *pY = sc + 4 * plane,
+          *pZZ = sc + 5 * plane, *pZZZ = sc + 6 * plane, *pre = sc + 7 * plane;
+  uint64_t *cm = cols, *cpx = cols + 4 * n, *cpy = cols + 8 * n, *cqx = cols + 12 * n, *cqy = cols + 16 * n,
+           *cla = cols + 20 * n, *cld = cols + 24 * n, *ccx = cols + 28 * n, *ccy = cols + 32 * n, *ccr = cols + 36 * n;
+  u256 zero;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) zero.w[q] = 0;
+  const aff shift_m = ld_aff(&shift);
+  aff out[3];  // ladder outputs (Montgomery affine)
+#pragma unroll 1
+  for (int blk = 0; blk < 3; ++blk) {
+    const size_t row0 = 1024 * h + 256 * (size_t)blk;
+    const u256 m0 = ld_u256((blk == 0 ? pz : blk == 1 ? pr : pw) + 4 * h);
+    aff base, start = shift_m;
+    if (blk == 0) {
+      base = ld_aff(&gen);
+      start.y = fe_neg(start.y);  // MINUS_SHIFT_POINT
+    } else if (blk == 1) {
+      base.x = fe_to_mont(fe_unpack(ld_u256(pqx + 4 * h)));
+      base.y = fe_to_mont(fe_unpack(ld_u256(pqy + 4 * h)));
+    } else {  // B = zG + rQ (affine chord rule; x1 == x2 cannot happen for a signature verify() accepts)
+      const fe lam = fe_mul(fe_sub(out[1].y, out[0].y), fe_inv(fe_carry(fe_sub(out[1].x, out[0].x))));
+      base.x = fe_carry(fe_sub(fe_sub(fe_sqr(lam), out[0].x), out[1].x));
+      base.y = fe_carry(fe_sub(fe_mul(lam, fe_sub(out[0].x, base.x)), out[0].y));
+      st_u256(cla + 4 * (1024 * h + 511), fe_pack(fe_from_mont(lam)));
+    }
+    {  // m column
+      u256 s = m0;
+      for (int j = 0; j < 256; ++j) {
+        st_u256(cm + 4 * (row0 + j), s);
+        if (j < 255) {
+#pragma unroll
+          for (int q = 0; q < 7; ++q) s.w[q] = (s.w[q] >> 1) | (s.w[q + 1] << 31);
+          s.w[7] >>= 1;
+        }
+      }
+    }
+    // phase 1: doubling chain, Jacobian -> affine with one inversion
+    jac Q;
+    Q.X = base.x;
+    Q.Y = base.y;
+    Q.Z = FE_ONE_M;
+    fe run = FE_ONE_M;
+    for (int j = 0; j < 256; ++j) {
+      tr_store(qX, K, j, h, Q.X);
+      tr_store(qY, K, j, h, Q.Y);
+      tr_store(qZ, K, j, h, Q.Z);
+      tr_store(pre, K, j, h, run);
+      run = fe_mul(run, Q.Z);
+      if (j < 255) Q = jac_dbl(Q, FE_ONE_M);
+    }
+    fe inv = fe_inv(run);
+    for (int j = 255; j >= 0; --j) {
+      const fe z = tr_load(qZ, K, j, h);
+      const fe iz = fe_mul(inv, tr_load(pre, K, j, h));
+      inv = fe_mul(inv, z);
+      const fe iz2 = fe_sqr(iz);
+      const fe ax = fe_mul(tr_load(qX, K, j, h), iz2);
+      const fe ay = fe_mul(tr_load(qY, K, j, h), fe_mul(iz2, iz));
+      tr_store(qX, K, j, h, ax);
+      tr_store(qY, K, j, h, ay);
+      st_u256(cqx + 4 * (row0 + j), fe_pack(fe_from_mont(ax)));
+      st_u256(cqy + 4 * (row0 + j), fe_pack(fe_from_mont(ay)));
+    }
+    // phase 2: tangent slopes ld = (3 qx^2 + 1) / (2 qy), rows 0..254
+    run = FE_ONE_M;
+    for (int j = 0; j < 255; ++j) {
+      tr_store(pre, K, j, h, run);
+      run = fe_mul(run, fe_carry(fe_dbl(tr_load(qY, K, j, h))));
+    }
+    inv = fe_inv(run);
+    st_u256(cld + 4 * (row0 + 255), zero);
+    for (int j = 254; j >= 0; --j) {
+      const fe d = fe_carry(fe_dbl(tr_load(qY, K, j, h)));
+      const fe id = fe_mul(inv, tr_load(pre, K, j, h));
+      inv = fe_mul(inv, d);
+      const fe xx = fe_sqr(tr_load(qX, K, j, h));
+      const fe num = fe_carry(fe_add(fe_carry(fe_add(fe_dbl(xx), xx)), FE_ONE_M));
+      st_u256(cld + 4 * (row0 + j), fe_pack(fe_from_mont(fe_mul(num, id))));
+    }
+    // phase 3: partial sums in XYZZ, then affine with one inversion
+    xyzz acc = xyzz_from_aff(start);
+    for (int j = 0; j < 256; ++j) {
+      tr_store(pX, K, j, h, acc.X);
+      tr_store(pY, K, j, h, acc.Y);
+      tr_store(pZZ, K, j, h, acc.ZZ);
+      tr_store(pZZZ, K, j, h, acc.ZZZ);
+      if (j < 251 && ((m0.w[j >> 5] >> (j & 31)) & 1u)) {
+        aff q;
+        q.x = tr_load(qX, K, j, h);
+        q.y = tr_load(qY, K, j, h);
+        acc = xyzz_madd(acc, q);
+      }
+    }
+    run = FE_ONE_M;
+    for (int j = 0; j < 256; ++j) {
+      tr_store(pre, K, j, h, run);
+      run = fe_mul(run, tr_load(pZZZ, K, j, h));
+    }
+    inv = fe_inv(run);
+    for (int j = 255; j >= 0; --j) {
+      const fe zzz = tr_load(pZZZ, K, j, h);
+      const fe izzz = fe_mul(inv, tr_load(pre, K, j, h));
+      inv = fe_mul(inv, zzz);
+      const fe iz = fe_mul(tr_load(pZZ, K, j, h), izzz);
+      const fe ax = fe_mul(tr_load(pX, K, j, h), fe_sqr(iz));
+      const fe ay = fe_mul(tr_load(pY, K, j, h), izzz);
+      tr_store(pX, K, j, h, ax);
+      tr_store(pY, K, j, h, ay);
+      st_u256(cpx + 4 * (row0 + j), fe_pack(fe_from_mont(ax)));
+      st_u256(cpy + 4 * (row0 + j), fe_pack(fe_from_mont(ay)));
+      if (j == 255) { out[blk].x = ax; out[blk].y = ay; }
+    }
+    // phase 4: chord slopes la = (py - qy) / (px - qx) on the addition rows
+    run = FE_ONE_M;
+    for (int j = 0; j < 251; ++j) {
+      if ((m0.w[j >> 5] >> (j & 31)) & 1u) {
+        const fe dx = fe_carry(fe_sub(tr_load(pX, K, j, h), tr_load(qX, K, j, h)));
+        tr_store(pZZ, K, j, h, dx);
+        tr_store(pre, K, j, h, run);
+        run = fe_mul(run, dx);
+      }
+    }
+    inv = fe_inv(run);
+    for (int j = 255; j >= 0; --j) {
+      u256 o = zero;
+      if (j < 251 && ((m0.w[j >> 5] >> (j & 31)) & 1u)) {
+        const fe dx = tr_load(pZZ, K, j, h);
+        const fe idx = fe_mul(inv, tr_load(pre, K, j, h));
+        inv = fe_mul(inv, dx);
+        const fe lam = fe_mul(fe_sub(tr_load(pY, K, j, h), tr_load(qY, K, j, h)), idx);
+        o = fe_pack(fe_from_mont(lam));
+      }
+      if (!(blk == 1 && j == 255)) st_u256(cla + 4 * (row0 + j), o);  // row 511 receives the linking slope below
+    }
+  }
+  // linking slope at row 767: wB + (-SHIFT), whose x must be r
+  {
+    const fe lam = fe_mul(fe_add(out[2].y, shift_m.y), fe_inv(fe_carry(fe_sub(out[2].x, shift_m.x))));
+    st_u256(cla + 4 * (1024 * h + 767), fe_pack(fe_from_mont(lam)));
+  }
+  // carries and the idle block
+  const u256 zgx = fe_pack(fe_from_mont(out[0].x)), zgy = fe_pack(fe_from_mont(out[0].y));
+  const u256 rr = ld_u256(pr + 4 * h);
+  for (int i = 0; i < 1024; ++i) {
+    const size_t row = 1024 * h + i;
+    const bool b1 = i >= 256 && i < 512;
+    st_u256(ccx + 4 * row, b1 ? zgx : zero);
+    st_u256(ccy + 4 * row, b1 ? zgy : zero);
+    st_u256(ccr + 4 * row, (i >= 256 && i < 768) ? rr : zero);
+    if (i >= 768) {
+      st_u256(cm + 4 * row, zero); st_u256(cpx + 4 * row, zero); st_u256(cpy + 4 * row, zero);
+      st_u256(cqx + 4 * row, zero); st_u256(cqy + 4 * row, zero); st_u256(cla + 4 * row, zero);
+      st_u256(cld + 4 * row, zero);
+    }
+  }
+}
+
+struct EcdsaAirParams {
+  fe alpha[26];  // Montgomery
+  fe zinv[4];    // R * Montgomery form of 1 / (x^n - 1)
+  fe sx, sy, gx, gy, beta;  // plain
+};
+
+// Composition of the ECDSA-verification AIR (26 constraints, oracle/stark_ref.py ecdsa_constraint_values);
+// plain operands, Montgomery constants (see the file comment).  per: 12 tables of 4096 plain felts.
+__global__ void __launch_bounds__(256)
+air_eval_ecdsa_kernel(const uint64_t* __restrict__ trace /* [10][M] plain */, const uint64_t* __restrict__ per,
+                      size_t M, EcdsaAirParams prm, uint64_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const size_t in = (i + 4) & (M - 1);
+  auto col = [&](int c, size_t r) { return ld_fe_packed(trace + 4 * ((size_t)c * M + r)); };
+  auto pcol = [&](int c) { return ld_fe_packed(per + 4 * ((size_t)c * 4096 + (i & 4095))); };
+  const fe m = col(0, i), px = col(1, i), py = col(2, i), qx = col(3, i), qy = col(4, i), la = col(5, i),
+           ld = col(6, i), cx = col(7, i), cy = col(8, i), cr = col(9, i);
+  const fe m_n = col(0, in), px_n = col(1, in), py_n = col(2, in), qx_n = col(3, in), qy_n = col(4, in),
+           cx_n = col(7, in), cy_n = col(8, in), cr_n = col(9, in);
+  const fe one = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+  const fe b = fe_carry(fe_sub(m, fe_dbl(m_n)));
+  const fe bM = fe_to_mont(b), laM = fe_to_mont(la), ldM = fe_to_mont(ld), qxM = fe_to_mont(qx), qyM = fe_to_mont(qy);
+  const fe nbM = fe_carry(fe_sub(FE_ONE_M, bM));
+  const fe qxx = fe_mul(qxM, qx);
+  const fe lala = fe_mul(laM, la);
+  // ladder rows (selector `step`)
+  fe acc = fe_mul(prm.alpha[0], fe_mul(bM, fe_carry(fe_sub(b, one))));
+  auto add = [&](int k, const fe& c) { acc = fe_weak_reduce(fe_add(acc, fe_mul(prm.alpha[k], c))); };
+  add(1, fe_carry(fe_sub(fe_sub(fe_mul(ldM, fe_carry(fe_dbl(qy))), fe_carry(fe_add(fe_dbl(qxx), qxx))), one)));
+  add(2, fe_carry(fe_add(fe_sub(qx_n, fe_mul(ldM, ld)), fe_dbl(qx))));
+  add(3, fe_carry(fe_add(fe_sub(qy_n, fe_mul(ldM, fe_sub(qx, qx_n))), qy)));
+  add(4, fe_mul(bM, fe_carry(fe_sub(fe_mul(laM, fe_sub(px, qx)), fe_sub(py, qy)))));
+  add(5, fe_mul(bM, fe_carry(fe_add(fe_sub(px_n, lala), fe_add(px, qx)))));
+  add(6, fe_mul(bM, fe_carry(fe_add(fe_sub(py_n, fe_mul(laM, fe_sub(px, px_n))), py))));
+  add(7, fe_mul(nbM, fe_carry(fe_sub(px_n, px))));
+  add(8, fe_mul(nbM, fe_carry(fe_sub(py_n, py))));
+  fe total = fe_mul(pcol(0), acc);  // every term below carries the same single 1/R (absorbed by zinv)
+  auto term = [&](const fe& selector, const fe& value) { total = fe_weak_reduce(fe_add(total, fe_mul(selector, value))); };
+  const fe first = pcol(1);
+  term(first, fe_mul(prm.alpha[9], fe_carry(fe_sub(px, prm.sx))));
+  // alpha10 (first * py - start_y): start_y is plain, so alpha10 * start_y is plain and must lose one R like the rest
+  term(first, fe_mul(prm.alpha[10], py));
+  total = fe_weak_reduce(fe_sub(total, fe_mul(one, fe_mul(prm.alpha[10], pcol(2)))));
+  term(pcol(3), fe_mul(prm.alpha[11], m));
+  const fe gbase = pcol(4);
+  term(gbase, fe_mul_add_mul(prm.alpha[12], fe_carry(fe_sub(qx, prm.gx)), prm.alpha[13], fe_carry(fe_sub(qy, prm.gy))));
+  // on-curve: qy^2 - qx^3 - qx - beta
+  term(pcol(5), fe_mul(prm.alpha[14], fe_carry(fe_sub(fe_sub(fe_mul(qyM, qy), fe_mul(qxM, qxx)), fe_add(qx, prm.beta)))));
+  term(pcol(6), fe_mul_add_mul(prm.alpha[15], fe_carry(fe_sub(cx_n, px)), prm.alpha[16], fe_carry(fe_sub(cy_n, py))));
+  term(pcol(7), fe_mul_add_mul(prm.alpha[17], fe_carry(fe_sub(cx_n, cx)), prm.alpha[18], fe_carry(fe_sub(cy_n, cy))));
+  {
+    const fe a0 = fe_carry(fe_sub(fe_mul(laM, fe_sub(px, cx)), fe_sub(py, cy)));
+    const fe a1 = fe_carry(fe_add(fe_sub(qx_n, lala), fe_add(px, cx)));
+    const fe a2 = fe_carry(fe_add(fe_sub(qy_n, fe_mul(laM, fe_sub(px, qx_n))), py));
+    term(pcol(8), fe_mul3_add(prm.alpha[19], a0, prm.alpha[20], a1, prm.alpha[21], a2));
+  }
+  term(pcol(9), fe_mul(prm.alpha[22], fe_carry(fe_sub(cr, m))));
+  term(pcol(10), fe_mul(prm.alpha[23], fe_carry(fe_sub(cr_n, cr))));
+  {
+    const fe f0 = fe_carry(fe_sub(fe_mul(laM, fe_sub(px, prm.sx)), fe_add(py, prm.sy)));
+    const fe f1 = fe_carry(fe_add(fe_sub(cr, lala), fe_add(px, prm.sx)));
+    term(pcol(11), fe_mul_add_mul(prm.alpha[24], f0, prm.alpha[25], f1));
+  }
+  st_u256(out + 4 * i, fe_pack(fe_canon(fe_mul(total, prm.zinv[i & 3]))));
+}
+
 struct EcAirParams {
   fe alpha[12];  // Montgomery
   fe zinv[4];    // R * Montgomery form of 1 / (x^n - 1) for i mod 4 (absorbs the one R the selectors leave)
@@ -878,6 +1117,55 @@ int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodi
   prm.shift_y = fe_unpack(PT_SHIFT_Y);
   hipLaunchKernelGGL(air_eval_ec_ladder_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, trace_lde, periodic_lde, M, prm, out);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_ecdsa_trace_dev(const uint64_t* z, const uint64_t* r, const uint64_t* w, const uint64_t* qx,
+                       const uint64_t* qy, size_t n_sigs, uint64_t* cols, void* stream) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  aff_packed shift, gen;
+  shift.x = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_X))));
+  shift.y = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_SHIFT_Y))));
+  gen.x = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_GEN_X))));
+  gen.y = fe_pack(fe_canon(fe_to_mont(fe_unpack(PT_GEN_Y))));
+  DeviceBuffer& scratch = g_tab.trace_scratch[(hipStream_t)stream];
+  SP_HIP(scratch.reserve((size_t)8 * 256 * NL * n_sigs * sizeof(int32_t)));
+  hipLaunchKernelGGL(ecdsa_trace_kernel, dim3((unsigned)((n_sigs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, z, r,
+                     w, qx, qy, n_sigs, shift, gen, cols, (int32_t*)scratch.ptr);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_air_eval_ecdsa_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
+                          const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  const size_t n = (size_t)1 << log_n, M = 4 * n;
+  EcdsaAirParams prm;
+  for (int k = 0; k < 26; ++k) {
+    u256 a;
+    std::memcpy(a.w, alphas_host + 4 * k, 32);
+    prm.alpha[k] = fe_to_mont(fe_unpack(a));
+  }
+  u256 sh;
+  std::memcpy(sh.w, shift_host, 32);
+  fe sn = fe_to_mont(fe_unpack(sh));
+  for (unsigned i = 0; i < log_n; ++i) sn = fe_sqr(sn);
+  const fe w4 = h_root_of_unity(2);
+  fe wk = FE_ONE_M;
+  for (int k = 0; k < 4; ++k) {
+    prm.zinv[k] = fe_mul(fe_inv(fe_carry(fe_sub(fe_mul(sn, wk), FE_ONE_M))), FE_R2);  // zinv * R^2
+    wk = fe_mul(wk, w4);
+  }
+  prm.sx = fe_unpack(PT_SHIFT_X);
+  prm.sy = fe_unpack(PT_SHIFT_Y);
+  prm.gx = fe_unpack(PT_GEN_X);
+  prm.gy = fe_unpack(PT_GEN_Y);
+  prm.beta = fe_unpack(CURVE_BETA);
+  hipLaunchKernelGGL(air_eval_ecdsa_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     trace_lde, periodic_lde, M, prm, out);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }

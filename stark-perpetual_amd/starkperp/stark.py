@@ -97,8 +97,26 @@ def ec_ladder_periodic_columns():
             [1 if j == 251 else 0 for j in range(256)]]
 
 
+def ecdsa_periodic_columns():
+    """Period-1024 tables of the ECDSA-verification AIR (oracle/stark_ref.py ecdsa_periodic_columns is the
+    definition): step, first, start_y, z251, gbase, oncurve, carry_load, carry_hold, addb, rload, rhold, fin."""
+    def rows(fn):
+        return [1 if fn(i) else 0 for i in range(1024)]
+    ladder = lambda i: i < 768
+    start_y = [0] * 1024
+    start_y[0], start_y[256], start_y[512] = FIELD_PRIME - SHIFT_POINT[1], SHIFT_POINT[1], SHIFT_POINT[1]
+    return [rows(lambda i: ladder(i) and i % 256 != 255), rows(lambda i: ladder(i) and i % 256 == 0), start_y,
+            rows(lambda i: ladder(i) and i % 256 == 251), rows(lambda i: i == 0), rows(lambda i: i == 256),
+            rows(lambda i: i == 255), rows(lambda i: 256 <= i < 511), rows(lambda i: i == 511),
+            rows(lambda i: i == 256), rows(lambda i: 256 <= i < 767), rows(lambda i: i == 767)]
+
+
 N_EC_LADDER_CONSTRAINTS = 12
+N_ECDSA_CONSTRAINTS = 26
+EC_ORDER = 0x800000000000010FFFFFFFFFFFFFFFFB781126DCAE7B2321E66A241ADC64D2F
 AIRS = {
+    "ecdsa": {"n_cols": 10, "period": 1024, "n_constraints": N_ECDSA_CONSTRAINTS, "periodic": ecdsa_periodic_columns,
+              "eval": "sp_air_eval_ecdsa_dev"},
     "pedersen": {"n_cols": 4, "period": 512, "n_constraints": N_CONSTRAINTS, "periodic": periodic_columns,
                  "eval": "sp_air_eval_dev"},
     "ec_ladder": {"n_cols": 7, "period": 256, "n_constraints": N_EC_LADDER_CONSTRAINTS,
@@ -136,6 +154,18 @@ def ec_ladder_trace(ms, qxs, qys):
     cols = torch.empty((7, 256 * k, 4), dtype=torch.int64, device=ms.device)
     _lib.check(lib.sp_ec_ladder_trace_dev(ms.data_ptr(), qxs.data_ptr(), qys.data_ptr(), k, cols.data_ptr(),
                                           _stream()), "sp_ec_ladder_trace_dev")
+    return cols
+
+
+def ecdsa_trace(zs, rs, ws, qxs, qys):
+    """zs, rs, ws, qxs, qys: [k, 4] device tensors (message hashes, r, w = s^-1 mod N, public key points) of
+    signatures verify() accepts -> [10, 1024 k, 4] witness of the ECDSA-verification AIR."""
+    torch = _torch()
+    lib = _lib.ensure_init()
+    k = zs.shape[0]
+    cols = torch.empty((10, 1024 * k, 4), dtype=torch.int64, device=zs.device)
+    _lib.check(lib.sp_ecdsa_trace_dev(zs.data_ptr(), rs.data_ptr(), ws.data_ptr(), qxs.data_ptr(), qys.data_ptr(), k,
+                                      cols.data_ptr(), _stream()), "sp_ecdsa_trace_dev")
     return cols
 
 
@@ -239,6 +269,23 @@ def prove_ec_ladders(ms, qxs, qys, n_queries: int = 8, seed: int = 0, final_log:
     """Benchmark-grade argument (NOT a sound proof system) that k scalar multiplications
     m * Q + SHIFT_POINT were carried out step by step as mimic_ec_mult_air does (the EC-ladder AIR)."""
     return prove_trace(ec_ladder_trace(ms, qxs, qys), "ec_ladder", n_queries, seed, final_log, shift)
+
+
+def prove_ecdsa(msg_hashes, rs, ss, public_keys, n_queries: int = 8, seed: int = 0, final_log: int = 6,
+                shift: int = FIELD_GEN):
+    """Benchmark-grade argument (NOT a sound proof system) that every (z, r, s, Q) passes the reference's
+    verify (signature.py:217-260: the three ladders, the two additions, x == r).  Python ints in; the
+    count must be a power of two.  w = s^-1 mod N is computed here as verify() does (:220) and the public
+    inputs (z, r, s, Qx, Qy per signature) are absorbed into the transcript; the CPU verifier
+    (oracle/stark_ref.verify_proof) re-derives w from s."""
+    dev = "cuda"
+    ws = [pow(s, -1, EC_ORDER) for s in ss]
+    for z, r, w in zip(msg_hashes, rs, ws):
+        assert 0 < z < 2**251 and 1 <= r < 2**251 and 1 <= w < 2**251
+    trace = ecdsa_trace(*(felts_to_tensor(v, dev) for v in (msg_hashes, rs, ws, [q[0] for q in public_keys],
+                                                          [q[1] for q in public_keys])))
+    public = [v for z, r, s, q in zip(msg_hashes, rs, ss, public_keys) for v in (z, r, s, q[0], q[1])]
+    return prove_trace(trace, "ecdsa", n_queries, seed, final_log, shift, public)
 
 
 def prove_trace(trace, air: str, n_queries: int = 8, seed: int = 0, final_log: int = 6,

@@ -326,3 +326,59 @@ def test_sharded_prover_on_one_rank_equals_the_plain_job(stark):
     roots, final = sharded_prover.commit_job(sharded_prover.GpuOps("cuda"), None, stark.pedersen_trace(xs, ys),
                                              alphas, betas)
     assert roots == want_roots and final == want_final
+
+
+def _signatures(k, seed):
+    from starkperp import batch
+    rng = random.Random(seed)
+    keys = [rng.randrange(1, R.EC_ORDER) for _ in range(k)]
+    zs = [rng.randrange(1, 2**251) for _ in range(k)]
+    sigs = batch.sign_many(zs, keys)
+    return zs, [r for r, _ in sigs], [s for _, s in sigs], batch.public_keys_many(keys)
+
+
+def test_ecdsa_air_matches_oracle_and_proves(stark):
+    """N4: the ECDSA-verification AIR (three linked ladders).  GPU witness == oracle witness, the third
+    ladder's base is zG + rQ, GPU composition == oracle composition, a proof verifies on the CPU and a
+    forged public input / tampered opening does not."""
+    import copy
+    zs, rs, ss, pubs = _signatures(2, 41)
+    insts = [S.ecdsa_instance(z, r, s, q) for z, r, s, q in zip(zs, rs, ss, pubs)]
+    ws = [i[2] for i in insts]
+    trace = stark.ecdsa_trace(*(stark.felts_to_tensor(v) for v in (zs, rs, ws, [q[0] for q in pubs], [q[1] for q in pubs])))
+    exp = S.ecdsa_trace(insts)
+    for c, (g, e) in enumerate(zip(trace, exp)):
+        assert stark.tensor_to_felts(g) == e, "column %d" % c
+    n = 2048
+    per = stark.periodic_lde(n, air="ecdsa")
+    exp_per = S.periodic_lde(n, air="ecdsa")
+    for g, e in zip(per, exp_per):
+        assert stark.tensor_to_felts(g) == e
+    rng = random.Random(42)
+    alphas = [rng.randrange(P) for _ in range(S.N_ECDSA_CONSTRAINTS)]
+    comp = stark.air_eval(stark.lde(trace), per, n, alphas, air="ecdsa")
+    assert stark.tensor_to_felts(comp) == S.composition_on_coset([S.lde(c) for c in exp], exp_per, n, alphas, air="ecdsa")
+    proof = stark.prove_ecdsa(zs, rs, ss, pubs, n_queries=2, seed=9)
+    ok, why = S.verify_proof(proof)
+    assert ok, why
+    bad = copy.deepcopy(proof)
+    bad["public_inputs"][1] ^= 1          # another r: the transcript (hence every challenge) changes
+    assert not S.verify_proof(bad)[0]
+    bad = copy.deepcopy(proof)
+    bad["queries"][0]["trace"][0]["values"][9] ^= 1
+    assert not S.verify_proof(bad)[0]
+
+
+def test_ecdsa_air_proves_4096_verifications(stark):
+    """2^12 signatures = 2^22 trace rows x 10 columns proved on the GPU, verified on the CPU (C-oracle hash)."""
+    from oracle import cref
+    zs, rs, ss, pubs = _signatures(4096, 43)
+    proof = stark.prove_ecdsa(zs, rs, ss, pubs, n_queries=3, seed=2)
+    assert proof["n"] == 1 << 22 and len(proof["layer_roots"]) == 18
+    ok, why = S.verify_proof(proof, hash2=lambda a, b: cref.pedersen_hash_many([a], [b])[0][0])
+    assert ok, why
+    # a corrupted signature has no valid witness: the final layer stops being low degree
+    ss_bad = list(ss)
+    ss_bad[7] = (ss_bad[7] + 1) % R.EC_ORDER
+    bad = stark.prove_ecdsa(zs[:8], rs[:8], ss_bad[:8], pubs[:8], n_queries=1, seed=2)
+    assert S.verify_proof(bad) == (False, "final layer degree")

@@ -119,3 +119,41 @@ def test_ec_ladder_air_trace_and_degree():
     bad[6][10] = (bad[6][10] + 1) % P
     comp_bad = S.composition_on_coset([S.lde(c) for c in bad], per_lde, n, alphas, air="ec_ladder")
     assert not S.poly_degree_bound_check(comp_bad, S.GEN, 3 * n - 1)
+
+
+def test_ecdsa_air_trace_and_degree():
+    """The ECDSA-verification AIR (three linked ladders, signature.py:217-260): every constraint vanishes
+    on the witness of signatures the reference accepts, the composition has degree < 3n, and tampering with
+    the link between the ladders (B), with r, or with a carry is caught."""
+    rng = random.Random(18)
+    insts = []
+    for _ in range(2):
+        d = rng.randrange(1, R.EC_ORDER)
+        z = rng.randrange(1, 2**251)
+        r, s = R.sign(z, d)
+        insts.append(S.ecdsa_instance(z, r, s, R.private_key_to_ec_point_on_stark_curve(d)))
+    cols = S.ecdsa_trace(insts)
+    n = len(cols[0])
+    assert n == 2048 and len(cols) == 10
+    per = S.ecdsa_periodic_columns()
+    for i in range(n):
+        vals = S.ecdsa_constraint_values([c[i] for c in cols], [c[(i + 1) % n] for c in cols], [t[i % 1024] for t in per])
+        assert all(v == 0 for v in vals), (i, [k for k, v in enumerate(vals) if v])
+    # the third ladder's base point is zG + rQ, its output minus the shift point has x = r
+    z, r, w, q = insts[0]
+    b = R.ec_add(R.mimic_ec_mult_air(z, R.EC_GEN, R.MINUS_SHIFT_POINT), R.mimic_ec_mult_air(r, q, R.SHIFT_POINT))
+    assert (cols[3][512], cols[4][512]) == b
+    assert R.ec_add((cols[1][767], cols[2][767]), R.MINUS_SHIFT_POINT)[0] == r
+    alphas = [rng.randrange(P) for _ in range(S.N_ECDSA_CONSTRAINTS)]
+    per_lde = S.periodic_lde(n, air="ecdsa")
+    comp = S.composition_on_coset([S.lde(c) for c in cols], per_lde, n, alphas, air="ecdsa")
+    assert S.poly_degree_bound_check(comp, S.GEN, 3 * n - 1)
+    for col, row in ((3, 512), (9, 600), (7, 300), (0, 256)):
+        bad = [list(c) for c in cols]
+        bad[col][row] = (bad[col][row] + 1) % P
+        comp_bad = S.composition_on_coset([S.lde(c) for c in bad], per_lde, n, alphas, air="ecdsa")
+        assert not S.poly_degree_bound_check(comp_bad, S.GEN, 3 * n - 1), (col, row)
+    # a signature the reference rejects has no instance
+    import pytest
+    with pytest.raises(AssertionError):
+        S.ecdsa_instance(z + 1, insts[0][1], R.sign(z, 5)[1], q)
