@@ -33,6 +33,14 @@
 
 namespace sp {
 
+// Threads per block of the verification kernels: 256 = one wave per SIMD of a CU.  With 128-thread blocks
+// the dispatcher packed two blocks onto the same SIMD pair of half the CUs for a 2^16-signature batch
+// (3.1 ms; 2^15: 1.8 ms, 2^17: 3.7 ms) - the batch of BASELINE.json configs[2] ran at half speed.
+#ifndef SP_VERIFY_TPB
+#define SP_VERIFY_TPB 256
+#endif
+constexpr int VERIFY_TPB = SP_VERIFY_TPB;
+
 // k * EC_GEN from the window table; k < 2^252.  Infinity (only for k == 0 mod N) shows as ZZ == 0.
 __device__ __forceinline__ xyzz gen_mul(u256 k, const aff_packed* __restrict__ gen, int wbits, int nwin) {
   const size_t per = (size_t)1 << wbits;
@@ -88,7 +96,7 @@ __device__ __forceinline__ uint8_t verify_prepare(const uint64_t* __restrict__ p
                                                   verify_scalars& v) {
   const u256 z = ld_u256(pz + 4 * e), r = ld_u256(pr + 4 * e), s = ld_u256(ps + 4 * e);
   if (u256_is_zero(s) || !u256_lt(s, U256_N)) return SP_VERIFY_ASSERT_S;  // :219
-  const fe w_m = fn_inv(montn_of(s));
+  const fe w_m = fn_inv_var(montn_of(s));  // s is public: variable-time divsteps
   const u256 w = fe_pack(fn_from_mont(w_m));
   if (u256_is_zero(r) || !u256_lt(r, U256_2P251)) return SP_VERIFY_ASSERT_R;  // :225
   if (u256_is_zero(w) || !u256_lt(w, U256_2P251)) return SP_VERIFY_ASSERT_W;  // :226
@@ -251,7 +259,7 @@ __device__ __forceinline__ uint8_t key_model(const uint64_t* __restrict__ pqx, c
   return VERIFY_CONTINUE;
 }
 
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(VERIFY_TPB)
 ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr,
                     const uint64_t* __restrict__ ps, const uint64_t* __restrict__ pqx,
                     const uint64_t* __restrict__ pqy, uint8_t* __restrict__ result, size_t n,
@@ -478,7 +486,7 @@ __device__ __forceinline__ jac comb_mul(const u256& u2, const aff_packed* __rest
   return B;
 }
 
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(VERIFY_TPB)
 ecdsa_verify_keyed_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr,
                           const uint64_t* __restrict__ ps, const uint32_t* __restrict__ slots,
                           uint8_t* __restrict__ result, size_t n, const aff_packed* __restrict__ gen,
@@ -692,7 +700,7 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
   // per-signature table of the eight odd multiples of the key: 8 x 27 limbs, limb-major
   DeviceBuffer& tab = g_verify_tab[(hipStream_t)stream];
   SP_HIP(tab.reserve(n * 8 * 27 * sizeof(int32_t)));
-  hipLaunchKernelGGL(ecdsa_verify_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z, r,
+  hipLaunchKernelGGL(ecdsa_verify_kernel, dim3(nblocks(n, VERIFY_TPB)), dim3(VERIFY_TPB), 0, (hipStream_t)stream, z, r,
                      s, qx, qy, result, n, c.gen, c.wbits, c.nwin, (int32_t*)tab.ptr);
   SP_HIP(hipGetLastError());
   return SP_OK;
@@ -836,7 +844,7 @@ int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64
   Context& c = ctx();
   ctx_lock lk(c.mu);
   if (g_keys.capacity == 0) { set_error("no key has been registered"); return SP_ERR_BAD_ARGUMENT; }
-  hipLaunchKernelGGL(ecdsa_verify_keyed_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z,
+  hipLaunchKernelGGL(ecdsa_verify_keyed_kernel, dim3(nblocks(n, VERIFY_TPB)), dim3(VERIFY_TPB), 0, (hipStream_t)stream, z,
                      r, s, slots, result, n, c.gen, c.wbits, c.nwin, (const aff_packed*)g_keys.tab.ptr,
                      (const uint64_t*)g_keys.c.ptr, (const uint8_t*)g_keys.flag.ptr, (uint32_t)g_keys.used,
                      g_keys.generation);

@@ -771,6 +771,43 @@ SP_HD fe fn_inv(const fe& a) {
   return fn_mul(r, FN_R3);
 }
 
+// Variable-time twin of fn_inv for PUBLIC scalars (w = s^-1 of a signature being verified): the same
+// divsteps_29_var batches as fe_inv_plain_gcd_var, transition matrices applied modulo N.
+SP_HD fe fn_inv_var(const fe& a) {
+  const fe x = fn_canon(fn_mul(a, FN_ONE_M));
+  fe d = FE_ZERO, e = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+  fe f = FN_N, g = x;
+  int32_t eta = -1;
+  for (int it = 0; it < 26; ++it) {
+    trans2x2 t;
+    eta = divsteps_29_var(eta, (uint32_t)f.l[0], (uint32_t)g.l[0], t);
+    gcd_update_de_n(d, e, t);
+    gcd_update_fg(f, g, t);
+    int32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) nz |= g.l[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__all(nz == 0)) break;
+#else
+    if (nz == 0) break;
+#endif
+  }
+  const int32_t sf = f.l[NL - 1] >> 31;
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = (d.l[i] ^ sf) - sf;
+  r = fe_carry(r);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    if (r.l[8] < 0) r = fe_carry(fe_add(r, FN_N));
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (limbs_geq(r, FN_N)) r = fe_carry(fe_sub(r, FN_N));
+  }
+  return fn_mul(r, FN_R3);
+}
+
 // a^(N-2) by square-and-multiply over the bits of N-2 (kept as a cross-check of fn_inv).
 SP_HD fe fn_inv_fermat(const fe& a) {
   // N - 2 limbs: N_LIMB with limb0 - 2 (0xdc64d2f - 2 = 0xdc64d2d, no borrow)

@@ -201,3 +201,13 @@ def test_fe_half(shim):
     for a, b in pairs:
         shim.t_fe_half(W(a), W(b), out)
         assert I(out) == (a - b) * inv2 % P, (hex(a), hex(b))
+
+
+def test_fn_inv_variable_time(shim):
+    """fn_inv_var: the mod-N inversion of verification (public scalars) in its variable-time form."""
+    rng = random.Random(13)
+    out = (ctypes.c_uint32 * 8)()
+    vals = [1, 2, 3, N - 1, N - 2, 2**251, 2**250 + 1, (N + 1) // 2] + [rng.randrange(1, N) for _ in range(2000)]
+    for a in vals:
+        shim.t_fn_inv_var(W(a), out)
+        assert I(out) == pow(a, -1, N), hex(a)
