@@ -201,3 +201,46 @@ def test_library_tree_rejects_bad_input_and_keeps_its_state():
     assert t.root == before and t.get(5) == 0
     assert lib.sp_tree_update(12345, keys, _lib.pack_felts([1]), 1, old, new, st) < 0  # unknown handle
     t.close()
+
+
+def test_library_tree_large_batches_and_table_growth():
+    """Device-resident tree at the sizes of BASELINE configs[2] and beyond: batches of 3000-5000 leaves at
+    height 64 (several 1024-node tiles per level in the structure kernel, the hash table growing and
+    rehashing twice), dense runs of adjacent keys (pairs that are both new), overwrites, then a failed
+    update in the middle - against the Python tree with the optimised C comparator's hash."""
+    import random
+    from oracle import cref
+    from starkperp import state
+
+    def oracle_hash_many(xs, ys):
+        return cref.opt_pedersen_hash_many(list(xs), list(ys))[0]
+
+    rng = random.Random(23)
+    lib_tree = state.LibrarySparseTree(64, 0)
+    ref_tree = state.SparseMerkleTree(64, 0, hash_many=oracle_hash_many)
+    known = []
+    for r, n in enumerate((3000, 5000, 4096, 700)):
+        mods = {}
+        base = rng.randrange(2**63)
+        for i in range(n):
+            c = rng.random()
+            if known and c < 0.2:
+                k = rng.choice(known)
+            elif c < 0.5:
+                k = base + i                                   # a dense run: siblings inside the batch
+            else:
+                k = rng.randrange(2**64)
+            mods[k] = rng.randrange(P)
+        known += list(mods)
+        assert lib_tree.update(mods) == ref_tree.update(mods), r
+        probe = rng.sample(known, 50) + [rng.randrange(2**64)]
+        assert lib_tree.get_many(probe) == ref_tree.get_many(probe)
+        if r == 1:  # an update that fails leaves every level untouched
+            root = lib_tree.root
+            import numpy as np
+            from starkperp import batch_np as bn
+            bad = {**{rng.randrange(2**64): rng.randrange(P) for _ in range(2000)}, 12345: P}  # one leaf == p
+            with pytest.raises(AssertionError):  # detected by the hash kernel on the device, 64 levels later
+                lib_tree.update_arrays(np.array(list(bad), dtype=np.uint64), bn.felts_from_ints(list(bad.values())))
+            assert lib_tree.root == root and lib_tree.get_many(probe) == ref_tree.get_many(probe)
+    lib_tree.close()
