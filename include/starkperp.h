@@ -145,13 +145,13 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
                               const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n,
                               void* stream);
 /* Key tables - the same verify() for public keys that are seen again (an exchange's accounts):
- * a registered key owns a 128-entry signed comb table (8 KiB) in HBM that replaces the 252 doublings
+ * a registered key owns four 128-entry signed comb tables (32 KiB, on Q, 2^8 Q, 2^16 Q, 2^24 Q) in HBM that replace the 252 doublings
  * + 63 additions of the per-signature ladder by 31 doublings + 32 mixed additions.  Results are
  * identical to sp_ecdsa_verify_batch for every input (same pre-asserts, same False cases).
  *   sp_ecdsa_register_keys  host pointers; qy == NULL registers x-only keys; equal keys share a
  *                           slot; slots[i] receives the slot of key i; invalid keys get a slot too
  *                           (their verifications return False / SP_VERIFY_ASSERT_CURVE as before);
- *                           SP_ERR_CACHE_FULL when no slot is free (capacity: 2^17 keys = 1 GiB, or
+ *                           SP_ERR_CACHE_FULL when no slot is free (capacity: 2^17 keys = 4 GiB, or
  *                           STARKPERP_KEY_CACHE_SLOTS), in which case nothing is registered.
  *   sp_ecdsa_verify_keyed_dev  device pointers; slots[i] names the key of signature i.
  *   sp_ecdsa_verify_batch_keyed  host pointers: registers what is new, then verifies.

@@ -288,7 +288,8 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
 // The ladder above spends 252 doublings + 63 additions per signature on u2 * Q because Q is new to
 // it every time.  Exchange traffic is not like that: the same accounts sign again and again
 // (BASELINE.json configs[2]: 4096 orders from 1024 keys).  With 288 GB of HBM a signed comb table per
-// key is cheap - 128 affine points, 8 KiB - and turns u2 * Q into 31 doublings + 32 mixed additions:
+// key is cheap - COMB_TABLES x 128 affine points, 32 KiB - and turns u2 * Q into 7 doublings + 31 mixed additions
+// (one table: 31 + 32):
 //   rows     Q_i = 2^(32 i) Q, i = 0..7          (the 256 signed bits of the recoding, 8 rows x 32 columns)
 //   entries  T[v] = Q_7 + sum_{i<7} (2 v_i - 1) Q_i,  v = 0..127   (row 7 carries the column's sign)
 //   column c of E = (k-1)/2 + 2^255: bit c of word i is row i; sign = row 7, index = rows 0..6
@@ -299,6 +300,13 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
 // the column addition detects Z3 == 0 and takes the doubling / infinity branch explicitly.
 constexpr int COMB_ENTRIES = 128;
 constexpr int COMB_ROW_POINTS = 15;  // Q_0, 2Q_0, Q_1, 2Q_1, ..., Q_6, 2Q_6, Q_7
+// COMB_TABLES tables per key (round 2): table t is the same 128-entry signed comb built on 2^(t * COMB_COLS) Q and
+// serves the columns t * COMB_COLS .. (t + 1) * COMB_COLS - 1 of the recoded scalar, so u2 * Q costs
+// COMB_COLS - 1 = 7 doublings + 32 mixed additions instead of 31 + 32 - HBM is plentiful: 32 KiB per key.
+constexpr int COMB_TABLES = 4;
+constexpr int COMB_COLS = 32 / COMB_TABLES;
+constexpr int KEY_ENTRIES = COMB_TABLES * COMB_ENTRIES;
+constexpr int KEY_ROW_POINTS = COMB_TABLES * COMB_ROW_POINTS;
 // A slot handle is (generation << 24) | index: sp_ecdsa_key_cache_reset starts a new generation, so a
 // handle from before the reset can never name another key's table - the kernel answers
 // SP_VERIFY_STALE_SLOT for it.  Generations run 1..255 and wrap (a handle would have to survive 255
@@ -348,27 +356,39 @@ key_rows_kernel(const uint64_t* __restrict__ pqx, const uint64_t* __restrict__ p
     }
     run = fe_mul(run, P.Z);
   };
-  for (int i = 0; i < 8; ++i) {
-    emit(2 * i);
-    if (i == 7) break;
-    P = jac_dbl(P, a_coef);
-    emit(2 * i + 1);
-    for (int j = 1; j < 32; ++j) P = jac_dbl(P, a_coef);
+  // one doubling chain 2^d base, d = 0 .. 224 + (COMB_TABLES - 1) COMB_COLS: table t, row i needs
+  // Q_{t,i} = 2^(32 i + t COMB_COLS) base (point 2 i of the table) and, for i < 7, its double (point 2 i + 1)
+  const int last = 224 + (COMB_TABLES - 1) * COMB_COLS;
+  for (int d = 0; d <= last; ++d) {
+    const int i = d >> 5, off = d & 31;
+    if (off % COMB_COLS == 0 && off / COMB_COLS < COMB_TABLES) emit((off / COMB_COLS) * COMB_ROW_POINTS + 2 * i);
+    if (i < 7 && off % COMB_COLS == 1 && (off - 1) / COMB_COLS < COMB_TABLES)
+      emit(((off - 1) / COMB_COLS) * COMB_ROW_POINTS + 2 * i + 1);
+    if (d < last) P = jac_dbl(P, a_coef);
   }
   fe inv = fe_inv(run);
-  for (int point = COMB_ROW_POINTS - 1; point >= 0; --point) {
-    fe X, Y, Z, pre;
+  // undo the prefix products in reverse order of emission
+  for (int d = last; d >= 0; --d) {
+    const int i = d >> 5, off = d & 31;
+    int pts[2], np = 0;
+    if (off % COMB_COLS == 0 && off / COMB_COLS < COMB_TABLES) pts[np++] = (off / COMB_COLS) * COMB_ROW_POINTS + 2 * i;
+    if (i < 7 && off % COMB_COLS == 1 && (off - 1) / COMB_COLS < COMB_TABLES)
+      pts[np++] = ((off - 1) / COMB_COLS) * COMB_ROW_POINTS + 2 * i + 1;
+    for (int k = np - 1; k >= 0; --k) {
+      const int point = pts[k];
+      fe X, Y, Z, pre;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      X.l[l] = *plane(point, l);
-      Y.l[l] = *plane(point, 9 + l);
-      Z.l[l] = *plane(point, 18 + l);
-      pre.l[l] = *plane(point, 27 + l);
+      for (int l = 0; l < NL; ++l) {
+        X.l[l] = *plane(point, l);
+        Y.l[l] = *plane(point, 9 + l);
+        Z.l[l] = *plane(point, 18 + l);
+        pre.l[l] = *plane(point, 27 + l);
+      }
+      const fe zinv = fe_mul(inv, pre);
+      inv = fe_mul(inv, Z);
+      const fe zi2 = fe_sqr(zinv);
+      st_aff(rows + e * KEY_ROW_POINTS + point, fe_mul(X, zi2), fe_mul(Y, fe_mul(zi2, zinv)));
     }
-    const fe zinv = fe_mul(inv, pre);
-    inv = fe_mul(inv, Z);
-    const fe zi2 = fe_sqr(zinv);
-    st_aff(rows + e * COMB_ROW_POINTS + point, fe_mul(X, zi2), fe_mul(Y, fe_mul(zi2, zinv)));
   }
   key_flag[slot] = point_key ? KEY_POINT : KEY_XONLY;
 }
@@ -382,15 +402,16 @@ key_table_kernel(const aff_packed* __restrict__ rows, const uint32_t* __restrict
                  int32_t* __restrict__ work) {
   size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int t = (int)(gt & 3);
-  if ((gt >> 2) >= n_new) gt = ((n_new - 1) << 2) | (size_t)t;  // redundant copy, see ecdsa_verify_kernel
-  const size_t e = gt >> 2;
+  const size_t lanes = 4 * COMB_TABLES * n_new;
+  if (gt >= lanes) gt = (lanes - 4) | (size_t)t;  // redundant copy, see ecdsa_verify_kernel
+  const int tb = (int)((gt >> 2) % COMB_TABLES);  // which of the key's tables
+  const size_t e = (gt >> 2) / COMB_TABLES;
   const uint32_t slot = slot_of[e];
   const uint8_t flag = key_flag[slot];
   if (flag != KEY_XONLY && flag != KEY_POINT) return;
-  const size_t lanes = 4 * n_new;
   auto plane = [&](int entry, int limb) -> int32_t* { return work + ((size_t)(entry * 45 + limb) * lanes + gt); };
   auto row_point = [&](int point, bool negative) {
-    aff q = ld_aff(rows + e * COMB_ROW_POINTS + point);
+    aff q = ld_aff(rows + e * KEY_ROW_POINTS + tb * COMB_ROW_POINTS + point);
     if (negative) q.y = fe_neg(q.y);
     return q;
   };
@@ -433,7 +454,7 @@ key_table_kernel(const aff_packed* __restrict__ rows, const uint32_t* __restrict
     }
     const fe izzz = fe_mul(inv, pre);
     inv = fe_mul(inv, ZZZ);
-    st_aff(key_tab + (size_t)slot * COMB_ENTRIES + ((t << 5) | entry),
+    st_aff(key_tab + (size_t)slot * KEY_ENTRIES + tb * COMB_ENTRIES + ((t << 5) | entry),
            fe_mul(X, fe_sqr(fe_mul(ZZ, izzz))), fe_mul(Y, izzz));
     if (g > 0) gray ^= 1u << (__ffs(g) - 1);
   }
@@ -459,9 +480,12 @@ __device__ __forceinline__ jac jac_madd_complete(const jac& p, const aff& q, con
   return r;
 }
 
-__device__ __forceinline__ jac comb_mul(const u256& u2, const aff_packed* __restrict__ tab, const fe& a_coef) {
-  bool flip;
-  const u256 E = recode_odd(u2, flip);
+// COMPLETE = false: plain mixed additions; an exceptional column (accumulator == +-entry, possible only
+// for a chosen u2 = N - 2|t| of a table multiple t) drives Z to 0 and Z stays 0 to the end, where the
+// caller reruns the scalar with COMPLETE = true (the zero test costs a reduction + canonical form per
+// column: 8 k of the 150 k instructions of a keyed verification when done on every column).
+template <bool COMPLETE>
+__device__ __forceinline__ jac comb_mul_impl(const u256& E, bool flip, const aff_packed* __restrict__ tab, const fe& a_coef) {
   auto column = [&](int col, bool& negative) -> const aff_packed* {
     uint32_t idx = 0;
 #pragma unroll
@@ -470,19 +494,37 @@ __device__ __forceinline__ jac comb_mul(const u256& u2, const aff_packed* __rest
     if (negative) idx ^= 127u;
     return tab + idx;
   };
+  // column c = tb * COMB_COLS + j lives in table tb: sum_j 2^j (sum_tb T_tb[column]) - Horner over j.  Steps are
+  // numbered k = 0 .. 31 (j = COMB_COLS - 1 - k / COMB_TABLES, tb = COMB_TABLES - 1 - k % COMB_TABLES); the entry of
+  // step k + 1 is requested before step k is added (a lone wave has nothing else to hide the gather behind).
+  auto step_entry = [&](int k, bool& negative) -> const aff_packed* {
+    const int j = COMB_COLS - 1 - k / COMB_TABLES, tb = COMB_TABLES - 1 - k % COMB_TABLES;
+    return column(tb * COMB_COLS + j, negative) + tb * COMB_ENTRIES;
+  };
   bool neg;
-  aff q = ld_aff(column(31, neg));  // bit 255 of E is always set: the top column is +T
+  aff q = ld_aff(step_entry(0, neg));  // column 31: bit 255 of E is always set, this entry is +T
   jac B;
   B.X = q.x; B.Y = q.y; B.Z = FE_ONE_M;
-  aff nxt = ld_aff(column(30, neg));
-  for (int col = 30; col >= 0; --col) {
+  aff nxt = ld_aff(step_entry(1, neg));
+#pragma unroll 1
+  for (int k = 1; k < 32; ++k) {
     q = nxt;
     if (neg) q.y = fe_neg(q.y);
-    if (col > 0) nxt = ld_aff(column(col - 1, neg));
-    B = jac_dbl(B, a_coef);
-    B = jac_madd_complete(B, q, a_coef);
+    if (k + 1 < 32) nxt = ld_aff(step_entry(k + 1, neg));
+    if (k % COMB_TABLES == 0) B = jac_dbl(B, a_coef);
+    B = COMPLETE ? jac_madd_complete(B, q, a_coef) : jac_madd(B, q);
   }
   if (flip) B.Y = fe_neg(B.Y);
+  return B;
+}
+__device__ __forceinline__ jac comb_mul(const u256& u2, const aff_packed* __restrict__ tab, const fe& a_coef) {
+  bool flip;
+  const u256 E = recode_odd(u2, flip);
+  jac B = comb_mul_impl<false>(E, flip, tab, a_coef);
+  if (__any(fe_is_zero(B.Z))) {  // wave-uniform branch: some lane met an exceptional column (or infinity)
+    const jac C = comb_mul_impl<true>(E, flip, tab, a_coef);
+    B = C;
+  }
   return B;
 }
 
@@ -513,7 +555,7 @@ ecdsa_verify_keyed_kernel(const uint64_t* __restrict__ pz, const uint64_t* __res
     c = fe_unpack(ld_u256(key_c + 4 * (size_t)slot));
     a_coef = fe_sqr(c);
   }
-  const jac B = comb_mul(v.u2, key_tab + (size_t)slot * COMB_ENTRIES, a_coef);
+  const jac B = comb_mul(v.u2, key_tab + (size_t)slot * KEY_ENTRIES, a_coef);
   const xyzz A = gen_mul(v.u1, gen, wbits, nwin);
   result[e] = verify_finish(A, B, c, has_y, v.r);
 }
@@ -728,13 +770,13 @@ static int stage_in(const uint64_t* const* host, int count, size_t n, uint64_t**
 
 static int key_cache_ready() {
   if (g_keys.capacity) return SP_OK;
-  size_t cap = (size_t)1 << 17;  // 128 Ki keys = 1 GiB of tables
+  size_t cap = (size_t)1 << 17;  // 128 Ki keys x 4 tables x 8 KiB = 4 GiB of tables
   if (const char* env = getenv("STARKPERP_KEY_CACHE_SLOTS")) {
     const long long v = atoll(env);
     if (v > 0) cap = (size_t)v;
   }
   if (cap > SLOT_INDEX_MASK) cap = SLOT_INDEX_MASK;  // a slot handle carries 24 index bits
-  SP_HIP(g_keys.tab.reserve(cap * COMB_ENTRIES * sizeof(aff_packed)));
+  SP_HIP(g_keys.tab.reserve(cap * KEY_ENTRIES * sizeof(aff_packed)));
   SP_HIP(g_keys.c.reserve(cap * 32));
   SP_HIP(g_keys.flag.reserve(cap));
   SP_HIP(hipMemset(g_keys.flag.ptr, 0, cap));
@@ -748,13 +790,13 @@ static int build_key_tables(const std::vector<uint64_t>& qx, const std::vector<u
                             const std::vector<uint8_t>& has_y, const std::vector<uint32_t>& slots) {
   const size_t m = slots.size();
   if (m == 0) return SP_OK;
-  const size_t chunk_max = (size_t)1 << 15;  // bounds the scratch: 92 KiB of work planes per key
+  const size_t chunk_max = (size_t)1 << 13;  // bounds the scratch: 4 x 92 KiB of work planes per key
   for (size_t first = 0; first < m; first += chunk_max) {
     const size_t cnt = m - first < chunk_max ? m - first : chunk_max;
     const size_t fb = cnt * 32;
-    const size_t rows_b = cnt * COMB_ROW_POINTS * sizeof(aff_packed);
-    const size_t work1 = cnt * COMB_ROW_POINTS * 36 * sizeof(int32_t);
-    const size_t work2 = cnt * 4 * 32 * 45 * sizeof(int32_t);
+    const size_t rows_b = cnt * KEY_ROW_POINTS * sizeof(aff_packed);
+    const size_t work1 = cnt * KEY_ROW_POINTS * 36 * sizeof(int32_t);
+    const size_t work2 = cnt * COMB_TABLES * 4 * 32 * 45 * sizeof(int32_t);
     const size_t work_b = work1 > work2 ? work1 : work2;
     SP_HIP(g_keys.stage.reserve(2 * fb + cnt + cnt * 4 + rows_b + work_b + 1024));
     char* b = (char*)g_keys.stage.ptr;
@@ -770,7 +812,7 @@ static int build_key_tables(const std::vector<uint64_t>& qx, const std::vector<u
     SP_HIP(hipMemcpy(d_hasy, has_y.data() + first, cnt, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(key_rows_kernel, dim3(nblocks(cnt, 64)), dim3(64), 0, 0, d_qx, d_qy, d_hasy, d_slot,
                        cnt, (uint64_t*)g_keys.c.ptr, (uint8_t*)g_keys.flag.ptr, d_rows, d_work);
-    hipLaunchKernelGGL(key_table_kernel, dim3(nblocks(4 * cnt, 64)), dim3(64), 0, 0, d_rows, d_slot, cnt,
+    hipLaunchKernelGGL(key_table_kernel, dim3(nblocks(4 * COMB_TABLES * cnt, 64)), dim3(64), 0, 0, d_rows, d_slot, cnt,
                        (const uint8_t*)g_keys.flag.ptr, (aff_packed*)g_keys.tab.ptr, d_work);
     SP_HIP(hipGetLastError());
     SP_HIP(hipDeviceSynchronize());
