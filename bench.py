@@ -424,7 +424,10 @@ def main():
             "avg_launch_us": avg_launch_s * 1e6,
             "timing": "HIP events around every ped_accumulate_kernel launch inside the timed region, on the "
                       "stream it is launched on (sp_profile_begin/_end)",
-            "traffic": pmc_traffic("sp::ped_accumulate_kernel", config_key),
+            "traffic": (pmc_traffic("sp::ped_accumulate_kernel", config_key) or {}).get("bytes_per_launch"),
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE); algorithmic: %d" % int(
+                ALGO_BYTES_PER_HASH * hashes_per_launch),
+            "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", config_key),
             "hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hbm_gbs / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_hash": ALGO_BYTES_PER_HASH,
@@ -599,7 +602,8 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
                 peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value),
                 hashes_in_timed_launches=int(k_units.value), avg_launch_us=avg_launch_s * 1e6,
                 timing="HIP events around every ped_accumulate_kernel launch inside the timed region",
-                traffic=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
+                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)) or {}).get("bytes_per_launch"),
+                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
                 hbm={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS}),
             "cpu_baseline": (cpu_airfri_baseline(10) if (world == 1 and not args.no_cpu_baseline) else None),
@@ -686,7 +690,8 @@ def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, tr
                 or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None},
                 kernel="ped_accumulate_kernel (row chains and commit-tree levels above 65 536 hashes)",
                 peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value), avg_launch_us=avg_launch_s * 1e6,
-                traffic=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
+                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)) or {}).get("bytes_per_launch"),
+                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
                 hbm={"bound": "hbm", "achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}),
             "cpu_baseline": None,
@@ -801,7 +806,8 @@ def airfri_object(torch, lib, _lib, dev, with_cpu):
     roof.update({"kernel": "ped_accumulate_kernel (row chains and the tree levels above 65 536 hashes: %.0f %% of the "
                            "job's hashes)" % (100.0 * k_units.value / (3.0 * hashes)),
                  "launches": int(k_launches.value), "avg_launch_us": (k_ms.value / n_l) * 1e3,
-                 "traffic": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
+                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)) or {}).get("bytes_per_launch"),
+                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
                  "hbm": {"achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}})
     out["roofline"] = roof
