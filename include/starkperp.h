@@ -68,7 +68,8 @@ extern "C" {
 /* ---- lifecycle ---------------------------------------------------------------------------- */
 /* Selects the HIP device and builds the window tables of the Pedersen constant points
  * (signature.py:43 CONSTANT_POINTS; table structure nothing_up_my_sleeve_gen.py:88-90) and of
- * EC_GEN (signature.py:56) in HBM.  window_bits = 0 picks the default (21: 3 x 12 x 2^21 x 64 B = 4.5 GiB of tables).  Idempotent. */
+ * EC_GEN (signature.py:56) in HBM.  window_bits = 0 picks the default (21: 2^20 + 22 x 2^21 Pedersen entries + 12 x 2^21
+ * EC_GEN entries, 64 B each = 4.3 GiB of tables).  Idempotent. */
 int sp_init(int device, int window_bits);
 void sp_shutdown(void);
 const char* sp_last_error(void);
