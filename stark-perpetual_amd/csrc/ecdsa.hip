@@ -168,6 +168,9 @@ __device__ __forceinline__ jac ladder_mul(const u256& u2, const aff& base, const
     for (int i = 7; i > 0; --i) E.w[i] = (E.w[i] << 4) | (E.w[i - 1] >> 28);
     E.w[0] <<= 4;
   }
+  // The loop body is kept to ONE doubling + ONE addition of code (~40 KB): with the four doublings unrolled the
+  // body outgrows the 64 KB instruction cache and a lone wave per SIMD waits on instruction fetch.
+#pragma unroll 1
   for (int wi = 0; wi < 63; ++wi) {
     const uint32_t ew = E.w[7] >> 28;
 #pragma unroll
@@ -183,8 +186,8 @@ __device__ __forceinline__ jac ladder_mul(const u256& u2, const aff& base, const
       T.Y.l[l] = d < 0 ? -y : y;
       T.Z.l[l] = *tab_at(mag, 18 + l);
     }
-    B = jac_dbl(jac_dbl(B, a_coef), a_coef);
-    B = jac_dbl(jac_dbl(B, a_coef), a_coef);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) B = jac_dbl(B, a_coef);
     B = jac_add(B, T);
   }
   if (flip) B.Y = fe_neg(B.Y);
@@ -238,6 +241,20 @@ __device__ __forceinline__ uint8_t verify_finish(const xyzz& A, const jac& B, co
 // c = x^3 + x + beta the multiples of (x, sqrt c) are rational points of
 // y'^2 = x'^3 + c^2 x' + beta c^3 (x' = c x, y' = c^2 b); base = (c x, c^2);
 // c a non-residue -> SP_VERIFY_FALSE (InvalidPublicKeyError, signature.py:232-235).
+//
+// CHECK_QR = false (the ladder kernel): the Legendre test (~310 field multiplications) is left to
+// verify_finish, whose x-only acceptance test E^2 == 4 ya^2 t^2 c can only hold for a residue c:
+//   * ya != 0 and A != infinity: A = u1 G with u1 = z w != 0 mod N (z, w in [1, N), N prime) on a curve of
+//     odd prime order - no point with y = 0;
+//   * the model of a non-residue c is the quadratic twist, of order 2 p + 2 - N, odd as well: t = 0 only at
+//     infinity, and every exceptional case of the incomplete ladder formulas (a base point of small order
+//     on the twist can reach them) ends with Z = 0, which is absorbing (Z3 = Z1 Z2 H, resp. 2 Y1 Z1) and
+//     answers False at the D == 0 guard;
+//   * with ya t != 0 the equality gives c = (E / (2 ya t))^2, a residue.
+// So a non-residue c always ends in SP_VERIFY_FALSE, which is the reference's answer for it
+// (InvalidPublicKeyError -> False, signature.py:232-235); dx == 0 cannot occur either (an x that is on the
+// curve and on its twist has c = 0, excluded above).
+template <bool CHECK_QR = true>
 __device__ __forceinline__ uint8_t key_model(const uint64_t* __restrict__ pqx, const uint64_t* __restrict__ pqy,
                                              size_t e, aff& base, fe& c, fe& a_coef) {
   const fe qx = mont_of(reduce_mod_p(ld_u256(pqx + 4 * e)));
@@ -251,7 +268,8 @@ __device__ __forceinline__ uint8_t key_model(const uint64_t* __restrict__ pqx, c
     base.y = qy;
   } else {
     c = rhs;
-    if (fe_is_zero(c) || !fe_is_qr(c)) return SP_VERIFY_FALSE;
+    if (fe_is_zero(c)) return SP_VERIFY_FALSE;
+    if (CHECK_QR && !fe_is_qr(c)) return SP_VERIFY_FALSE;
     a_coef = fe_sqr(c);
     base.x = fe_mul(c, qx);
     base.y = a_coef;
@@ -274,7 +292,7 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
   if (code != VERIFY_CONTINUE) { result[e] = code; return; }
   aff base;
   fe c, a_coef;
-  code = key_model(pqx, pqy, e, base, c, a_coef);
+  code = key_model<false>(pqx, pqy, e, base, c, a_coef);
   if (code != VERIFY_CONTINUE) { result[e] = code; return; }
   if (v.z_zero) { result[e] = SP_VERIFY_FALSE; return; }
   const jac B = ladder_mul(v.u2, base, a_coef, tab, n, e);

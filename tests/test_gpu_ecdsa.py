@@ -233,6 +233,29 @@ def test_verify_random_differential(batch):
             assert code == oracle_verdict(*c), c
 
 
+def test_xonly_keys_off_the_curve_are_false(batch):
+    """x-only keys whose x^3 + x + beta is a non-residue (the reference: InvalidPublicKeyError -> False,
+    signature.py:232-235).  The ladder kernel has no Legendre test of its own - its acceptance identity cannot
+    hold on the twist (ecdsa.hip key_model) - so this is the case to pin."""
+    import random
+    rng = random.Random(77)
+    beta = R.BETA
+    xs = []
+    while len(xs) < 96:
+        x = rng.randrange(P)
+        if pow((x * x * x + x + beta) % P, (P - 1) // 2, P) == P - 1:
+            xs.append(x)
+    d = rng.randrange(1, N)
+    zs = [rng.randrange(1, 2**251) for _ in xs]
+    sigs = [R.sign(z, d) for z in zs]
+    codes = batch.verify_codes(zs, [r for r, _ in sigs], [s_ for _, s_ in sigs], xs)
+    assert codes == [0] * len(xs)
+    assert not any(R.verify(z, r, s_, x) for z, (r, s_), x in list(zip(zs, sigs, xs))[:8])
+    # the same signatures under the signer's own x are accepted
+    q = R.private_key_to_ec_point_on_stark_curve(d)
+    assert batch.verify_codes(zs, [r for r, _ in sigs], [s_ for _, s_ in sigs], [q[0]] * len(xs)) == [1] * len(xs)
+
+
 def test_verify_1024_vs_c_oracle(batch):
     """A thousand signatures (valid and corrupted) against the C oracle's three-ladder verify."""
     import random
