@@ -52,8 +52,15 @@ __device__ __forceinline__ xyzz gen_mul(u256 k, const aff_packed* __restrict__ g
     k.w[7] >>= wbits;
     return v;
   };
+  // the entry of window i + 1 is requested before window i is added: a lone wave per SIMD has nothing else to
+  // hide a random 64-byte gather (tables of tens of GiB: a TLB miss on most of them) behind
   xyzz acc = xyzz_from_aff(ld_aff(gen + pop()));
-  for (int i = 1; i < nwin; ++i) acc = xyzz_madd(acc, ld_aff(gen + (size_t)i * per + pop()));
+  aff nxt = nwin > 1 ? ld_aff(gen + per + pop()) : aff{};
+  for (int i = 1; i < nwin; ++i) {
+    const aff q = nxt;
+    if (i + 1 < nwin) nxt = ld_aff(gen + (size_t)(i + 1) * per + pop());
+    acc = xyzz_madd(acc, q);
+  }
   return acc;
 }
 
@@ -75,7 +82,7 @@ __device__ __forceinline__ fe mont_of(const u256& a) { return fe_to_mont(fe_unpa
 __device__ __forceinline__ fe montn_of(const u256& a) { return fn_to_mont(fe_unpack(a)); }
 
 // x(2A) for affine A (Montgomery form), rare path.
-__device__ __noinline__ fe double_x(const fe& xa, const fe& ya) {
+__device__ __forceinline__ fe double_x(const fe& xa, const fe& ya) {
   const fe xx = fe_sqr(xa);
   const fe num = fe_carry(fe_add(fe_carry(fe_add(fe_dbl(xx), xx)), FE_ONE_M));
   const fe lam = fe_mul(num, fe_inv(fe_carry(fe_dbl(ya))));
@@ -197,8 +204,18 @@ __device__ __forceinline__ jac ladder_mul(const u256& u2, const aff& base, const
 // Acceptance test for A = u1 G (XYZZ, real curve) and B = u2 Q (Jacobian; on the real curve for a
 // point key, c = 1, or on the c-twisted model for an x-only key): r == x(A + B), resp.
 // r in { x(A + B), x(A - B) } as one polynomial identity.
-__device__ __forceinline__ uint8_t verify_finish(const xyzz& A, const jac& B, const fe& c, bool has_y,
-                                                 const u256& r) {
+//
+// Affine form of the test (xa, ya the coordinates of A; xB = x(B), yB^2 = t^2 c, dx = xa - xB):
+//   E = (r + xa + xB) dx^2 - ya^2 - t^2 c;   x(A + B) == r  <=>  E == -2 ya yB;   x(A +- B) == r  <=>  E^2 == 4 ya^2 t^2 c.
+// verify_finish_affine evaluates it after one shared inversion (rare path: B == +-A needs the doubling);
+// verify_finish clears the denominators instead - a = ZZ_A, b = c Z_B^2:
+//   xa = X_A / a,  ya^2 = Y_A^2 / a^3 (ZZZ_A^2 = a^3),  xB = X_B / b,  t^2 c = Y_B^2 / b^3,  dx = Dn / (a b),
+//   En = a^3 b^3 E = (r a b + X_A b + X_B a) Dn^2 - Y_A^2 b^3 - Y_B^2 a^3
+//   x-only:  En^2 == 4 (Y_A^2 b^3)(Y_B^2 a^3);      point key (c = 1, b^3 = Z_B^6):  En == -2 (Y_A ZZZ_A)(Y_B Z_B b)
+// - 12 multiplications + 7 squarings and no inversion (the inversion was 10 k of the 131 k instructions
+// of a keyed verification).
+__device__ __forceinline__ uint8_t verify_finish_affine(const xyzz& A, const jac& B, const fe& c, bool has_y,
+                                                     const u256& r) {
   // one inversion for 1/ZZZ_A, 1/Z_B, 1/c
   const fe zc = fe_mul(B.Z, c);
   const fe D = fe_mul(A.ZZZ, zc);
@@ -232,6 +249,32 @@ __device__ __forceinline__ uint8_t verify_finish(const xyzz& A, const jac& B, co
       const fe rhs2 = fe_mul(fe_carry(fe_dbl(fe_carry(fe_dbl(fe_sqr(yat))))), c);  // 4 ya^2 t^2 c
       ok = fe_eq(fe_sqr(E), rhs2);
     }
+  }
+  return ok ? SP_VERIFY_TRUE : SP_VERIFY_FALSE;
+}
+
+__device__ __forceinline__ uint8_t verify_finish(const xyzz& A, const jac& B, const fe& c, bool has_y,
+                                                 const u256& r) {
+  const fe zb2 = fe_sqr(B.Z);
+  const fe b = fe_mul(zb2, c);
+  const fe& a = A.ZZ;
+  const fe xan = fe_mul(A.X, b), xbn = fe_mul(B.X, a);
+  const fe Dn = fe_carry(fe_sub(xan, xbn));
+  // infinity on either side (a b == 0; unreachable for A, the absorbing state of the ladder / comb for B) and
+  // B == +-A (Dn == 0) go through the affine form, which owns those cases
+  const fe ab = fe_mul(a, b);
+  if (fe_is_zero(ab) || fe_is_zero(Dn)) return verify_finish_affine(A, B, c, has_y, r);
+  const fe sum = fe_carry(fe_add(fe_add(fe_mul(mont_of(r), ab), xan), xbn));
+  const fe a3 = fe_sqr(A.ZZZ);
+  const fe b3 = fe_mul(fe_sqr(b), b);
+  const fe P = fe_mul(fe_sqr(A.Y), b3), Q = fe_mul(fe_sqr(B.Y), a3);
+  const fe En = fe_carry(fe_sub(fe_sub(fe_mul(sum, fe_sqr(Dn)), P), Q));
+  bool ok;
+  if (has_y) {
+    const fe rhs = fe_mul(fe_mul(A.Y, A.ZZZ), fe_mul(fe_mul(B.Y, B.Z), b));
+    ok = fe_eq(En, fe_carry(fe_neg(fe_dbl(rhs))));
+  } else {
+    ok = fe_eq(fe_sqr(En), fe_carry(fe_dbl(fe_carry(fe_dbl(fe_mul(P, Q))))));
   }
   return ok ? SP_VERIFY_TRUE : SP_VERIFY_FALSE;
 }
@@ -321,7 +364,10 @@ constexpr int COMB_ROW_POINTS = 15;  // Q_0, 2Q_0, Q_1, 2Q_1, ..., Q_6, 2Q_6, Q_
 // COMB_TABLES tables per key (round 2): table t is the same 128-entry signed comb built on 2^(t * COMB_COLS) Q and
 // serves the columns t * COMB_COLS .. (t + 1) * COMB_COLS - 1 of the recoded scalar, so u2 * Q costs
 // COMB_COLS - 1 = 7 doublings + 32 mixed additions instead of 31 + 32 - HBM is plentiful: 32 KiB per key.
-constexpr int COMB_TABLES = 4;
+#ifndef SP_COMB_TABLES
+#define SP_COMB_TABLES 4
+#endif
+constexpr int COMB_TABLES = SP_COMB_TABLES;
 constexpr int COMB_COLS = 32 / COMB_TABLES;
 constexpr int KEY_ENTRIES = COMB_TABLES * COMB_ENTRIES;
 constexpr int KEY_ROW_POINTS = COMB_TABLES * COMB_ROW_POINTS;

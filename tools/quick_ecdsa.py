@@ -1,50 +1,59 @@
 #!/usr/bin/env python3
-"""Ad-hoc ECDSA throughput (development aid)."""
-import os, sys, time, random, ctypes
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "stark-perpetual_amd"))
+"""Device-resident ECDSA verification rates at one batch size (default 2^16, the size bench.py quotes):
+per-signature ladder (x-only keys) and per-key comb tables.  `python tools/quick_ecdsa.py [log_n] [iters]`"""
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stark-perpetual_amd"))
+import numpy as np
 import torch
 from starkperp import _lib, batch, stark
 
-N = batch.EC_ORDER
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 16
-rng = random.Random(1)
-ds = [rng.randrange(1, N) for _ in range(n)]
-zs = [rng.randrange(2**251) for _ in range(n)]
-ks = [rng.randrange(1, N) for _ in range(n)]
-t0 = time.time(); pubs = batch.public_keys_many(ds); t1 = time.time()
-print("public keys: %.3f s host-inclusive (%d)" % (t1 - t0, n))
-t0 = time.time(); rs, ss, st = batch.sign_attempt_many(zs, ds, ks); t1 = time.time()
-print("sign attempts: %.3f s host-inclusive, ok=%d" % (t1 - t0, st.count(0)))
-lib = _lib.ensure_init()
-dz, dr, dss = (stark.felts_to_tensor(v) for v in (zs, rs, ss))
-qx = stark.felts_to_tensor([p[0] for p in pubs]); qy = stark.felts_to_tensor([p[1] for p in pubs])
-res = torch.zeros(n, dtype=torch.uint8, device="cuda")
-s = torch.cuda.current_stream().cuda_stream
-for name, py in (("x-only", None), ("point", qy.data_ptr())):
-    for _ in range(2):
-        torch.cuda.synchronize(); t0 = time.time()
-        _lib.check(lib.sp_ecdsa_verify_batch_dev(dz.data_ptr(), dr.data_ptr(), dss.data_ptr(), qx.data_ptr(), py, res.data_ptr(), n, s), "verify")
-        torch.cuda.synchronize(); t1 = time.time()
-    ok = int((res == 1).sum())
-    print("verify %s: %.3f ms -> %.3e verifies/s (true=%d of %d signed ok=%d)" % (name, (t1 - t0) * 1e3, n / (t1 - t0), ok, n, st.count(0)))
 
-# key tables: registration cost and warm verification rate
-import numpy as np
-for label, keyset in (("x-only", [p[0] for p in pubs]), ("point", pubs)):
+def main():
+    log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    lib = _lib.ensure_init()
+    dev = "cuda"
+    stream = torch.cuda.current_stream().cuda_stream
+    nv = 1 << log_n
+    rng = random.Random(21)
+    dsk = [rng.randrange(1, batch.EC_ORDER) for _ in range(nv)]
+    zv = [rng.randrange(2**251) for _ in range(nv)]
+    kv = [rng.randrange(1, batch.EC_ORDER) for _ in range(nv)]
+    pv = batch.public_keys_many(dsk)
+    rv, sv, stv = batch.sign_attempt_many(zv, dsk, kv)
+    dz, dr, dsig, dq = (stark.felts_to_tensor(v, dev) for v in (zv, rv, sv, [q[0] for q in pv]))
+    res = torch.zeros(nv, dtype=torch.uint8, device=dev)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters / 1e3
+
+    t = timed(lambda: _lib.check(lib.sp_ecdsa_verify_batch_dev(
+        dz.data_ptr(), dr.data_ptr(), dsig.data_ptr(), dq.data_ptr(), None, res.data_ptr(), nv, stream), "verify"))
+    ok = int((res == 1).sum()) == stv.count(0)
+    print("ladder  n=2^%d  %.1f us  %.3e /s  all_true=%s" % (log_n, t * 1e6, nv / t, ok))
     batch.key_cache_reset()
-    t0 = time.time(); slots = batch.register_keys(keyset); t1 = time.time()
-    print("register %d %s keys: %.1f ms host-inclusive (%.3e keys/s)" % (n, label, (t1 - t0) * 1e3, n / (t1 - t0)))
-    dslots = torch.from_numpy(np.asarray(slots, dtype=np.uint32).view(np.int32)).cuda()
-    for _ in range(3):
-        torch.cuda.synchronize(); t0 = time.time()
-        _lib.check(lib.sp_ecdsa_verify_keyed_dev(dz.data_ptr(), dr.data_ptr(), dss.data_ptr(), dslots.data_ptr(), res.data_ptr(), n, s), "keyed")
-        torch.cuda.synchronize(); t1 = time.time()
-    print("verify keyed %s: %.3f ms -> %.3e verifies/s (true=%d)" % (label, (t1 - t0) * 1e3, n / (t1 - t0), int((res == 1).sum())))
+    t0 = time.perf_counter()
+    slots = batch.register_keys([q[0] for q in pv])
+    t_reg = time.perf_counter() - t0
+    dslots = torch.from_numpy(np.asarray(slots, dtype=np.uint32).view(np.int32)).to(dev)
+    t = timed(lambda: _lib.check(lib.sp_ecdsa_verify_keyed_dev(
+        dz.data_ptr(), dr.data_ptr(), dsig.data_ptr(), dslots.data_ptr(), res.data_ptr(), nv, stream), "keyed"))
+    ok = int((res == 1).sum()) == stv.count(0)
+    print("keyed   n=2^%d  %.1f us  %.3e /s  all_true=%s   registration %.3e keys/s (host-inclusive)" % (
+        log_n, t * 1e6, nv / t, ok, nv / t_reg))
 
-# full signing (RFC 6979 nonce + attempt on the device) vs the host-nonce path on a sample
-t0 = time.time(); sigs = batch.sign_many(zs, ds); t1 = time.time()
-print("sign_many (device RFC 6979): %d in %.1f ms host-inclusive -> %.3e signatures/s" % (n, (t1 - t0) * 1e3, n / (t1 - t0)))
-m = min(n, 2048)
-t0 = time.time(); ref = batch._sign_many_host_nonces(zs[:m], ds[:m], [None] * m); t1 = time.time()
-print("host nonces: %d in %.1f ms -> %.3e signatures/s; equal=%s" % (m, (t1 - t0) * 1e3, m / (t1 - t0), ref == sigs[:m]))
+
+if __name__ == "__main__":
+    main()
