@@ -219,6 +219,16 @@ int sp_ec_ladder_trace_dev(const uint64_t* m, const uint64_t* qx, const uint64_t
 int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
                               const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out,
                               void* stream);
+/* Range-check AIR (what the Cairo range-check builtin asserts for every amount, position id, nonce and
+ * expiration of the exchange messages, e.g. signature_message_hashes.cairo:60-75 via assert_nn_le /
+ * the 2^64, 2^32 bounds of perpetual_messages.py:226-236): 0 <= value < 2^128 by bit decomposition,
+ * 128 rows of one column per value (col = 128 * n_values felts, v_i = value >> i), and its composition
+ * column (2 constraints, periodic_lde: 2 tables of 512 felts).  A value >= 2^128 gives a trace whose
+ * composition is not a polynomial: the proof fails at the verifier, nothing is rejected here. */
+int sp_range_check_trace_dev(const uint64_t* values, size_t n_values, uint64_t* col, void* stream);
+int sp_air_eval_range_check_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
+                                const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out,
+                                void* stream);
 /* ECDSA-verification AIR (what verify() mimics, signature.py:217-260): three linked EC ladders per
  * signature - z G from MINUS_SHIFT_POINT, r Q and w B from SHIFT_POINT with B = zG + rQ (:252-254) - and
  * x(wB - SHIFT_POINT) == r (:255); 1024 rows of ten columns m, px, py, qx, qy, la, ld, cx, cy, cr per

@@ -302,6 +302,34 @@ def ecdsa_constraint_values(cur, nxt, per):
     ]
 
 
+# ---- range-check AIR ------------------------------------------------------------------------------
+# 0 <= value < 2^128 by bit decomposition (the statement of the Cairo range-check builtin, which bounds the
+# amounts / ids / nonces / timestamps of the exchange messages: perpetual_messages.py:226-236 asserts the same
+# bounds on the Python side).  One column, 128 rows per value: v_i = value >> i.
+RANGE_CHECK_BITS = 128
+
+
+def range_check_trace(values):
+    col = []
+    for v in values:
+        col.extend(v >> i for i in range(RANGE_CHECK_BITS))
+    return [col]
+
+
+def range_check_periodic_columns():
+    return [[1] * 127 + [0], [0] * 127 + [1]]
+
+
+N_RANGE_CHECK_CONSTRAINTS = 2
+
+
+def range_check_constraint_values(cur, nxt, per):
+    v, vn = cur[0], nxt[0]
+    step, last = per
+    b = (v - 2 * vn) % P
+    return [step * b * (b - 1) % P, last * v * (v - 1) % P]
+
+
 AIRS = {
     "ecdsa": {"n_cols": 10, "period": 1024, "n_constraints": N_ECDSA_CONSTRAINTS,
               "periodic": ecdsa_periodic_columns, "constraints": ecdsa_constraint_values},
@@ -309,6 +337,8 @@ AIRS = {
                  "periodic": periodic_columns, "constraints": constraint_values},
     "ec_ladder": {"n_cols": 7, "period": 256, "n_constraints": N_EC_LADDER_CONSTRAINTS,
                   "periodic": ec_ladder_periodic_columns, "constraints": ec_ladder_constraint_values},
+    "range_check": {"n_cols": 1, "period": 128, "n_constraints": N_RANGE_CHECK_CONSTRAINTS,
+                    "periodic": range_check_periodic_columns, "constraints": range_check_constraint_values},
 }
 
 
@@ -423,6 +453,10 @@ def verify_proof(proof, hash2=R.pedersen_hash, final_log=6, air=None):
                 return False, "public inputs"
             if not 1 <= R.inv_mod_curve_size(sig_s) < 2**251:
                 return False, "public inputs"
+    if (air or proof.get("air")) == "range_check":
+        pub = proof.get("public_inputs", [])
+        if len(pub) != n // RANGE_CHECK_BITS or not all(0 <= v < 2**RANGE_CHECK_BITS for v in pub):
+            return False, "public inputs"
     m = BLOWUP * n
     log_m = m.bit_length() - 1
     root_t, roots, final = proof["trace_root"], proof["layer_roots"], proof["final_layer"]

@@ -690,6 +690,51 @@ air_eval_ec_ladder_kernel(const uint64_t* __restrict__ trace /* [7][M] plain */,
   st_u256(out + 4 * i, fe_pack(fe_canon(fe_mul(acc, prm.zinv[i & 3]))));
 }
 
+// ---- range-check AIR ------------------------------------------------------------------------------
+// What the Cairo range-check builtin asserts (0 <= value < 2^128, the bound every amount / position id /
+// nonce of the exchange messages goes through before it is packed) as a one-column AIR by bit
+// decomposition: 128 rows per value, v_i = value >> i, so that b_i = v_i - 2 v_{i+1} is the i-th bit.
+//   rows i mod 128 != 127 (selector `step`):  b (b - 1) = 0
+//   rows i mod 128 == 127 (selector `last`):  v (v - 1) = 0
+// oracle/stark_ref.py range_check_constraint_values is the definition.
+__global__ void __launch_bounds__(256)
+range_check_trace_kernel(const uint64_t* __restrict__ values, size_t n_values, uint64_t* __restrict__ col) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_values * 128) return;
+  const uint64_t* v = values + 4 * (i >> 7);
+  const unsigned sh = (unsigned)(i & 127), w = sh >> 6, b = sh & 63;
+  uint64_t o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned src = k + w;
+    const uint64_t lo = src < 4 ? v[src] : 0, hi = src + 1 < 4 ? v[src + 1] : 0;
+    o[k] = b ? (lo >> b) | (hi << (64 - b)) : lo;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) col[4 * i + k] = o[k];
+}
+
+struct RangeCheckAirParams {
+  fe alpha[2];  // Montgomery
+  fe zinv[4];   // R * Montgomery form of 1 / (x^n - 1) for i mod 4 (absorbs the one R the selectors leave)
+};
+
+// Plain operands, Montgomery constants (see the file comment).  per: step, last - 2 tables of 512 plain felts.
+__global__ void __launch_bounds__(256)
+air_eval_range_check_kernel(const uint64_t* __restrict__ trace /* [1][M] plain */, const uint64_t* __restrict__ per,
+                            size_t M, RangeCheckAirParams prm, uint64_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const fe v = ld_fe_packed(trace + 4 * i), v_n = ld_fe_packed(trace + 4 * ((i + 4) & (M - 1)));
+  const fe step = ld_fe_packed(per + 4 * (i & 511)), last = ld_fe_packed(per + 4 * (512 + (i & 511)));
+  const fe one = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+  const fe b = fe_carry(fe_sub(v, fe_dbl(v_n)));
+  const fe c0 = fe_mul(fe_to_mont(b), fe_carry(fe_sub(b, one)));
+  const fe c1 = fe_mul(fe_to_mont(v), fe_carry(fe_sub(v, one)));
+  const fe acc = fe_mul_add_mul(step, fe_mul(prm.alpha[0], c0), last, fe_mul(prm.alpha[1], c1));
+  st_u256(out + 4 * i, fe_pack(fe_canon(fe_mul(acc, prm.zinv[i & 3]))));
+}
+
 struct AirParams {
   fe alpha[11];  // Montgomery
   fe zinv[4];    // R * Montgomery form of 1 / (x^n - 1) for i mod 4 (absorbs the one R the selectors leave)
@@ -1116,6 +1161,48 @@ int sp_air_eval_ec_ladder_dev(const uint64_t* trace_lde, const uint64_t* periodi
   prm.shift_x = fe_unpack(PT_SHIFT_X);
   prm.shift_y = fe_unpack(PT_SHIFT_Y);
   hipLaunchKernelGGL(air_eval_ec_ladder_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, trace_lde, periodic_lde, M, prm, out);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_range_check_trace_dev(const uint64_t* values, size_t n_values, uint64_t* col, void* stream) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  if (n_values == 0) return SP_OK;
+  hipLaunchKernelGGL(range_check_trace_kernel, dim3((unsigned)((n_values * 128 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, values, n_values, col);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_air_eval_range_check_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
+                                const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out,
+                                void* stream) {
+  SP_REQUIRE_READY();
+  ctx_lock lk(ctx().mu);
+  if (log_n < 7 || log_n > 30) {
+    set_error("sp_air_eval_range_check_dev: log_n out of range (one value is 128 rows)");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  const size_t n = (size_t)1 << log_n, M = 4 * n;
+  RangeCheckAirParams prm;
+  for (int k = 0; k < 2; ++k) {
+    u256 a;
+    std::memcpy(a.w, alphas_host + 4 * k, 32);
+    prm.alpha[k] = fe_to_mont(fe_unpack(a));
+  }
+  u256 sh;
+  std::memcpy(sh.w, shift_host, 32);
+  fe sn = fe_to_mont(fe_unpack(sh));
+  for (unsigned i = 0; i < log_n; ++i) sn = fe_sqr(sn);
+  const fe w4 = h_root_of_unity(2);
+  fe wk = FE_ONE_M;
+  for (int k = 0; k < 4; ++k) {
+    prm.zinv[k] = fe_mul(fe_inv(fe_carry(fe_sub(fe_mul(sn, wk), FE_ONE_M))), FE_R2);  // zinv * R^2
+    wk = fe_mul(wk, w4);
+  }
+  hipLaunchKernelGGL(air_eval_range_check_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, trace_lde, periodic_lde, M, prm, out);
   SP_HIP(hipGetLastError());
   return SP_OK;

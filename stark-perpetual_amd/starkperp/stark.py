@@ -111,6 +111,13 @@ def ecdsa_periodic_columns():
             rows(lambda i: i == 256), rows(lambda i: 256 <= i < 767), rows(lambda i: i == 767)]
 
 
+def range_check_periodic_columns():
+    """step (rows 0..126 of every 128), last (row 127): oracle/stark_ref.py range_check_periodic_columns."""
+    return [[1] * 127 + [0], [0] * 127 + [1]]
+
+
+N_RANGE_CHECK_CONSTRAINTS = 2
+RANGE_CHECK_BITS = 128
 N_EC_LADDER_CONSTRAINTS = 12
 N_ECDSA_CONSTRAINTS = 26
 EC_ORDER = 0x800000000000010FFFFFFFFFFFFFFFFB781126DCAE7B2321E66A241ADC64D2F
@@ -121,6 +128,8 @@ AIRS = {
                  "eval": "sp_air_eval_dev"},
     "ec_ladder": {"n_cols": 7, "period": 256, "n_constraints": N_EC_LADDER_CONSTRAINTS,
                   "periodic": ec_ladder_periodic_columns, "eval": "sp_air_eval_ec_ladder_dev"},
+    "range_check": {"n_cols": 1, "period": 128, "n_constraints": N_RANGE_CHECK_CONSTRAINTS,
+                    "periodic": range_check_periodic_columns, "eval": "sp_air_eval_range_check_dev"},
 }
 
 
@@ -167,6 +176,17 @@ def ecdsa_trace(zs, rs, ws, qxs, qys):
     _lib.check(lib.sp_ecdsa_trace_dev(zs.data_ptr(), rs.data_ptr(), ws.data_ptr(), qxs.data_ptr(), qys.data_ptr(), k,
                                       cols.data_ptr(), _stream()), "sp_ecdsa_trace_dev")
     return cols
+
+
+def range_check_trace(values):
+    """values: [k, 4] device tensor -> [1, 128 k, 4] witness of the range-check AIR (v_i = value >> i)."""
+    torch = _torch()
+    lib = _lib.ensure_init()
+    k = values.shape[0]
+    col = torch.empty((1, RANGE_CHECK_BITS * k, 4), dtype=torch.int64, device=values.device)
+    _lib.check(lib.sp_range_check_trace_dev(values.data_ptr(), k, col.data_ptr(), _stream()),
+               "sp_range_check_trace_dev")
+    return col
 
 
 def fri_fold(layer, beta, shift):
@@ -286,6 +306,18 @@ def prove_ecdsa(msg_hashes, rs, ss, public_keys, n_queries: int = 8, seed: int =
                                                           [q[1] for q in public_keys])))
     public = [v for z, r, s, q in zip(msg_hashes, rs, ss, public_keys) for v in (z, r, s, q[0], q[1])]
     return prove_trace(trace, "ecdsa", n_queries, seed, final_log, shift, public)
+
+
+def prove_range_checks(values, n_queries: int = 8, seed: int = 0, final_log: int = 6, shift: int = FIELD_GEN):
+    """Benchmark-grade argument (NOT a sound proof system) that every value lies in [0, 2^128) - the bound
+    the Cairo range-check builtin gives the amounts, ids, nonces and timestamps of the exchange messages.
+    Python ints in; the count must be a power of two.  The values are absorbed as public inputs."""
+    values = list(values)
+    assert values and len(values) & (len(values) - 1) == 0
+    for v in values:
+        assert 0 <= v < FIELD_PRIME
+    return prove_trace(range_check_trace(felts_to_tensor(values, "cuda")), "range_check", n_queries, seed, final_log,
+                       shift, values)
 
 
 def prove_trace(trace, air: str, n_queries: int = 8, seed: int = 0, final_log: int = 6,

@@ -121,6 +121,32 @@ def test_ec_ladder_air_trace_and_degree():
     assert not S.poly_degree_bound_check(comp_bad, S.GEN, 3 * n - 1)
 
 
+def test_range_check_air_trace_and_degree():
+    """0 <= value < 2^128 by bit decomposition: constraints vanish on honest traces (edge values included), the
+    composition has degree < 3n, and a value of 2^128 (or a flipped cell) breaks it."""
+    rng = random.Random(12)
+    values = [0, 1, 2**128 - 1, 2**64, rng.randrange(2**128), rng.randrange(2**64), rng.randrange(2**32), 2**127]
+    cols = S.range_check_trace(values)
+    n = len(cols[0])
+    assert n == 1024 and [cols[0][128 * k] for k in range(8)] == values
+    per = S.range_check_periodic_columns()
+    for i in range(n):
+        vals = S.range_check_constraint_values([cols[0][i]], [cols[0][(i + 1) % n]], [t[i % 128] for t in per])
+        assert vals == [0, 0], (i, vals)
+    alphas = [rng.randrange(P) for _ in range(S.N_RANGE_CHECK_CONSTRAINTS)]
+    per_lde = S.periodic_lde(n, air="range_check")
+    comp = S.composition_on_coset([S.lde(c) for c in cols], per_lde, n, alphas, air="range_check")
+    assert S.poly_degree_bound_check(comp, S.GEN, 3 * n - 1)
+    for bad_values in ([2**128] + values[1:], values[:3] + [2**200] + values[4:]):
+        bad = S.range_check_trace(bad_values)
+        comp_bad = S.composition_on_coset([S.lde(c) for c in bad], per_lde, n, alphas, air="range_check")
+        assert not S.poly_degree_bound_check(comp_bad, S.GEN, 3 * n - 1)
+    flipped = [list(cols[0])]
+    flipped[0][300] ^= 2
+    comp_bad = S.composition_on_coset([S.lde(c) for c in flipped], per_lde, n, alphas, air="range_check")
+    assert not S.poly_degree_bound_check(comp_bad, S.GEN, 3 * n - 1)
+
+
 def test_ecdsa_air_trace_and_degree():
     """The ECDSA-verification AIR (three linked ladders, signature.py:217-260): every constraint vanishes
     on the witness of signatures the reference accepts, the composition has degree < 3n, and tampering with
