@@ -146,8 +146,8 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
                               const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n,
                               void* stream);
 /* Key tables - the same verify() for public keys that are seen again (an exchange's accounts):
- * a registered key owns four 128-entry signed comb tables (32 KiB, on Q, 2^8 Q, 2^16 Q, 2^24 Q) in HBM that replace the 252 doublings
- * + 63 additions of the per-signature ladder by 31 doublings + 32 mixed additions.  Results are
+ * a registered key owns four 128-entry signed comb tables (32 KiB, on Q, 2^8 Q, 2^16 Q, 2^24 Q) in HBM that
+ * replace the 252 doublings + 63 additions of the per-signature ladder by 7 doublings + 31 mixed additions.  Results are
  * identical to sp_ecdsa_verify_batch for every input (same pre-asserts, same False cases).
  *   sp_ecdsa_register_keys  host pointers; qy == NULL registers x-only keys; equal keys share a
  *                           slot; slots[i] receives the slot of key i; invalid keys get a slot too
@@ -159,7 +159,19 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
  * sp_ecdsa_verify_batch itself switches to the tables when at most 40 % of a batch's signatures bring
  * a key the library has never met (not registered, not seen in an earlier call, not repeated inside the
  * batch) - so a caller verifying one signature at a time reaches the tables on the second sighting of
- * a key.  STARKPERP_VERIFY_KEYED=0 / 1 forces the ladder / the tables. */
+ * a key.  That default (SP_VERIFY_POLICY_AUTO) makes sp_ecdsa_verify_batch remember keys between calls and
+ * allocate the key cache on first use; sp_ecdsa_set_verify_policy chooses otherwise for the whole process:
+ *   SP_VERIFY_POLICY_LADDER  sp_ecdsa_verify_batch never looks at, fills or allocates the key cache - the
+ *                            stateless-after-init function of the reference; tables only through the
+ *                            explicit calls above; selecting it also forgets the keys seen so far;
+ *   SP_VERIFY_POLICY_KEYED   always through the tables (falls back to the ladder only when the cache is full).
+ * STARKPERP_VERIFY_KEYED=0 / 1 in the environment selects LADDER / KEYED as the initial policy.  The verdicts do
+ * not depend on the policy. */
+#define SP_VERIFY_POLICY_AUTO 0
+#define SP_VERIFY_POLICY_LADDER 1
+#define SP_VERIFY_POLICY_KEYED 2
+int sp_ecdsa_set_verify_policy(int policy);
+int sp_ecdsa_get_verify_policy(void);
 int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uint32_t* slots);
 int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                               const uint32_t* slots, uint8_t* result, size_t n, void* stream);

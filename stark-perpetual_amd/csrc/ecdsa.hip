@@ -965,9 +965,16 @@ int sp_ecdsa_verify_keyed_dev(const uint64_t* z, const uint64_t* r, const uint64
 // key), or when it repeats inside the batch; the tables are used when at most 40 % of the batch's
 // signatures bring a key that is none of these.  STARKPERP_VERIFY_KEYED=0 / 1 forces the ladder /
 // the tables.
+static int initial_verify_policy() {
+  const char* mode = getenv("STARKPERP_VERIFY_KEYED");
+  if (mode && mode[0] == '0') return SP_VERIFY_POLICY_LADDER;
+  if (mode && mode[0] == '1') return SP_VERIFY_POLICY_KEYED;
+  return SP_VERIFY_POLICY_AUTO;
+}
+static int g_verify_policy = initial_verify_policy();  // read and written under the context lock
+
 static bool use_key_tables(const uint64_t* qx, const uint64_t* qy, size_t n) {
-  static const char* mode = getenv("STARKPERP_VERIFY_KEYED");
-  if (mode && mode[0] == '0') return false;
+  if (g_verify_policy == SP_VERIFY_POLICY_LADDER) return false;  // nothing remembered, nothing allocated
   if (key_cache_ready() != SP_OK) return false;
   std::unordered_map<KeyId, int, KeyIdHash> fresh;  // unregistered keys of this batch -> occurrences
   for (size_t i = 0; i < n; ++i) {
@@ -981,8 +988,24 @@ static bool use_key_tables(const uint64_t* qx, const uint64_t* qy, size_t n) {
   if (g_seen_keys.size() > ((size_t)1 << 20)) g_seen_keys.clear();
   for (const auto& kv : fresh) g_seen_keys.emplace(kv.first, 1);
   if (g_keys.used + fresh.size() > g_keys.capacity) return false;
-  if (mode && mode[0] == '1') return true;
+  if (g_verify_policy == SP_VERIFY_POLICY_KEYED) return true;
   return first_sightings * 5 <= n * 2;
+}
+
+int sp_ecdsa_set_verify_policy(int policy) {
+  if (policy != SP_VERIFY_POLICY_AUTO && policy != SP_VERIFY_POLICY_LADDER && policy != SP_VERIFY_POLICY_KEYED) {
+    set_error("sp_ecdsa_set_verify_policy: unknown policy");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  ctx_lock lk(ctx().mu);
+  g_verify_policy = policy;
+  if (policy == SP_VERIFY_POLICY_LADDER) g_seen_keys.clear();
+  return SP_OK;
+}
+
+int sp_ecdsa_get_verify_policy(void) {
+  ctx_lock lk(ctx().mu);
+  return g_verify_policy;
 }
 
 // Host-pointer verification through the key tables: registers the keys it has not seen, then runs

@@ -62,6 +62,8 @@ _SIGNATURES = {
                                               ctypes.c_void_p, ctypes.c_void_p]),
     "sp_air_eval_ec_ladder_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_ecdsa_set_verify_policy": (ctypes.c_int, [ctypes.c_int]),
+    "sp_ecdsa_get_verify_policy": (ctypes.c_int, []),
     "sp_range_check_trace_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_air_eval_range_check_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -275,6 +275,19 @@ def key_cache_reset():
     _lib.check(_lib.ensure_init().sp_ecdsa_key_cache_reset(), "sp_ecdsa_key_cache_reset")
 
 
+VERIFY_POLICY_AUTO, VERIFY_POLICY_LADDER, VERIFY_POLICY_KEYED = 0, 1, 2
+
+
+def set_verify_policy(policy: int):
+    """How verify_many / sp_ecdsa_verify_batch choose between the per-signature ladder and the key tables
+    (include/starkperp.h): AUTO remembers keys between calls, LADDER is stateless, KEYED always registers."""
+    _lib.check(_lib.ensure_init().sp_ecdsa_set_verify_policy(int(policy)), "sp_ecdsa_set_verify_policy")
+
+
+def get_verify_policy() -> int:
+    return int(_lib.ensure_init().sp_ecdsa_get_verify_policy())
+
+
 def raise_for_verify_code(code, msg_hash, r, s):
     """Re-creates the reference's assertion (text included) for a pre-assert code."""
     if code == VERIFY_ASSERT_S:

@@ -137,6 +137,42 @@ def test_invalid_keys_and_cache_bookkeeping(batch):
     assert batch.verify_codes([z], [r], [s], [q[0]], key_tables=True) == [1]
 
 
+def test_verify_policy_is_explicit(batch):
+    """sp_ecdsa_set_verify_policy: LADDER makes sp_ecdsa_verify_batch stateless (the key cache is never filled,
+    however often a key comes back), KEYED registers on first sight, AUTO on the second; same verdicts."""
+    import random
+    rng = random.Random(6)
+    ds = [rng.randrange(1, N) for _ in range(8)]
+    zs = [rng.randrange(2**251) for _ in ds]
+    sigs = [R.sign(z, d) for z, d in zip(zs, ds)]
+    rs, ss = [a for a, _ in sigs], [b for _, b in sigs]
+    ss[3] = ss[3] % (N - 1) + 1
+    keys = [R.private_key_to_ec_point_on_stark_curve(d)[0] for d in ds]
+    want = [1, 1, 1, 0, 1, 1, 1, 1]
+    assert batch.get_verify_policy() == batch.VERIFY_POLICY_AUTO
+    try:
+        batch.key_cache_reset()
+        batch.set_verify_policy(batch.VERIFY_POLICY_LADDER)
+        for _ in range(3):
+            assert batch.verify_codes(zs, rs, ss, keys) == want
+        assert batch.key_cache_info()[1] == 0
+        batch.set_verify_policy(batch.VERIFY_POLICY_KEYED)
+        assert batch.verify_codes(zs, rs, ss, keys) == want
+        assert batch.key_cache_info()[1] == 8
+        batch.key_cache_reset()
+        batch.set_verify_policy(batch.VERIFY_POLICY_LADDER)      # also forgets which keys were seen
+        batch.set_verify_policy(batch.VERIFY_POLICY_AUTO)
+        assert batch.verify_codes(zs, rs, ss, keys) == want      # first sighting: ladder
+        assert batch.key_cache_info()[1] == 0
+        assert batch.verify_codes(zs, rs, ss, keys) == want      # seen before: tables
+        assert batch.key_cache_info()[1] == 8
+        with pytest.raises(Exception):
+            batch.set_verify_policy(7)
+    finally:
+        batch.set_verify_policy(batch.VERIFY_POLICY_AUTO)
+        batch.key_cache_reset()
+
+
 def test_stale_and_foreign_slot_handles_are_refused(batch):
     """A slot handle carries the cache generation: after sp_ecdsa_key_cache_reset an old handle must not
     verify against whatever key took its index, and an x-only registration does not alias a
