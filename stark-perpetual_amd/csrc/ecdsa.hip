@@ -54,9 +54,19 @@ __device__ __forceinline__ xyzz gen_mul(u256 k, const aff_packed* __restrict__ g
   };
   // the entry of window i + 1 is requested before window i is added: a lone wave per SIMD has nothing else to
   // hide a random 64-byte gather (tables of tens of GiB: a TLB miss on most of them) behind
-  xyzz acc = xyzz_from_aff(ld_aff(gen + pop()));
+  const aff e0 = ld_aff(gen + pop());
   aff nxt = nwin > 1 ? ld_aff(gen + per + pop()) : aff{};
-  for (int i = 1; i < nwin; ++i) {
+  xyzz acc;
+  int first = 1;
+  if (nwin > 1) {  // windows 0 and 1 are both affine: mmadd (4M + 2S) instead of a mixed addition (8M + 2S)
+    const aff q1 = nxt;
+    if (2 < nwin) nxt = ld_aff(gen + (size_t)2 * per + pop());
+    acc = xyzz_mmadd(e0, q1);
+    first = 2;
+  } else {
+    acc = xyzz_from_aff(e0);
+  }
+  for (int i = first; i < nwin; ++i) {
     const aff q = nxt;
     if (i + 1 < nwin) nxt = ld_aff(gen + (size_t)(i + 1) * per + pop());
     acc = xyzz_madd(acc, q);

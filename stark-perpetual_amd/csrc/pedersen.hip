@@ -156,7 +156,7 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
   auto next_window = [&](int g) {  // consumes the next window of the string
     return window_entry(ped, g, pop_bits(str, window_width(g, w0, log2e)), w0, log2e);
   };
-  xyzz acc = xyzz_from_aff(unpack_raw(ld_raw(next_window(0).entry)));  // window 0 is never negative
+  const raw_aff e0 = ld_raw(next_window(0).entry);  // window 0 is never negative
   window_ref r1 = next_window(1 < nwin ? 1 : 0);
   raw_aff n1 = ld_raw(r1.entry);
   bool neg1 = r1.negative, neg2 = false;
@@ -166,7 +166,24 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
     n2 = ld_raw(r2.entry);
     neg2 = r2.negative;
   }
-  for (int i = 1; i + 1 < nwin; ++i) {
+  xyzz acc;
+  int first = 1;
+  if (nwin > 2) {
+    // windows 0 and 1 are both affine: 4M + 2S (mmadd) instead of the 8M + 2S of a mixed addition
+    const aff q1 = signed_aff(n1, neg1);
+    n1 = n2;
+    neg1 = neg2;
+    if (3 < nwin) {
+      const window_ref r = next_window(3);
+      n2 = ld_raw(r.entry);
+      neg2 = r.negative;
+    }
+    acc = xyzz_mmadd(unpack_raw(e0), q1);
+    first = 2;
+  } else {
+    acc = xyzz_from_aff(unpack_raw(e0));
+  }
+  for (int i = first; i + 1 < nwin; ++i) {
     const aff q = signed_aff(n1, neg1);
     n1 = n2;
     neg1 = neg2;
