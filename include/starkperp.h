@@ -20,9 +20,14 @@
  *   - Ownership: the library never keeps a caller pointer after a host-pointer call returns; a _dev
  *     call's buffers must stay valid until the work enqueued on its stream has completed.
  *   - Threading: every entry point may be called from any host thread.  One recursive lock
- *     serialises the host-side bookkeeping (and, for host-pointer calls, the whole staged
- *     round trip through the shared staging buffers); scratch, window tables of the verifier and
- *     NTT work columns are per stream, so _dev calls on different streams overlap on the device.
+ *     serialises the host-side bookkeeping; scratch, window tables of the verifier and NTT work
+ *     columns are per stream, so _dev calls on different streams overlap on the device.  The
+ *     host-pointer batches that carry no shared state - sp_pedersen_batch, sp_ecdsa_verify_batch
+ *     (per-signature ladder), sp_ecdsa_sign_batch, sp_ecdsa_sign_rfc6979_batch, sp_public_key_batch -
+ *     run on one of 8 host lanes (own stream, own staging buffer) and hold the lock only while a
+ *     kernel is enqueued: calls from different threads overlap on the device (a ninth concurrent
+ *     caller waits for a lane).  The other host-pointer calls (chains, trees, key registration and
+ *     keyed verification) hold the lock for their whole staged round trip.
  *     Each entry point binds the device given to sp_init for its duration and restores the calling
  *     thread's current HIP device on return.
  */

@@ -37,6 +37,55 @@ static std::string g_err;
 static std::mutex g_err_mu;
 
 Context& ctx() { return g_ctx; }
+
+static HostLane g_lanes[HOST_LANES];
+static std::mutex g_lane_mu;
+static std::condition_variable g_lane_cv;
+
+HostLane* lane_acquire() {
+  std::unique_lock<std::mutex> lk(g_lane_mu);
+  HostLane* lane = nullptr;
+  g_lane_cv.wait(lk, [&] {
+    for (HostLane& l : g_lanes) {
+      if (!l.busy) {
+        lane = &l;
+        return true;
+      }
+    }
+    return false;
+  });
+  if (!lane->stream) {
+    const hipError_t e = hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      lane->stream = nullptr;
+      (void)hip_fail(e, "hipStreamCreateWithFlags (host lane)");
+      return nullptr;
+    }
+  }
+  lane->busy = true;
+  return lane;
+}
+
+void lane_release(HostLane* lane) {
+  {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    lane->busy = false;
+  }
+  g_lane_cv.notify_one();
+}
+
+void release_host_lanes() {
+  std::lock_guard<std::mutex> lk(g_lane_mu);
+  for (HostLane& l : g_lanes) {
+    if (l.stream) {
+      (void)hipStreamSynchronize(l.stream);
+      (void)hipStreamDestroy(l.stream);
+      l.stream = nullptr;
+    }
+    l.io.release();
+    l.busy = false;
+  }
+}
 void set_error(const std::string& s) {
   std::lock_guard<std::mutex> lk(g_err_mu);
   g_err = s;
@@ -309,6 +358,7 @@ void sp_shutdown(void) {
   sp::release_stark_state();
   sp::release_ecdsa_state();
   sp::release_tree_state();
+  sp::release_host_lanes();
   if (g_ctx.ped) (void)hipFree(g_ctx.ped);
   if (g_ctx.gen) (void)hipFree(g_ctx.gen);
   if (g_ctx.d_plan) (void)hipFree(g_ctx.d_plan);

@@ -2,6 +2,7 @@
 // growable scratch.  One context per process (one process per GPU).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 
@@ -69,6 +70,32 @@ struct Context {
 using ctx_lock = std::lock_guard<std::recursive_mutex>;
 
 Context& ctx();
+
+// Host lanes: the host-pointer entry points that carry no shared state (hash / verify / sign / public-key
+// batches) each take one of HOST_LANES lanes - a non-blocking stream with its own staging buffer - so that
+// calls from different host threads overlap on the device instead of queueing behind one lock (the scalar
+// API of the reference is a stream of one-item calls: 0.1 - 0.4 ms of latency each, almost all of it idle
+// chip).  The context lock is then held only while a kernel is enqueued.  A caller blocks while every lane is
+// taken.
+constexpr int HOST_LANES = 8;
+struct HostLane {
+  hipStream_t stream = nullptr;
+  DeviceBuffer io;
+  bool busy = false;
+};
+HostLane* lane_acquire();         // nullptr: the stream could not be created (sp_last_error says why)
+void lane_release(HostLane* lane);
+void release_host_lanes();        // sp_shutdown
+struct LaneScope {
+  HostLane* lane;
+  LaneScope() : lane(lane_acquire()) {}
+  ~LaneScope() {
+    if (lane) lane_release(lane);
+  }
+  LaneScope(const LaneScope&) = delete;
+  LaneScope& operator=(const LaneScope&) = delete;
+};
+
 void set_error(const std::string& s);
 int hip_fail(hipError_t e, const char* what);
 

@@ -842,6 +842,24 @@ static int stage_in(const uint64_t* const* host, int count, size_t n, uint64_t**
   return SP_OK;
 }
 
+// The same on a host lane (context.hpp): the lane's own staging buffer, copies ordered on the lane's stream.
+static int stage_in_lane(HostLane& L, const uint64_t* const* host, int count, size_t n, uint64_t** dev, size_t extra,
+                         char** extra_ptr) {
+  const size_t fb = n * 32;
+  SP_HIP(L.io.reserve((size_t)count * fb + extra + 256));
+  char* base = (char*)L.io.ptr;
+  for (int i = 0; i < count; ++i) {
+    if (host[i]) {
+      dev[i] = (uint64_t*)(base + (size_t)i * fb);
+      SP_HIP(hipMemcpyAsync(dev[i], host[i], fb, hipMemcpyHostToDevice, L.stream));
+    } else {
+      dev[i] = nullptr;
+    }
+  }
+  *extra_ptr = base + (size_t)count * fb;
+  return SP_OK;
+}
+
 static int key_cache_ready() {
   if (g_keys.capacity) return SP_OK;
   size_t cap = (size_t)1 << 17;  // 128 Ki keys x 4 tables x 8 KiB = 4 GiB of tables
@@ -1047,17 +1065,22 @@ int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* 
                           const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
-  ctx_lock lk(ctx().mu);
-  if (use_key_tables(qx, qy, n)) return sp_ecdsa_verify_batch_keyed(z, r, s, qx, qy, result, n);
+  {
+    ctx_lock lk(ctx().mu);  // the policy reads and fills the key cache: shared state, one caller at a time
+    if (use_key_tables(qx, qy, n)) return sp_ecdsa_verify_batch_keyed(z, r, s, qx, qy, result, n);
+  }
+  LaneScope ls;  // the ladder carries no shared state: calls from different host threads overlap
+  if (!ls.lane) return SP_ERR_HIP;
+  HostLane& L = *ls.lane;
   const uint64_t* host[5] = {z, r, s, qx, qy};
   uint64_t* dev[5];
   char* extra;
-  int rc = stage_in(host, 5, n, dev, n, &extra);
+  int rc = stage_in_lane(L, host, 5, n, dev, n, &extra);
   if (rc != SP_OK) return rc;
-  rc = sp_ecdsa_verify_batch_dev(dev[0], dev[1], dev[2], dev[3], dev[4], (uint8_t*)extra, n, 0);
+  rc = sp_ecdsa_verify_batch_dev(dev[0], dev[1], dev[2], dev[3], dev[4], (uint8_t*)extra, n, L.stream);
   if (rc != SP_OK) return rc;
-  SP_HIP(hipDeviceSynchronize());
-  SP_HIP(hipMemcpy(result, extra, n, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpyAsync(result, extra, n, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }
 
@@ -1066,24 +1089,26 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
-  ctx_lock lk(c.mu);
+  LaneScope ls;
+  if (!ls.lane) return SP_ERR_HIP;
+  HostLane& L = *ls.lane;
   const uint64_t* host[3] = {z, d, k};
   uint64_t* dev[3];
   char* extra;
   const size_t fb = n * 32;
-  int rc = stage_in(host, 3, n, dev, 2 * fb + n, &extra);
+  int rc = stage_in_lane(L, host, 3, n, dev, 2 * fb + n, &extra);
   if (rc != SP_OK) return rc;
   uint64_t* dr = (uint64_t*)extra;
   uint64_t* ds = (uint64_t*)(extra + fb);
   uint8_t* dst = (uint8_t*)(extra + 2 * fb);
-  SP_HIP(hipMemset(dr, 0, 2 * fb));
-  hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(n, 128)), dim3(128), 0, 0, dev[0], dev[1], dev[2],
+  SP_HIP(hipMemsetAsync(dr, 0, 2 * fb, L.stream));
+  hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(n, 128)), dim3(128), 0, L.stream, dev[0], dev[1], dev[2],
                      dr, ds, dst, n, c.gen, c.wbits, c.nwin);
   SP_HIP(hipGetLastError());
-  SP_HIP(hipDeviceSynchronize());
-  SP_HIP(hipMemcpy(r, dr, fb, hipMemcpyDeviceToHost));
-  SP_HIP(hipMemcpy(s, ds, fb, hipMemcpyDeviceToHost));
-  SP_HIP(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpyAsync(r, dr, fb, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipMemcpyAsync(s, ds, fb, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }
 
@@ -1092,26 +1117,28 @@ int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
-  ctx_lock lk(c.mu);
+  LaneScope ls;
+  if (!ls.lane) return SP_ERR_HIP;
+  HostLane& L = *ls.lane;
   const uint64_t* host[2] = {z, d};
   uint64_t* dev[2];
   char* extra;
   const size_t fb = n * 32;
-  int rc = stage_in(host, 2, n, dev, 2 * fb + n * 8 + n + 64, &extra);
+  int rc = stage_in_lane(L, host, 2, n, dev, 2 * fb + n * 8 + n + 64, &extra);
   if (rc != SP_OK) return rc;
   uint64_t* dr = (uint64_t*)extra;
   uint64_t* ds = (uint64_t*)(extra + fb);
   uint64_t* dseed = (uint64_t*)(extra + 2 * fb);
   uint8_t* dst = (uint8_t*)(extra + 2 * fb + n * 8);
-  SP_HIP(hipMemset(dr, 0, 2 * fb));
-  if (seeds) SP_HIP(hipMemcpy(dseed, seeds, n * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n, 128)), dim3(128), 0, 0, dev[0], dev[1],
+  SP_HIP(hipMemsetAsync(dr, 0, 2 * fb, L.stream));
+  if (seeds) SP_HIP(hipMemcpyAsync(dseed, seeds, n * 8, hipMemcpyHostToDevice, L.stream));
+  hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n, 128)), dim3(128), 0, L.stream, dev[0], dev[1],
                      seeds ? dseed : nullptr, dr, ds, dst, n, c.gen, c.wbits, c.nwin);
   SP_HIP(hipGetLastError());
-  SP_HIP(hipDeviceSynchronize());
-  SP_HIP(hipMemcpy(r, dr, fb, hipMemcpyDeviceToHost));
-  SP_HIP(hipMemcpy(s, ds, fb, hipMemcpyDeviceToHost));
-  SP_HIP(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpyAsync(r, dr, fb, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipMemcpyAsync(s, ds, fb, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }
 
@@ -1119,24 +1146,26 @@ int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* 
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
-  ctx_lock lk(c.mu);
+  LaneScope ls;
+  if (!ls.lane) return SP_ERR_HIP;
+  HostLane& L = *ls.lane;
   const uint64_t* host[1] = {d};
   uint64_t* dev[1];
   char* extra;
   const size_t fb = n * 32;
-  int rc = stage_in(host, 1, n, dev, 2 * fb + n, &extra);
+  int rc = stage_in_lane(L, host, 1, n, dev, 2 * fb + n, &extra);
   if (rc != SP_OK) return rc;
   uint64_t* dx = (uint64_t*)extra;
   uint64_t* dy = (uint64_t*)(extra + fb);
   uint8_t* dst = (uint8_t*)(extra + 2 * fb);
-  SP_HIP(hipMemset(dx, 0, 2 * fb));
-  hipLaunchKernelGGL(public_key_kernel, dim3(nblocks(n, 128)), dim3(128), 0, 0, dev[0], dx, dy, dst, n,
+  SP_HIP(hipMemsetAsync(dx, 0, 2 * fb, L.stream));
+  hipLaunchKernelGGL(public_key_kernel, dim3(nblocks(n, 128)), dim3(128), 0, L.stream, dev[0], dx, dy, dst, n,
                      c.gen, c.wbits, c.nwin);
   SP_HIP(hipGetLastError());
-  SP_HIP(hipDeviceSynchronize());
-  SP_HIP(hipMemcpy(qx, dx, fb, hipMemcpyDeviceToHost));
-  if (qy) SP_HIP(hipMemcpy(qy, dy, fb, hipMemcpyDeviceToHost));
-  if (status) SP_HIP(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpyAsync(qx, dx, fb, hipMemcpyDeviceToHost, L.stream));
+  if (qy) SP_HIP(hipMemcpyAsync(qy, dy, fb, hipMemcpyDeviceToHost, L.stream));
+  if (status) SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }
 

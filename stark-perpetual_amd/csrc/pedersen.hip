@@ -682,23 +682,28 @@ int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
-  ctx_lock lk(c.mu);
+  LaneScope ls;  // calls from different host threads overlap on the device (context.hpp "Host lanes")
+  if (!ls.lane) return SP_ERR_HIP;
+  HostLane& L = *ls.lane;
   const size_t fb = n * 32;
-  SP_HIP(c.io.reserve(3 * fb + n + 64));
-  uint64_t* dx = (uint64_t*)c.io.ptr;
-  uint64_t* dy = (uint64_t*)((char*)c.io.ptr + fb);
-  uint64_t* dout = (uint64_t*)((char*)c.io.ptr + 2 * fb);
-  uint8_t* dst = (uint8_t*)c.io.ptr + 3 * fb;
-  SP_HIP(hipMemcpy(dx, x, fb, hipMemcpyHostToDevice));
-  SP_HIP(hipMemcpy(dy, y, fb, hipMemcpyHostToDevice));
-  Scratch s;
-  int rc = get_scratch(n, s, 0);
-  if (rc != SP_OK) return rc;
-  rc = enqueue_pedersen(dx, 1, dy, 1, dout, 1, dst, nullptr, n, 0, s, nullptr);
-  if (rc != SP_OK) return rc;
-  SP_HIP(hipDeviceSynchronize());
-  SP_HIP(hipMemcpy(out, dout, fb, hipMemcpyDeviceToHost));
-  if (status) SP_HIP(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
+  SP_HIP(L.io.reserve(3 * fb + n + 64));
+  uint64_t* dx = (uint64_t*)L.io.ptr;
+  uint64_t* dy = (uint64_t*)((char*)L.io.ptr + fb);
+  uint64_t* dout = (uint64_t*)((char*)L.io.ptr + 2 * fb);
+  uint8_t* dst = (uint8_t*)L.io.ptr + 3 * fb;
+  SP_HIP(hipMemcpyAsync(dx, x, fb, hipMemcpyHostToDevice, L.stream));
+  SP_HIP(hipMemcpyAsync(dy, y, fb, hipMemcpyHostToDevice, L.stream));
+  {
+    ctx_lock lk(c.mu);  // the per-stream scratch map and the launch bookkeeping
+    Scratch s;
+    int rc = get_scratch(n, s, L.stream);
+    if (rc != SP_OK) return rc;
+    rc = enqueue_pedersen(dx, 1, dy, 1, dout, 1, dst, nullptr, n, L.stream, s, nullptr);
+    if (rc != SP_OK) return rc;
+  }
+  SP_HIP(hipMemcpyAsync(out, dout, fb, hipMemcpyDeviceToHost, L.stream));
+  if (status) SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }
 
