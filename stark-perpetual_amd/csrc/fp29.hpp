@@ -315,26 +315,37 @@ SP_HD fe fe_mul3_add(const fe& a, const fe& b, const fe& c, const fe& d, const f
 // ---- canonical form ----
 // a in N-form with value in (-p, 2p)  ->  limbs of the unique representative in [0, p).
 SP_HD bool fe_geq_p_canon_limbs(const fe& a) {  // a has non-negative normalised limbs
-  // compare with p = (1,0,0,0,0,0,P6,0,P8) from the top limb down
-  if (a.l[8] != P8) return a.l[8] > P8;
-  if (a.l[7] != 0) return true;
-  if (a.l[6] != P6) return a.l[6] > P6;
-  if ((a.l[5] | a.l[4] | a.l[3] | a.l[2] | a.l[1]) != 0) return true;
-  return a.l[0] >= 1;
+  // compare with p = (1,0,0,0,0,0,P6,0,P8) from the top limb down - branch-free: the kernels call this once
+  // per stored felt and a chain of early returns became a chain of exec-mask regions
+  const bool gt8 = a.l[8] > P8, eq8 = a.l[8] == P8;
+  const bool gt6 = a.l[6] > P6, eq6 = a.l[6] == P6;
+  const bool low = (a.l[5] | a.l[4] | a.l[3] | a.l[2] | a.l[1]) != 0 || a.l[0] >= 1;
+  return gt8 | (eq8 & ((a.l[7] != 0) | gt6 | (eq6 & low)));
 }
+// Canonical form [0, p) of an N-form or lazy value (|limb 8| < 2^29).  One quotient estimate from the top
+// limb brings the value into (-p, 2p) (fe_weak_reduce), then ONE conditional + p and ONE conditional - p,
+// both as masked limb updates (p has three non-zero limbs): three carry chains and no branch, where the
+// round-1 version looped over "add p while negative, subtract p while >= p" with five.
 SP_HD fe fe_canon(const fe& a_in) {
-  fe a = fe_carry(a_in);
-  // make non-negative: add p while negative (at most once for the documented range; loop twice
-  // for safety), then subtract p while >= p (at most twice).
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    if (a.l[8] < 0) a = fe_carry(fe_add(a, FE_P));
+  fe a;
+  {
+    const int32_t q = a_in.l[8] >> 19;
+    a = a_in;
+    a.l[0] -= q;
+    a.l[6] -= q * P6;
+    a.l[8] -= q * P8;
+    a = fe_carry(a);  // value in (-p, 2p), limbs 0..7 normalised
   }
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    if (fe_geq_p_canon_limbs(a)) a = fe_carry(fe_sub(a, FE_P));
-  }
-  return a;
+  const int32_t neg = a.l[8] >> 31;  // all ones when negative
+  a.l[0] += neg & 1;
+  a.l[6] += neg & P6;
+  a.l[8] += neg & P8;
+  a = fe_carry(a);  // [0, 2p)
+  const int32_t ge = fe_geq_p_canon_limbs(a) ? -1 : 0;
+  a.l[0] -= ge & 1;
+  a.l[6] -= ge & P6;
+  a.l[8] -= ge & P8;
+  return fe_carry(a);
 }
 
 // Montgomery <-> plain.  to_mont input: canonical limbs of x (< p); output N-form of x*R.

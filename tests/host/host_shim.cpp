@@ -27,6 +27,12 @@ void t_fe_half(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   // half of (a - b) as plain integers: exercises negative and lazy inputs
   store_plain(fe_canon(fe_half(fe_sub(load_plain(a), load_plain(b)))), out);
 }
+// fe_canon on raw limbs (signed, possibly lazy: the caller builds N-form / lazy patterns directly)
+void t_fe_canon_limbs(const int32_t* limbs, uint32_t* out) {
+  fe a;
+  for (int i = 0; i < NL; ++i) a.l[i] = limbs[i];
+  store_plain(fe_canon(a), out);
+}
 void t_fe_inv_plain_gcd(const uint32_t* a, uint32_t* out) { store_plain(fe_inv_plain_gcd(load_plain(a)), out); }
 int t_fe_is_qr(const uint32_t* a) { return fe_is_qr(to_m(a)) ? 1 : 0; }
 // (a - b) * (c + d) - e*f : exercises lazy add/sub feeding products

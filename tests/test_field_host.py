@@ -211,3 +211,37 @@ def test_fn_inv_variable_time(shim):
     for a in vals:
         shim.t_fn_inv_var(W(a), out)
         assert I(out) == pow(a, -1, N), hex(a)
+
+
+def test_fe_canon_on_raw_limbs(shim):
+    """fe_canon takes any N-form or lazy value (|value| < 16 p, limbs up to 2 * 2^29 in magnitude, signed) to
+    [0, p): multiples of p, the boundaries around them, negative values, unnormalised limbs."""
+    rng = random.Random(99)
+
+    def limbs_of(v):  # normalised signed representation: limbs 0..7 in [0, 2^29), limb 8 carries the sign
+        out = [(v >> (29 * i)) & (2**29 - 1) for i in range(8)]
+        out.append(v >> 232)
+        return out
+
+    def check(limbs):
+        value = sum(l << (29 * i) for i, l in enumerate(limbs))
+        out = (ctypes.c_uint32 * 8)()
+        shim.t_fe_canon_limbs((ctypes.c_int32 * 9)(*limbs), out)
+        assert I(out) == value % P, (limbs, value)
+
+    for k in range(-15, 16):
+        for d in (-2, -1, 0, 1, 2, 2**29, -(2**29), 2**192 * 17, 2**250):
+            check(limbs_of(k * P + d))
+    for _ in range(2000):
+        v = rng.randrange(-16 * P + 1, 16 * P)
+        check(limbs_of(v))
+        # the same value with lazy limbs: move one unit of limb i + 1 down into limb i, or borrow the other way
+        l = limbs_of(v)
+        i = rng.randrange(8)
+        if rng.random() < 0.5:
+            l[i] += 2**29
+            l[i + 1] -= 1
+        else:
+            l[i] -= 2**29
+            l[i + 1] += 1
+        check(l)
