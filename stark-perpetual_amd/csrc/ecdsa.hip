@@ -12,8 +12,10 @@
 //     with c = x^3 + x + beta and a formal Y, Y^2 = c, the multiples of Q = (x, Y) are (a_k, b_k Y),
 //     i.e. rational points of the isomorphic curve y'^2 = x'^3 + c^2 x' + beta c^3 under
 //     x' = c x, y' = c^2 b.  The ladder runs on that curve from (c x, c^2); the acceptance test
-//     r in { x(A + B), x(A - B) } becomes one polynomial identity  E^2 == 4 ya^2 t^2 c  plus the
-//     Legendre test "c is a square" (InvalidPublicKeyError -> False, signature.py:232-235).
+//     r in { x(A + B), x(A - B) } becomes one polynomial identity  E^2 == 4 ya^2 t^2 c  (evaluated with
+//     the denominators cleared, verify_finish).  "c is a square" (InvalidPublicKeyError -> False,
+//     signature.py:232-235) is implied by that identity - on the twist it has no solution, see key_model -
+//     so only key registration still runs a Legendre test (to label the slot).
 // Reachable reference failure modes and how they are reproduced here:
 //   z == 0                      -> False   (mimic_ec_mult_air asserts 0 < m, signature.py:181)
 //   z*G + r*Q == infinity       -> False   (ec_add x-collision, signature.py:254)
