@@ -24,9 +24,9 @@
  *     columns are per stream, so _dev calls on different streams overlap on the device.  The
  *     host-pointer batches that carry no shared state - sp_pedersen_batch, sp_ecdsa_verify_batch
  *     (per-signature ladder), sp_ecdsa_sign_batch, sp_ecdsa_sign_rfc6979_batch, sp_public_key_batch -
- *     run on one of 8 host lanes (own stream, own staging buffer) and hold the lock only while a
- *     kernel is enqueued: calls from different threads overlap on the device (a ninth concurrent
- *     caller waits for a lane).  The other host-pointer calls (chains, trees, key registration and
+ *     run on one of 16 host lanes (own stream, own staging buffer) and hold the lock only while a
+ *     kernel is enqueued: calls from different threads overlap on the device - on the devices, after
+ *     sp_init_devices - (a seventeenth concurrent caller waits for a lane).  The other host-pointer calls (chains, trees, key registration and
  *     keyed verification) hold the lock for their whole staged round trip.
  *     Each entry point binds the device given to sp_init for its duration and restores the calling
  *     thread's current HIP device on return.
@@ -76,6 +76,23 @@ extern "C" {
  * EC_GEN (signature.py:56) in HBM.  window_bits = 0 picks the default (21: 2^20 + 22 x 2^21 Pedersen entries + 12 x 2^21
  * EC_GEN entries, 64 B each = 4.3 GiB of tables).  Idempotent. */
 int sp_init(int device, int window_bits);
+/* Several devices in one process (the SURVEY 8(b) shape `sp_init(n_devices, device_ids)`): one context - its own
+ * window tables - per entry of device_ids; context 0 is the PRIMARY.  What runs where:
+ *   - the stateless batches run on ANY context: sp_pedersen_batch, sp_ecdsa_verify_batch (ladder),
+ *     sp_ecdsa_sign_batch, sp_ecdsa_sign_rfc6979_batch, sp_public_key_batch take the context of the host lane
+ *     they are handed (lanes go round-robin over the contexts, so concurrent host threads spread over the
+ *     devices); sp_pedersen_batch_dev, sp_pedersen_chains_dev, sp_merkle_build_dev, sp_merkle_forest_dev,
+ *     sp_commit_rows_dev and sp_ecdsa_verify_batch_dev run on the device their pointers live on (the stream
+ *     must belong to that device);
+ *   - everything with state - persistent trees, key tables, the prover entry points (twiddle tables, witness
+ *     scratch) and the remaining host-pointer calls - stays on the primary device.
+ * The reference's deployment model here is one process per GPU (torch.distributed ranks, bench.py); this
+ * entry point is for a C caller that drives a node from one process.  Idempotent for the same layout;
+ * another layout needs sp_shutdown first.  A device may be listed twice (two contexts on one GPU: tests). */
+int sp_init_devices(int n_devices, const int* device_ids, int window_bits);
+int sp_device_count(void);  /* contexts initialised (0 before sp_init) */
+/* device index and host-lane calls served so far by context `index` */
+int sp_context_info(int index, int* device, uint64_t* host_calls);
 void sp_shutdown(void);
 const char* sp_last_error(void);
 int sp_is_initialised(void);

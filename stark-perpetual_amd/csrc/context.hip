@@ -32,38 +32,60 @@ void release_stark_state();     // twiddle / coset tables, work buffers (stark.h
 void release_ecdsa_state();     // per-signature window tables (ecdsa.hip)
 void release_tree_state();      // persistent sparse trees (merkle.hip)
 
-static Context g_ctx;
+std::recursive_mutex& global_mu() {
+  static std::recursive_mutex mu;
+  return mu;
+}
+static Context g_ctxs[SP_MAX_CONTEXTS];
+static int g_nctx = 1;
+static thread_local int tl_ctx = 0;
 static std::string g_err;
 static std::mutex g_err_mu;
 
-Context& ctx() { return g_ctx; }
+Context& ctx() { return g_ctxs[tl_ctx]; }
+Context& ctx_at(int index) { return g_ctxs[index]; }
+int ctx_count() { return g_nctx; }
+int ctx_current() { return tl_ctx; }
+void ctx_select(int index) { tl_ctx = (index >= 0 && index < g_nctx) ? index : 0; }
+
+CtxByPointer::CtxByPointer(const void* device_ptr) : previous(tl_ctx) {
+  if (g_nctx <= 1 || device_ptr == nullptr) return;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, device_ptr) != hipSuccess) {
+    (void)hipGetLastError();  // not a device pointer: the entry point will fail on its own terms
+    return;
+  }
+  if (g_ctxs[tl_ctx].ready && g_ctxs[tl_ctx].device == attr.device) return;  // e.g. a lane's own staging buffer
+  for (int i = 0; i < g_nctx; ++i) {
+    if (g_ctxs[i].ready && g_ctxs[i].device == attr.device) {
+      tl_ctx = i;
+      return;
+    }
+  }
+}
 
 static HostLane g_lanes[HOST_LANES];
 static std::mutex g_lane_mu;
 static std::condition_variable g_lane_cv;
+static int g_lane_next = 0;  // round-robin start: consecutive callers get lanes of consecutive contexts
 
-HostLane* lane_acquire() {
+HostLane* lane_acquire(int* ctx_index) {
   std::unique_lock<std::mutex> lk(g_lane_mu);
-  HostLane* lane = nullptr;
+  int got = -1;
   g_lane_cv.wait(lk, [&] {
-    for (HostLane& l : g_lanes) {
-      if (!l.busy) {
-        lane = &l;
+    for (int k = 0; k < HOST_LANES; ++k) {
+      const int i = (g_lane_next + k) % HOST_LANES;
+      if (!g_lanes[i].busy) {
+        got = i;
         return true;
       }
     }
     return false;
   });
-  if (!lane->stream) {
-    const hipError_t e = hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      lane->stream = nullptr;
-      (void)hip_fail(e, "hipStreamCreateWithFlags (host lane)");
-      return nullptr;
-    }
-  }
-  lane->busy = true;
-  return lane;
+  g_lane_next = (got + 1) % HOST_LANES;
+  g_lanes[got].busy = true;
+  *ctx_index = got % g_nctx;
+  return &g_lanes[got];
 }
 
 void lane_release(HostLane* lane) {
@@ -72,6 +94,29 @@ void lane_release(HostLane* lane) {
     lane->busy = false;
   }
   g_lane_cv.notify_one();
+}
+
+// Called with the lane's context selected and its device bound (after SP_REQUIRE_READY).
+int lane_stream(HostLane* lane) {
+  if (lane->stream && lane->stream_ctx == tl_ctx) {
+    std::lock_guard<std::recursive_mutex> lk(global_mu());
+    ++g_ctxs[tl_ctx].host_calls;
+    return SP_OK;
+  }
+  if (lane->stream) {  // the context layout changed (sp_shutdown + another sp_init_devices)
+    (void)hipStreamDestroy(lane->stream);
+    lane->stream = nullptr;
+    lane->io.release();
+  }
+  const hipError_t e = hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    lane->stream = nullptr;
+    return hip_fail(e, "hipStreamCreateWithFlags (host lane)");
+  }
+  lane->stream_ctx = tl_ctx;
+  std::lock_guard<std::recursive_mutex> lk(global_mu());
+  ++g_ctxs[tl_ctx].host_calls;
+  return SP_OK;
 }
 
 void release_host_lanes() {
@@ -226,8 +271,7 @@ static int make_plan(int log2e, PedPlan& p) {
   return SP_OK;
 }
 
-static int init_locked(int device, int window_bits) {
-  Context& c = g_ctx;
+static int init_locked(Context& c, int device, int window_bits) {
   if (c.ready) return SP_OK;
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -337,36 +381,84 @@ using namespace sp;
 
 extern "C" {
 
+static void free_tables(Context& c) {
+  if (c.ped) (void)hipFree(c.ped);
+  if (c.gen) (void)hipFree(c.gen);
+  if (c.d_plan) (void)hipFree(c.d_plan);
+  c.ped = c.gen = nullptr;
+  c.d_plan = nullptr;
+  c.io.release();
+  c.io2.release();
+  c.ready = false;
+}
+
 int sp_init(int device, int window_bits) {
-  ctx_lock lk(g_ctx.mu);
-  int rc = init_locked(device, window_bits);
-  if (rc != SP_OK && !g_ctx.ready) {
-    if (g_ctx.ped) (void)hipFree(g_ctx.ped);
-    if (g_ctx.gen) (void)hipFree(g_ctx.gen);
-    if (g_ctx.d_plan) (void)hipFree(g_ctx.d_plan);
-    g_ctx.ped = g_ctx.gen = nullptr;
-    g_ctx.d_plan = nullptr;
-  }
+  ctx_lock lk(global_mu());
+  Context& c = ctx_at(0);
+  if (c.ready) return SP_OK;  // idempotent (also after sp_init_devices: the contexts stay as they are)
+  int rc = init_locked(c, device, window_bits);
+  if (rc != SP_OK) free_tables(c);
   return rc;
 }
 
+int sp_init_devices(int n_devices, const int* device_ids, int window_bits) {
+  if (n_devices < 1 || n_devices > SP_MAX_CONTEXTS || device_ids == nullptr) {
+    set_error("sp_init_devices: 1 .. 16 devices");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  ctx_lock lk(global_mu());
+  if (ctx_at(0).ready) {  // idempotent for the same layout only: tables are immutable after init
+    bool same = g_nctx == n_devices;
+    for (int i = 0; same && i < n_devices; ++i) same = ctx_at(i).ready && ctx_at(i).device == device_ids[i];
+    if (same) return SP_OK;
+    set_error("sp_init_devices: already initialised with another device layout (sp_shutdown first)");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  int previous = -1;
+  (void)hipGetDevice(&previous);
+  int rc = SP_OK;
+  for (int i = 0; i < n_devices && rc == SP_OK; ++i) rc = init_locked(ctx_at(i), device_ids[i], window_bits);
+  if (rc != SP_OK) {
+    for (int i = 0; i < n_devices; ++i) free_tables(ctx_at(i));
+  } else {
+    g_nctx = n_devices;
+  }
+  if (previous >= 0) (void)hipSetDevice(previous);
+  return rc;
+}
+
+int sp_device_count(void) { return ctx_at(0).ready ? g_nctx : 0; }
+
+int sp_context_info(int index, int* device, uint64_t* host_calls) {
+  ctx_lock lk(global_mu());
+  if (index < 0 || index >= g_nctx || !ctx_at(index).ready) {
+    set_error("sp_context_info: no such context");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  if (device) *device = ctx_at(index).device;
+  if (host_calls) *host_calls = ctx_at(index).host_calls;
+  return SP_OK;
+}
+
 void sp_shutdown(void) {
-  ctx_lock lk(g_ctx.mu);
-  (void)hipDeviceSynchronize();
+  ctx_lock lk(global_mu());
+  int previous = -1;
+  (void)hipGetDevice(&previous);
+  for (int i = 0; i < g_nctx; ++i) {
+    if (ctx_at(i).ready && hipSetDevice(ctx_at(i).device) == hipSuccess) (void)hipDeviceSynchronize();
+  }
+  if (previous >= 0) (void)hipSetDevice(previous);
   sp::release_pedersen_state();
   sp::release_merkle_state();
   sp::release_stark_state();
   sp::release_ecdsa_state();
   sp::release_tree_state();
   sp::release_host_lanes();
-  if (g_ctx.ped) (void)hipFree(g_ctx.ped);
-  if (g_ctx.gen) (void)hipFree(g_ctx.gen);
-  if (g_ctx.d_plan) (void)hipFree(g_ctx.d_plan);
-  g_ctx.ped = g_ctx.gen = nullptr;
-  g_ctx.d_plan = nullptr;
-  g_ctx.io.release();
-  g_ctx.io2.release();
-  g_ctx.ready = false;
+  for (int i = 0; i < SP_MAX_CONTEXTS; ++i) {
+    free_tables(ctx_at(i));
+    ctx_at(i).host_calls = 0;
+  }
+  g_nctx = 1;
 }
 
 const char* sp_last_error(void) {
@@ -376,9 +468,13 @@ const char* sp_last_error(void) {
   return copy.c_str();
 }
 
-int sp_is_initialised(void) { return g_ctx.ready ? 1 : 0; }
-int sp_window_bits(void) { return g_ctx.plan.log2e; }
-size_t sp_table_bytes(void) { return g_ctx.table_bytes; }
+int sp_is_initialised(void) { return ctx_at(0).ready ? 1 : 0; }
+int sp_window_bits(void) { return ctx_at(0).plan.log2e; }
+size_t sp_table_bytes(void) {  // all contexts
+  size_t total = 0;
+  for (int i = 0; i < g_nctx; ++i) total += ctx_at(i).table_bytes;
+  return total;
+}
 
 int sp_synchronize(void* stream) {
   SP_REQUIRE_READY();

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <condition_variable>
 #include <mutex>
+#include <utility>
 #include <string>
 
 #include "../../include/starkperp.h"
@@ -51,6 +52,13 @@ struct DeviceBuffer {
   }
 };
 
+// One context per device the process drives (sp_init: one; sp_init_devices: several).  Context 0 is the
+// PRIMARY: the stateful machinery - persistent trees, the ECDSA key cache, the prover's twiddle tables and
+// witness scratch - lives on its device only.  The stateless batches (hash, ladder verification, signing,
+// public keys, tree / forest rebuilds, row commitments) run on any context: a host-pointer call takes the
+// context of the host lane it was given, a _dev call the context of the device its pointers live on.
+constexpr int SP_MAX_CONTEXTS = 16;
+std::recursive_mutex& global_mu();
 struct Context {
   bool ready = false;
   int device = -1;
@@ -63,34 +71,65 @@ struct Context {
   size_t table_bytes = 0;
   DeviceBuffer io;             // staging for host-pointer entry points
   DeviceBuffer io2;
+  uint64_t host_calls = 0;     // host-lane calls served (sp_context_info)
   // Recursive: host-pointer entry points hold it across the staging copies AND the nested _dev
-  // call, so two host threads can never interleave on the shared staging buffers.
-  std::recursive_mutex mu;
+  // call, so two host threads can never interleave on the shared staging buffers.  ONE lock for all
+  // contexts: it also guards the per-stream scratch maps, which are shared; it is held while work is
+  // enqueued, never while the device runs a stateless batch.
+  std::recursive_mutex& mu = global_mu();
 };
 using ctx_lock = std::lock_guard<std::recursive_mutex>;
 
-Context& ctx();
+Context& ctx();               // the context selected on this host thread (the primary unless a scope below says otherwise)
+Context& ctx_at(int index);
+int ctx_count();
+int ctx_current();
+void ctx_select(int index);
+// Key of the per-stream scratch maps: the null stream exists once per device.
+using StreamKey = std::pair<int, hipStream_t>;
+inline StreamKey stream_key(hipStream_t st) { return StreamKey(ctx_current(), st); }
+
+// Selects, for the duration of a _dev entry point, the context whose device owns `device_ptr`.  With one
+// context (the common case: one process per GPU) it does nothing.
+struct CtxByPointer {
+  int previous;
+  explicit CtxByPointer(const void* device_ptr);
+  ~CtxByPointer() { ctx_select(previous); }
+  CtxByPointer(const CtxByPointer&) = delete;
+  CtxByPointer& operator=(const CtxByPointer&) = delete;
+};
 
 // Host lanes: the host-pointer entry points that carry no shared state (hash / verify / sign / public-key
 // batches) each take one of HOST_LANES lanes - a non-blocking stream with its own staging buffer - so that
 // calls from different host threads overlap on the device instead of queueing behind one lock (the scalar
 // API of the reference is a stream of one-item calls: 0.1 - 0.4 ms of latency each, almost all of it idle
 // chip).  The context lock is then held only while a kernel is enqueued.  A caller blocks while every lane is
-// taken.
-constexpr int HOST_LANES = 8;
+// taken.  Lane i belongs to context i mod ctx_count(), and lanes are handed out round-robin: concurrent
+// callers spread over the devices of sp_init_devices.
+constexpr int HOST_LANES = 16;
 struct HostLane {
   hipStream_t stream = nullptr;
+  int stream_ctx = -1;          // the context the stream was created for
   DeviceBuffer io;
   bool busy = false;
 };
-HostLane* lane_acquire();         // nullptr: the stream could not be created (sp_last_error says why)
+HostLane* lane_acquire(int* ctx_index);
 void lane_release(HostLane* lane);
+int lane_stream(HostLane* lane);  // creates the lane's stream on the current device if needed; SP_OK or SP_ERR_HIP
 void release_host_lanes();        // sp_shutdown
+// Usage in an entry point:  LaneScope ls;  SP_REQUIRE_READY();  if (ls.open() != SP_OK) return SP_ERR_HIP;
 struct LaneScope {
   HostLane* lane;
-  LaneScope() : lane(lane_acquire()) {}
+  int previous_ctx;
+  LaneScope() : previous_ctx(ctx_current()) {
+    int index = 0;
+    lane = lane_acquire(&index);
+    ctx_select(index);
+  }
+  int open() { return lane_stream(lane); }
   ~LaneScope() {
-    if (lane) lane_release(lane);
+    lane_release(lane);
+    ctx_select(previous_ctx);
   }
   LaneScope(const LaneScope&) = delete;
   LaneScope& operator=(const LaneScope&) = delete;

@@ -741,7 +741,7 @@ using namespace sp;
 
 // Per-stream, like the Pedersen scratch: verifications in flight on different streams (or issued by
 // different host threads) never share a window table.
-static std::map<hipStream_t, sp::DeviceBuffer> g_verify_tab;
+static std::map<sp::StreamKey, sp::DeviceBuffer> g_verify_tab;
 // Key-table cache (see "Key tables" above): slot -> 128-entry comb table, curve-model constant c and
 // a flag, all in HBM; the host keeps the (qx, qy | x-only) -> slot map.
 struct KeyId {
@@ -811,12 +811,13 @@ extern "C" {
 int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                               const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n,
                               void* stream) {
+  CtxByPointer sp_ctx_sel__(z);  // the context of the device these pointers live on
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   Context& c = ctx();
   ctx_lock lk(c.mu);
   // per-signature table of the eight odd multiples of the key: 8 x 27 limbs, limb-major
-  DeviceBuffer& tab = g_verify_tab[(hipStream_t)stream];
+  DeviceBuffer& tab = g_verify_tab[stream_key((hipStream_t)stream)];
   SP_HIP(tab.reserve(n * 8 * 27 * sizeof(int32_t)));
   hipLaunchKernelGGL(ecdsa_verify_kernel, dim3(nblocks(n, VERIFY_TPB)), dim3(VERIFY_TPB), 0, (hipStream_t)stream, z, r,
                      s, qx, qy, result, n, c.gen, c.wbits, c.nwin, (int32_t*)tab.ptr);
@@ -1065,14 +1066,15 @@ int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint
 
 int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                           const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
-  SP_REQUIRE_READY();
-  if (n == 0) return SP_OK;
   {
-    ctx_lock lk(ctx().mu);  // the policy reads and fills the key cache: shared state, one caller at a time
+    SP_REQUIRE_READY();
+    if (n == 0) return SP_OK;
+    ctx_lock lk(ctx().mu);  // the policy reads and fills the key cache: shared state (primary context), one caller at a time
     if (use_key_tables(qx, qy, n)) return sp_ecdsa_verify_batch_keyed(z, r, s, qx, qy, result, n);
   }
   LaneScope ls;  // the ladder carries no shared state: calls from different host threads overlap
-  if (!ls.lane) return SP_ERR_HIP;
+  SP_REQUIRE_READY();
+  if (ls.open() != SP_OK) return SP_ERR_HIP;
   HostLane& L = *ls.lane;
   const uint64_t* host[5] = {z, r, s, qx, qy};
   uint64_t* dev[5];
@@ -1088,11 +1090,11 @@ int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* 
 
 int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r,
                         uint64_t* s, uint8_t* status, size_t n) {
+  LaneScope ls;
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
+  if (ls.open() != SP_OK) return SP_ERR_HIP;
   Context& c = ctx();
-  LaneScope ls;
-  if (!ls.lane) return SP_ERR_HIP;
   HostLane& L = *ls.lane;
   const uint64_t* host[3] = {z, d, k};
   uint64_t* dev[3];
@@ -1116,11 +1118,11 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
 
 int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
                                 uint64_t* s, uint8_t* status, size_t n) {
+  LaneScope ls;
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
+  if (ls.open() != SP_OK) return SP_ERR_HIP;
   Context& c = ctx();
-  LaneScope ls;
-  if (!ls.lane) return SP_ERR_HIP;
   HostLane& L = *ls.lane;
   const uint64_t* host[2] = {z, d};
   uint64_t* dev[2];
@@ -1145,11 +1147,11 @@ int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint
 }
 
 int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* status, size_t n) {
+  LaneScope ls;
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
+  if (ls.open() != SP_OK) return SP_ERR_HIP;
   Context& c = ctx();
-  LaneScope ls;
-  if (!ls.lane) return SP_ERR_HIP;
   HostLane& L = *ls.lane;
   const uint64_t* host[1] = {d};
   uint64_t* dev[1];

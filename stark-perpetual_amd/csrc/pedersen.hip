@@ -546,11 +546,11 @@ struct Scratch {
 // Scratch is per stream, so independent calls issued on different HIP streams (e.g. several trees
 // in flight) never share X / ZZ / prefix planes.  Growing a buffer reallocates it: callers that
 // overlap streams should size the first call of each stream for their largest batch.
-static std::map<hipStream_t, DeviceBuffer> g_stream_scratch;
+static std::map<StreamKey, DeviceBuffer> g_stream_scratch;
 int get_scratch_public(size_t n, Scratch& s, hipStream_t st);
 static int get_scratch(size_t n, Scratch& s, hipStream_t st) { return get_scratch_public(n, s, st); }
 int get_scratch_public(size_t n, Scratch& s, hipStream_t st) {
-  DeviceBuffer& buf = g_stream_scratch[st];
+  DeviceBuffer& buf = g_stream_scratch[stream_key(st)];
   const size_t plane = ((9 * n * sizeof(int32_t)) + 255) & ~(size_t)255;
   SP_HIP(buf.reserve(3 * plane + 256));
   char* b = (char*)buf.ptr;
@@ -670,6 +670,7 @@ extern "C" {
 
 int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status,
                           size_t n, void* stream) {
+  CtxByPointer sp_ctx_sel__(x);  // the context of the device these pointers live on
   SP_REQUIRE_READY();
   ctx_lock lk(ctx().mu);
   Scratch s;
@@ -679,11 +680,11 @@ int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, u
 }
 
 int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n) {
+  LaneScope ls;  // calls from different host threads overlap on the device(s) (context.hpp "Host lanes")
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
+  if (ls.open() != SP_OK) return SP_ERR_HIP;
   Context& c = ctx();
-  LaneScope ls;  // calls from different host threads overlap on the device (context.hpp "Host lanes")
-  if (!ls.lane) return SP_ERR_HIP;
   HostLane& L = *ls.lane;
   const size_t fb = n * 32;
   SP_HIP(L.io.reserve(3 * fb + n + 64));
@@ -767,6 +768,7 @@ int sp_pedersen_point_batch(const uint64_t* x, const uint64_t* y, uint64_t* ox, 
 
 int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, uint64_t* out,
                            uint8_t* status, void* stream) {
+  CtxByPointer sp_ctx_sel__(elems);  // the context of the device these pointers live on
   SP_REQUIRE_READY();
   if (depth < 1) { set_error("chain depth must be >= 1"); return SP_ERR_BAD_ARGUMENT; }
   if (width == 0) return SP_OK;
@@ -872,6 +874,7 @@ int sp_pedersen_chain_right(const uint64_t* elems, size_t n_elems, uint64_t* out
 // Buffer: n_trees (2^(height+1) - 1) felts, level-major, leaves first.
 int sp_merkle_forest_dev(uint64_t* levels, size_t n_trees, unsigned height, uint8_t* status,
                          void* stream) {
+  CtxByPointer sp_ctx_sel__(levels);  // the context of the device these pointers live on
   SP_REQUIRE_READY();
   if (n_trees == 0) return SP_OK;
   if (height > 40 || (n_trees >> (40 - height)) != 0) { set_error("forest too large"); return SP_ERR_BAD_ARGUMENT; }
@@ -904,6 +907,7 @@ int sp_merkle_build_dev(uint64_t* levels, unsigned height, uint8_t* status, void
 // the Merkle tree over the leaves.  levels: 2 n_rows - 1 felts, leaves first, root last.
 int sp_commit_rows_dev(const uint64_t* cols, size_t n_rows, size_t n_cols, uint64_t* levels, uint8_t* status,
                        void* stream) {
+  CtxByPointer sp_ctx_sel__(cols);  // the context of the device these pointers live on
   SP_REQUIRE_READY();
   if (n_rows == 0 || (n_rows & (n_rows - 1)) != 0 || n_cols == 0) {
     set_error("rows must be a power of two, columns at least one");

@@ -62,6 +62,9 @@ _SIGNATURES = {
                                               ctypes.c_void_p, ctypes.c_void_p]),
     "sp_air_eval_ec_ladder_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_init_devices": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]),
+    "sp_device_count": (ctypes.c_int, []),
+    "sp_context_info": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_ecdsa_set_verify_policy": (ctypes.c_int, [ctypes.c_int]),
     "sp_ecdsa_get_verify_policy": (ctypes.c_int, []),
     "sp_range_check_trace_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
@@ -153,12 +156,32 @@ def check(rc, what):
 def ensure_init(device=None, window_bits=None):
     lib = load()
     if not lib.sp_is_initialised():
+        explicit_device = device
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", os.environ.get("STARKPERP_DEVICE", "0")))
         if window_bits is None:
             window_bits = int(os.environ.get("STARKPERP_WINDOW_BITS", "0"))
-        check(lib.sp_init(device, window_bits), "sp_init")
+        devices = os.environ.get("STARKPERP_DEVICES")  # "0,1,2,3": several contexts in this process (sp_init_devices)
+        if devices and explicit_device is None:
+            init_devices([int(v) for v in devices.split(",")], window_bits)
+        else:
+            check(lib.sp_init(device, window_bits), "sp_init")
     return lib
+
+
+def init_devices(device_ids, window_bits=0):
+    """Several devices in one process (include/starkperp.h sp_init_devices): context 0 = primary."""
+    lib = load()
+    ids = (ctypes.c_int * len(device_ids))(*device_ids)
+    check(lib.sp_init_devices(len(device_ids), ids, int(window_bits or 0)), "sp_init_devices")
+    return lib
+
+
+def context_info(index):
+    """(device, host-lane calls served) of context `index`."""
+    dev, calls = ctypes.c_int(), ctypes.c_uint64()
+    check(load().sp_context_info(index, ctypes.byref(dev), ctypes.byref(calls)), "sp_context_info")
+    return dev.value, calls.value
 
 
 # ---- felt marshalling -------------------------------------------------------------------------
