@@ -19,6 +19,7 @@
 // The EC_GEN table (k*G for sign / public keys / the z*G leg of verify) is the plain unsigned
 // uniform-window table with offsets that are multiples of P0 and sum to the point at infinity.
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "context.hpp"
@@ -69,23 +70,48 @@ static std::mutex g_lane_mu;
 static std::condition_variable g_lane_cv;
 static int g_lane_next = 0;  // round-robin start: consecutive callers get lanes of consecutive contexts
 
-HostLane* lane_acquire(int* ctx_index) {
+HostLane* lane_acquire(int* ctx_index, int want_ctx) {
   std::unique_lock<std::mutex> lk(g_lane_mu);
   int got = -1;
   g_lane_cv.wait(lk, [&] {
     for (int k = 0; k < HOST_LANES; ++k) {
       const int i = (g_lane_next + k) % HOST_LANES;
-      if (!g_lanes[i].busy) {
+      if (!g_lanes[i].busy && (want_ctx < 0 || i % g_nctx == want_ctx)) {
         got = i;
         return true;
       }
     }
     return false;
   });
-  g_lane_next = (got + 1) % HOST_LANES;
+  if (want_ctx < 0) g_lane_next = (got + 1) % HOST_LANES;
   g_lanes[got].busy = true;
   *ctx_index = got % g_nctx;
   return &g_lanes[got];
+}
+
+static thread_local int tl_shard_ctx = -1;
+int shard_context() { return tl_shard_ctx; }
+
+int shard_over_contexts(size_t n, const std::function<int(size_t, size_t)>& fn) {
+  const int parts = g_nctx;
+  std::vector<int> rc(parts, SP_OK);
+  std::vector<std::thread> workers;
+  const size_t per = (n + parts - 1) / parts;
+  for (int i = 0; i < parts; ++i) {
+    const size_t off = (size_t)i * per;
+    if (off >= n) break;
+    const size_t cnt = n - off < per ? n - off : per;
+    workers.emplace_back([&, i, off, cnt] {
+      tl_shard_ctx = i;
+      rc[i] = fn(off, cnt);
+      tl_shard_ctx = -1;
+    });
+  }
+  for (std::thread& w : workers) w.join();
+  for (int v : rc) {
+    if (v != SP_OK) return v;
+  }
+  return SP_OK;
 }
 
 void lane_release(HostLane* lane) {
@@ -93,7 +119,7 @@ void lane_release(HostLane* lane) {
     std::lock_guard<std::mutex> lk(g_lane_mu);
     lane->busy = false;
   }
-  g_lane_cv.notify_one();
+  g_lane_cv.notify_all();  // waiters may want a lane of one particular context
 }
 
 // Called with the lane's context selected and its device bound (after SP_REQUIRE_READY).

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <utility>
 #include <string>
@@ -113,17 +114,24 @@ struct HostLane {
   DeviceBuffer io;
   bool busy = false;
 };
-HostLane* lane_acquire(int* ctx_index);
+HostLane* lane_acquire(int* ctx_index, int want_ctx);  // want_ctx < 0: any context, round-robin
 void lane_release(HostLane* lane);
 int lane_stream(HostLane* lane);  // creates the lane's stream on the current device if needed; SP_OK or SP_ERR_HIP
 void release_host_lanes();        // sp_shutdown
 // Usage in an entry point:  LaneScope ls;  SP_REQUIRE_READY();  if (ls.open() != SP_OK) return SP_ERR_HIP;
+// A large host batch on several contexts: `fn(offset, count)` runs once per context on its own host thread, each
+// bound to its context (so the LaneScope inside takes a lane of that context), over contiguous slices of the n
+// items; returns the first non-zero code.  Used by the stateless host-pointer batches when ctx_count() > 1.
+int shard_over_contexts(size_t n, const std::function<int(size_t, size_t)>& fn);
+int shard_context();  // the context this host thread was bound to by shard_over_contexts, or -1
+constexpr size_t SHARD_MIN_ITEMS = 16384;  // below this one device is faster than the host threads are to start
+
 struct LaneScope {
   HostLane* lane;
   int previous_ctx;
   LaneScope() : previous_ctx(ctx_current()) {
     int index = 0;
-    lane = lane_acquire(&index);
+    lane = lane_acquire(&index, shard_context());
     ctx_select(index);
   }
   int open() { return lane_stream(lane); }

@@ -1066,11 +1066,17 @@ int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint
 
 int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                           const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
-  {
+  if (shard_context() < 0) {  // (a slice of a sharded batch: the policy has spoken for the whole batch)
     SP_REQUIRE_READY();
     if (n == 0) return SP_OK;
     ctx_lock lk(ctx().mu);  // the policy reads and fills the key cache: shared state (primary context), one caller at a time
     if (use_key_tables(qx, qy, n)) return sp_ecdsa_verify_batch_keyed(z, r, s, qx, qy, result, n);
+  }
+  if (ctx_count() > 1 && shard_context() < 0 && n >= SHARD_MIN_ITEMS) {  // one slice per device, side by side
+    return shard_over_contexts(n, [&](size_t off, size_t cnt) {
+      return sp_ecdsa_verify_batch(z + 4 * off, r + 4 * off, s + 4 * off, qx + 4 * off, qy ? qy + 4 * off : nullptr,
+                                   result + off, cnt);
+    });
   }
   LaneScope ls;  // the ladder carries no shared state: calls from different host threads overlap
   SP_REQUIRE_READY();

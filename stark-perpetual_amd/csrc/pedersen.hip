@@ -680,6 +680,11 @@ int sp_pedersen_batch_dev(const uint64_t* x, const uint64_t* y, uint64_t* out, u
 }
 
 int sp_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, uint8_t* status, size_t n) {
+  if (ctx_count() > 1 && shard_context() < 0 && n >= SHARD_MIN_ITEMS) {  // one slice per device, side by side
+    return shard_over_contexts(n, [&](size_t off, size_t cnt) {
+      return sp_pedersen_batch(x + 4 * off, y + 4 * off, out + 4 * off, status ? status + off : nullptr, cnt);
+    });
+  }
   LaneScope ls;  // calls from different host threads overlap on the device(s) (context.hpp "Host lanes")
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;

@@ -71,6 +71,26 @@ SCRIPT = textwrap.dedent(
     _lib.check(lib.sp_pedersen_batch_dev(dx.data_ptr(), dy.data_ptr(), out.data_ptr(), None, 3000, st), "dev")
     torch.cuda.synchronize()
     assert stark.tensor_to_felts(out) == cref.pedersen_hash_many(xs, ys)[0]
+    # one large host batch: sliced over the contexts (one host thread each), results in place
+    before = [_lib.context_info(i)[1] for i in range(2)]
+    big = 40000
+    bx = [rng.randrange(P) for _ in range(big)]
+    by = [rng.randrange(P) for _ in range(big)]
+    got = batch.pedersen_hash_many(bx, by)
+    assert got[:64] == cref.pedersen_hash_many(bx[:64], by[:64])[0]
+    assert got[-64:] == cref.pedersen_hash_many(bx[-64:], by[-64:])[0]
+    assert got[big // 2 - 32 : big // 2 + 32] == cref.pedersen_hash_many(bx[big // 2 - 32 : big // 2 + 32], by[big // 2 - 32 : big // 2 + 32])[0]
+    after = [_lib.context_info(i)[1] for i in range(2)]
+    assert [a - b for a, b in zip(after, before)] == [1, 1], (before, after)
+    m = 20000
+    dsv = [rng.randrange(1, N) for _ in range(4)]
+    pk = batch.public_keys_many(dsv)
+    zs = [rng.randrange(2**251) for _ in range(m)]
+    sg = batch.sign_many(zs, [dsv[i %% 4] for i in range(m)])
+    zs[7] ^= 1
+    zs[m - 3] ^= 1
+    codes = batch.verify_codes(zs, [a for a, _ in sg], [b for _, b in sg], [pk[i %% 4][0] for i in range(m)])
+    assert codes.count(0) == 2 and codes[7] == 0 and codes[m - 3] == 0
     leaves = [rng.randrange(P) for _ in range(1 << 9)]
     assert batch.merkle_root(leaves) == cref.merkle_levels(leaves)[-1][0]
     # stateful path (primary context): a persistent tree
