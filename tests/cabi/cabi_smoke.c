@@ -2,7 +2,7 @@
  * compiler and the shared library (no Python, no torch).  Built and run by tests/test_gpu_cabi.py.
  * Checks pedersen_hash(1, 2) and the two hash_test vectors of the reference's
  * signature_test_data.json:190-201, a 2-leaf tree, a chain, sign -> verify (ladder and key tables),
- * deterministic signing on the device, a persistent tree. */
+ * deterministic signing on the device, a persistent tree, two contexts in one process. */
 #include <stdio.h>
 #include <string.h>
 #include "../../include/starkperp.h"
@@ -93,6 +93,24 @@ int main(void) {
   if (sp_ecdsa_verify_batch_keyed(z, r, s, qx, NULL, &code, 1) != SP_OK || code != SP_VERIFY_TRUE) return 33;
   if (sp_ecdsa_key_cache_info(&cap, &used) != SP_OK || used != 1) return 34;
   sp_shutdown();
+
+  /* a third life with two contexts (the box has one GPU: it is listed twice) */
+  {
+    const int ids[2] = {0, 0};
+    int dev = -1;
+    uint64_t calls = 99;
+    if (sp_device_count() != 0) return 35;
+    if (sp_init_devices(2, ids, 10) != SP_OK || sp_device_count() != 2) return 36;
+    if (sp_init_devices(1, ids, 10) == SP_OK) return 37; /* another layout needs sp_shutdown first */
+    if (sp_pedersen_batch(&x[0][0], &y[0][0], &out[0][0], st, 2) != SP_OK || st[0] || st[1]) return 38;
+    if (sp_pedersen_batch(&x[1][0], &y[1][0], &out[1][0], st, 1) != SP_OK || st[0]) return 39;
+    if (!felt_eq_hex(out[0], "30e480bed5fe53fa909cc0f8c4d99b8f9f2c016be4c41e13a4848797979c662")) return 40;
+    if (!felt_eq_hex(out[1], "68cc0b76cddd1dd4ed2301ada9b7c872b23875d5ff837b3a87993e0d9996b87")) return 41;
+    if (sp_context_info(0, &dev, &calls) != SP_OK || dev != 0 || calls != 1) return 42; /* one call each: */
+    if (sp_context_info(1, &dev, &calls) != SP_OK || dev != 0 || calls != 1) return 43; /* lanes alternate */
+    if (sp_context_info(2, &dev, &calls) == SP_OK) return 44;
+    sp_shutdown();
+  }
   printf("cabi_smoke ok\n");
   return 0;
 }
