@@ -155,30 +155,56 @@ __device__ __forceinline__ u256 recode_odd(const u256& u2, bool& flip) {
 // of E, and the top digit is always +1 - every lane does the same 252 doublings + 63 additions
 // (no divergent branch; the binary ladder paid a mixed addition on every bit because some lane
 // always needed one).  The eight odd multiples (2j+1)*base live in a per-signature table in HBM,
-// limb-major (entry * 27 + limb) * n + e.
+// limb-major (entry * 36 + limb) * n + e, and are made AFFINE before the ladder starts - one shared inversion
+// of Z_1 ... Z_7 (Montgomery's trick, ~100 multiplication-equivalents) buys 63 mixed additions (7M + 4S)
+// instead of 63 general ones (11M + 5S): -6 % of the ladder.  A zero among the Z's (a base point of order
+// <= 15: impossible on the curve, prime order, and on its twist, no factor below 2 * 10^5) would poison the
+// shared inversion; the product is tested and such a ladder returns the absorbing state Z = 0 (-> False).
 __device__ __forceinline__ jac ladder_mul(const u256& u2, const aff& base, const fe& a_coef,
                                           int32_t* __restrict__ tab, size_t n, size_t e) {
   bool flip;
   u256 E = recode_odd(u2, flip);
-  auto tab_at = [&](int entry, int limb) -> int32_t* { return tab + ((size_t)(entry * 27 + limb) * n + e); };
-  auto tab_store = [&](int entry, const jac& P) {
+  // planes of an entry: 0..8 X (then affine x), 9..17 Y (then affine y), 18..26 Z, 27..35 prefix product
+  auto tab_at = [&](int entry, int limb) -> int32_t* { return tab + ((size_t)(entry * 36 + limb) * n + e); };
+  auto tab_store = [&](int entry, int plane, const fe& v) {
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      *tab_at(entry, l) = P.X.l[l];
-      *tab_at(entry, 9 + l) = P.Y.l[l];
-      *tab_at(entry, 18 + l) = P.Z.l[l];
-    }
+    for (int l = 0; l < NL; ++l) *tab_at(entry, 9 * plane + l) = v.l[l];
+  };
+  auto tab_load = [&](int entry, int plane) {
+    fe v;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) v.l[l] = *tab_at(entry, 9 * plane + l);
+    return v;
   };
   jac B;
   B.X = base.x; B.Y = base.y; B.Z = FE_ONE_M;
   {
-    tab_store(0, B);
+    tab_store(0, 0, base.x);
+    tab_store(0, 1, base.y);
     const jac twoQ = jac_dbl(B, a_coef);
     jac odd = jac_madd(twoQ, base);  // 3Q
-    tab_store(1, odd);
-    for (int j = 2; j < 8; ++j) {
-      odd = jac_add(odd, twoQ);
-      tab_store(j, odd);
+    fe run = FE_ONE_M;
+#pragma unroll 1
+    for (int j = 1; j < 8; ++j) {
+      if (j > 1) odd = jac_add(odd, twoQ);
+      tab_store(j, 0, odd.X);
+      tab_store(j, 1, odd.Y);
+      tab_store(j, 2, odd.Z);
+      tab_store(j, 3, run);
+      run = fe_mul(run, odd.Z);
+    }
+    if (fe_is_zero(run)) {  // see above: unreachable for valid inputs, absorbing state otherwise
+      B.Z = FE_ZERO;
+      return B;
+    }
+    fe inv = fe_inv(run);
+#pragma unroll 1
+    for (int j = 7; j >= 1; --j) {
+      const fe zinv = fe_mul(inv, tab_load(j, 3));
+      inv = fe_mul(inv, tab_load(j, 2));
+      const fe zi2 = fe_sqr(zinv);
+      tab_store(j, 0, fe_mul(tab_load(j, 0), zi2));
+      tab_store(j, 1, fe_mul(tab_load(j, 1), fe_mul(zi2, zinv)));
     }
   }
   // top window is e = 8  ->  digit +1: start from Q itself, then 63 windows
@@ -187,7 +213,7 @@ __device__ __forceinline__ jac ladder_mul(const u256& u2, const aff& base, const
     for (int i = 7; i > 0; --i) E.w[i] = (E.w[i] << 4) | (E.w[i - 1] >> 28);
     E.w[0] <<= 4;
   }
-  // The loop body is kept to ONE doubling + ONE addition of code (~40 KB): with the four doublings unrolled the
+  // The loop body is kept to ONE doubling + ONE addition of code (~35 KB): with the four doublings unrolled the
   // body outgrows the 64 KB instruction cache and a lone wave per SIMD waits on instruction fetch.
 #pragma unroll 1
   for (int wi = 0; wi < 63; ++wi) {
@@ -197,17 +223,16 @@ __device__ __forceinline__ jac ladder_mul(const u256& u2, const aff& base, const
     E.w[0] <<= 4;
     const int d = 2 * (int)ew - 15;
     const int mag = (d < 0 ? -d : d) >> 1;  // table index of |d| = 2 mag + 1
-    jac T;
+    aff T;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      T.X.l[l] = *tab_at(mag, l);
+      T.x.l[l] = *tab_at(mag, l);
       const int32_t y = *tab_at(mag, 9 + l);
-      T.Y.l[l] = d < 0 ? -y : y;
-      T.Z.l[l] = *tab_at(mag, 18 + l);
+      T.y.l[l] = d < 0 ? -y : y;
     }
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) B = jac_dbl(B, a_coef);
-    B = jac_add(B, T);
+    B = jac_madd(B, T);
   }
   if (flip) B.Y = fe_neg(B.Y);
   return B;
@@ -350,7 +375,10 @@ ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict_
   code = key_model<false>(pqx, pqy, e, base, c, a_coef);
   if (code != VERIFY_CONTINUE) { result[e] = code; return; }
   if (v.z_zero) { result[e] = SP_VERIFY_FALSE; return; }
-  const jac B = ladder_mul(v.u2, base, a_coef, tab, n, e);
+  // the table slot is the LANE's (lanes past the end redo the last item: with a shared slot a wave that has already
+  // made its entries affine would race one that still reads the projective ones)
+  const jac B = ladder_mul(v.u2, base, a_coef, tab, (size_t)gridDim.x * blockDim.x,
+                           (size_t)blockIdx.x * blockDim.x + threadIdx.x);
   const xyzz A = gen_mul(v.u1, gen, wbits, nwin);
   result[e] = verify_finish(A, B, c, pqy != nullptr, v.r);
 }
@@ -816,9 +844,9 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
   if (n == 0) return SP_OK;
   Context& c = ctx();
   ctx_lock lk(c.mu);
-  // per-signature table of the eight odd multiples of the key: 8 x 27 limbs, limb-major
+  // per-signature table of the eight odd multiples of the key: 8 x 36 limbs (X, Y, Z, prefix product), limb-major
   DeviceBuffer& tab = g_verify_tab[stream_key((hipStream_t)stream)];
-  SP_HIP(tab.reserve(n * 8 * 27 * sizeof(int32_t)));
+  SP_HIP(tab.reserve((size_t)nblocks(n, VERIFY_TPB) * VERIFY_TPB * 8 * 36 * sizeof(int32_t)));  // one slot per lane
   hipLaunchKernelGGL(ecdsa_verify_kernel, dim3(nblocks(n, VERIFY_TPB)), dim3(VERIFY_TPB), 0, (hipStream_t)stream, z, r,
                      s, qx, qy, result, n, c.gen, c.wbits, c.nwin, (int32_t*)tab.ptr);
   SP_HIP(hipGetLastError());
