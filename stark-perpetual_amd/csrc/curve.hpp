@@ -144,6 +144,35 @@ SP_HD jac jac_dbl(const jac& p, const fe& a_coef) {
   return r;
 }
 
+// Modified Jacobian doubling (Cohen - Miyaji - Ono): the point carries W = a Z^4, so a doubling is 4M + 4S
+//   S = 4 X Y^2,  U = 8 Y^4,  M = 3 X^2 + W,  X3 = M^2 - 2 S,  Y3 = M (S - X3) - U,  Z3 = 2 Y Z,  W3 = 2 U W
+// and k doublings in a row cost 4k M + (4k + 2) S (W once: 1M + 2S; the last W3 is not needed) against
+// k (2M + 8S) for jac_dbl: 16M + 18S instead of 8M + 32S for the four doublings of a ladder window.
+struct mjac {
+  fe X, Y, Z, W;
+};
+SP_HD mjac mjac_from(const jac& p, const fe& a_coef) {
+  mjac m;
+  m.X = p.X; m.Y = p.Y; m.Z = p.Z;
+  m.W = fe_mul(a_coef, fe_sqr(fe_sqr(p.Z)));
+  return m;
+}
+SP_HD void mjac_dbl(mjac& p, bool need_w) {
+  const fe XX = fe_sqr(p.X);
+  const fe YY = fe_sqr(p.Y);
+  const fe YYYY = fe_sqr(YY);
+  const fe S = fe_carry(fe_dbl(fe_carry(fe_dbl(fe_mul(p.X, YY)))));                    // 4 X YY
+  const fe U = fe_carry(fe_dbl(fe_carry(fe_dbl(fe_carry(fe_dbl(YYYY))))));             // 8 YYYY
+  const fe M = fe_carry(fe_add(fe_carry(fe_add(fe_dbl(XX), XX)), p.W));
+  const fe X3 = fe_carry(fe_sub(fe_sqr(M), fe_dbl(S)));
+  const fe Y3 = fe_carry(fe_sub(fe_mul(M, fe_carry(fe_sub(S, X3))), U));
+  const fe Z3 = fe_carry(fe_dbl(fe_mul(p.Y, p.Z)));
+  if (need_w) p.W = fe_carry(fe_dbl(fe_mul(U, p.W)));
+  p.X = X3;
+  p.Y = Y3;
+  p.Z = Z3;
+}
+
 // "madd-2007-bl": Jacobian + affine, 7M + 4S.  Exceptional cases drive Z to 0 (see xyzz_madd).
 SP_HD jac jac_madd(const jac& p, const aff& q) {
   const fe Z1Z1 = fe_sqr(p.Z);

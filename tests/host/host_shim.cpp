@@ -27,6 +27,25 @@ void t_fe_half(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   // half of (a - b) as plain integers: exercises negative and lazy inputs
   store_plain(fe_canon(fe_half(fe_sub(load_plain(a), load_plain(b)))), out);
 }
+// 2^k P on y^2 = x^3 + a x + b by k modified-Jacobian doublings (mjac_dbl) and by k jac_dbl: affine x, y of both
+static void jac_to_aff_plain(const fe& X, const fe& Y, const fe& Z, uint32_t* x, uint32_t* y) {
+  const fe zi = fe_inv(Z), zi2 = fe_sqr(zi);
+  from_m(fe_mul(X, zi2), x);
+  from_m(fe_mul(Y, fe_mul(zi2, zi)), y);
+}
+void t_repeated_doubling(const uint32_t* px, const uint32_t* py, const uint32_t* pz, const uint32_t* a, int k,
+                         uint32_t* x_m, uint32_t* y_m, uint32_t* x_j, uint32_t* y_j) {
+  const fe z = to_m(pz), z2 = fe_sqr(z);
+  jac p;
+  p.X = fe_mul(to_m(px), z2); p.Y = fe_mul(to_m(py), fe_mul(z2, z)); p.Z = z;
+  const fe am = to_m(a);
+  mjac m = mjac_from(p, am);
+  for (int i = 0; i < k; ++i) mjac_dbl(m, i + 1 < k);
+  jac_to_aff_plain(m.X, m.Y, m.Z, x_m, y_m);
+  jac q = p;
+  for (int i = 0; i < k; ++i) q = jac_dbl(q, am);
+  jac_to_aff_plain(q.X, q.Y, q.Z, x_j, y_j);
+}
 // fe_canon on raw limbs (signed, possibly lazy: the caller builds N-form / lazy patterns directly)
 void t_fe_canon_limbs(const int32_t* limbs, uint32_t* out) {
   fe a;

@@ -245,3 +245,25 @@ def test_fe_canon_on_raw_limbs(shim):
             l[i] -= 2**29
             l[i + 1] += 1
         check(l)
+
+
+def test_repeated_modified_jacobian_doubling(shim):
+    """k modified-Jacobian doublings (curve.hpp mjac_dbl, W = a Z^4 carried along) == k jac_dbl == the oracle's
+    2^k P, on the curve (a = 1) and on the c-model of an x-only key (a = c^2), from a random projective form,
+    up to 64 doublings in a row (magnitudes must not grow: the shim runs with the limb bound checks on)."""
+    rng = random.Random(41)
+    for trial in range(6):
+        pt = R.ec_mult(rng.randrange(1, N), tuple(R.EC_GEN))
+        a, b = 1, R.BETA
+        if trial % 2:  # the model y'^2 = x'^3 + c^2 x' + beta c^3 of the same point
+            c = pt[1] * pt[1] % P
+            pt = (c * pt[0] % P, c * c % P * 1 % P * 1)  # (c x, c^2 * (y / sqrt c)) with sqrt c = y
+            a = c * c % P
+        for k in (1, 4, 64 if trial < 2 else 7):
+            outs = [(ctypes.c_uint32 * 8)() for _ in range(4)]
+            shim.t_repeated_doubling(W(pt[0]), W(pt[1]), W(rng.randrange(1, P)), W(a), k, *outs)
+            want = pt
+            for _ in range(k):
+                want = R.ec_double(want, a)
+            assert (I(outs[0]), I(outs[1])) == want, (trial, k, "mjac")
+            assert (I(outs[2]), I(outs[3])) == want, (trial, k, "jac")
