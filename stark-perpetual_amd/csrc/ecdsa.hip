@@ -450,8 +450,8 @@ key_rows_kernel(const uint64_t* __restrict__ pqx, const uint64_t* __restrict__ p
   }
   st_u256(key_c + 4 * (size_t)slot, fe_pack(fe_canon(c)));
   auto plane = [&](int point, int limb) -> int32_t* { return work + ((size_t)(point * 36 + limb) * n_new + e); };
-  jac P;
-  P.X = base.x; P.Y = base.y; P.Z = FE_ONE_M;
+  mjac P;  // modified Jacobian (curve.hpp): the chain is nothing but doublings, 4M + 4S each with W = a Z^4 carried along
+  P.X = base.x; P.Y = base.y; P.Z = FE_ONE_M; P.W = a_coef;
   fe run = FE_ONE_M;
   auto emit = [&](int point) {
 #pragma unroll
@@ -471,7 +471,7 @@ key_rows_kernel(const uint64_t* __restrict__ pqx, const uint64_t* __restrict__ p
     if (off % COMB_COLS == 0 && off / COMB_COLS < COMB_TABLES) emit((off / COMB_COLS) * COMB_ROW_POINTS + 2 * i);
     if (i < 7 && off % COMB_COLS == 1 && (off - 1) / COMB_COLS < COMB_TABLES)
       emit(((off - 1) / COMB_COLS) * COMB_ROW_POINTS + 2 * i + 1);
-    if (d < last) P = jac_dbl(P, a_coef);
+    if (d < last) mjac_dbl(P, d + 1 < last);
   }
   fe inv = fe_inv(run);
   // undo the prefix products in reverse order of emission
