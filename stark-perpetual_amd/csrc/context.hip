@@ -68,22 +68,27 @@ CtxByPointer::CtxByPointer(const void* device_ptr) : previous(tl_ctx) {
 static HostLane g_lanes[HOST_LANES];
 static std::mutex g_lane_mu;
 static std::condition_variable g_lane_cv;
-static int g_lane_next = 0;  // round-robin start: consecutive callers get lanes of consecutive contexts
+static int g_ctx_next = 0;  // round-robin over CONTEXTS: consecutive callers get lanes of consecutive devices
 
+// Within a context the LOWEST free lane is taken: a single-threaded caller then stays on one stream (cycling over
+// sixteen streams made every one-item call pay a hardware-queue switch: 0.09 -> 0.3 ms per scalar hash).
 HostLane* lane_acquire(int* ctx_index, int want_ctx) {
   std::unique_lock<std::mutex> lk(g_lane_mu);
   int got = -1;
   g_lane_cv.wait(lk, [&] {
-    for (int k = 0; k < HOST_LANES; ++k) {
-      const int i = (g_lane_next + k) % HOST_LANES;
-      if (!g_lanes[i].busy && (want_ctx < 0 || i % g_nctx == want_ctx)) {
-        got = i;
-        return true;
+    for (int c = 0; c < g_nctx && got < 0; ++c) {
+      const int ctx_i = want_ctx >= 0 ? want_ctx : (g_ctx_next + c) % g_nctx;
+      for (int i = ctx_i; i < HOST_LANES; i += g_nctx) {  // lanes of context ctx_i: i mod g_nctx == ctx_i
+        if (!g_lanes[i].busy) {
+          got = i;
+          break;
+        }
       }
+      if (want_ctx >= 0) break;
     }
-    return false;
+    return got >= 0;
   });
-  if (want_ctx < 0) g_lane_next = (got + 1) % HOST_LANES;
+  if (want_ctx < 0) g_ctx_next = (got % g_nctx + 1) % g_nctx;
   g_lanes[got].busy = true;
   *ctx_index = got % g_nctx;
   return &g_lanes[got];
