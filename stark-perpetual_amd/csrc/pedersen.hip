@@ -131,14 +131,13 @@ __device__ __forceinline__ void operand_pointers(const uint64_t* x, const uint64
   }
 }
 
-// Kernel A: one hash per thread -> projective (X, ZZ) in scratch.
-__global__ void __launch_bounds__(256, SP_ACC_WAVES)
-ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
-                      size_t ystride, size_t n, const aff_packed* __restrict__ ped, int w0, int log2e,
-                      int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
-                      uint8_t* __restrict__ status, unsigned* __restrict__ flag,
-                      const int2* __restrict__ src) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Kernel A: one hash per thread -> projective (X, ZZ) in scratch.  `e` = the thread's hash.
+__device__ __forceinline__ void
+bulk_accumulate(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
+                size_t ystride, size_t n, const aff_packed* __restrict__ ped, int w0, int log2e,
+                int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
+                uint8_t* __restrict__ status, unsigned* __restrict__ flag,
+                const int2* __restrict__ src, size_t plane, size_t e) {
   if (e >= n) return;
   const uint64_t *fx, *fy;
   operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
@@ -198,11 +197,11 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
     // only x = X / ZZ of the result is wanted: the last addition skips Y3 and ZZZ3 (3 of 10 multiplications)
     fe X3, ZZ3;
     xyzz_madd_x_only(acc, signed_aff(n1, neg1), X3, ZZ3);
-    store_limbs(sX, n, e, X3);
-    store_limbs(sZZ, n, e, ZZ3);
+    store_limbs(sX, plane, e, X3);
+    store_limbs(sZZ, plane, e, ZZ3);
   } else {
-    store_limbs(sX, n, e, acc.X);
-    store_limbs(sZZ, n, e, acc.ZZ);
+    store_limbs(sX, plane, e, acc.X);
+    store_limbs(sZZ, plane, e, acc.ZZ);
   }
   if (st != SP_HASH_OK) {
     if (status) status[e] = st;
@@ -210,6 +209,16 @@ ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict
   } else if (status) {
     status[e] = SP_HASH_OK;
   }
+}
+
+__global__ void __launch_bounds__(256, SP_ACC_WAVES)
+ped_accumulate_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
+                      size_t ystride, size_t n, const aff_packed* __restrict__ ped, int w0, int log2e,
+                      int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
+                      uint8_t* __restrict__ status, unsigned* __restrict__ flag,
+                      const int2* __restrict__ src, size_t plane) {
+  bulk_accumulate(x, y, xstride, ystride, n, ped, w0, log2e, nwin, sX, sZZ, status, flag, src, plane,
+                  (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // Kernel A', latency variant for small batches (upper tree levels, short chains): 2^LOG_L lanes
@@ -312,7 +321,8 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
                             size_t ystride, size_t n, const aff_packed* __restrict__ ped, int w0, int log2e,
                             int nwin, int32_t* __restrict__ sX, int32_t* __restrict__ sZZ,
                             uint8_t* __restrict__ status, unsigned* __restrict__ flag,
-                            const int2* __restrict__ src, uint64_t* __restrict__ out, size_t ostride) {
+                            const int2* __restrict__ src, uint64_t* __restrict__ out, size_t ostride,
+                            size_t plane) {
   constexpr int L = 1 << LOG_L;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t e_raw = gt >> LOG_L;
@@ -325,17 +335,17 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
   uint8_t st = SP_HASH_OK;
   u256 xa_plain;
   if (FUSED) {
-    // EVERY lane inverts (all lanes of a group hold the same sum after the butterfly): measured
-    // (tools/ubench/inv_lanes.hip) an inversion under a 1-lane-in-8 execution mask takes 4x as long as
-    // the same code with all lanes active - 136 vs 33 us - so the redundant copies are the fast way.
+    // EVERY lane takes part in the inversion (an inversion under a 1-lane-in-8 execution mask takes 4x as
+    // long as the same code with all lanes active, tools/ubench/inv_lanes.hip), and a DPP quad always
+    // shares ONE quad-split divsteps run: its lanes hold one sum (L >= 4), two (L = 2) or four different
+    // ones (L = 1), multiplied together first and separated afterwards (quad.hpp fe_inv_shared_quad).
     fe zz = acc.ZZ;
     const bool unhashable = fe_is_zero(zz);  // exceptional addition happened (signature.py:313 territory)
     if (unhashable) {
       zz = FE_ONE_M;
       st = SP_HASH_UNHASHABLE;
     }
-    // groups of >= 4 lanes cover whole DPP quads holding the same sum: the four lanes share one inversion
-    const fe zinv = LOG_L >= 2 ? fe_inv_quad(zz, (int)(threadIdx.x & 3)) : fe_inv(zz);
+    const fe zinv = fe_inv_shared_quad<(LOG_L >= 2 ? 0 : 2 - LOG_L)>(zz, (int)(threadIdx.x & 3));
     xa_plain = fe_pack(fe_from_mont(fe_mul(acc.X, zinv)));
   }
   if (!active || sub != 0) return;
@@ -343,9 +353,45 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
   if (FUSED) {
     st_u256(out + 4 * e * ostride, xa_plain);
   } else {
-    store_limbs(sX, n, e, acc.X);
-    store_limbs(sZZ, n, e, acc.ZZ);
+    store_limbs(sX, plane, e, acc.X);
+    store_limbs(sZZ, plane, e, acc.ZZ);
   }
+  if (status) status[e] = st;
+  if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
+}
+
+// Kernel A + A' in ONE launch (a level that is not a whole number of waves per SIMD): the first
+// `bulk_blocks` workgroups run the one-lane-per-hash body on the first n_bulk hashes (whole rounds of 65 536),
+// the others the lane-split body (unfused: X, ZZ to the same scratch planes) on the remaining `rem` hashes.
+// Both populations are resident together, so the remainder's short chain fills issue slots beside the bulk
+// waves instead of costing a launch of its own at one latency-bound wave per SIMD (measured for 163 840 and
+// 81 920 hashes, profiles/r03_levels_forest_20.txt).
+template <int LOG_L>
+__global__ void __launch_bounds__(256, SP_ACC_WAVES)
+ped_accumulate_mixed_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,
+                            size_t ystride, size_t n_bulk, size_t rem, unsigned bulk_blocks,
+                            const aff_packed* __restrict__ ped, int w0, int log2e, int nwin,
+                            int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, uint8_t* __restrict__ status,
+                            unsigned* __restrict__ flag, const int2* __restrict__ src, size_t plane) {
+  if (blockIdx.x < bulk_blocks) {
+    bulk_accumulate(x, y, xstride, ystride, n_bulk, ped, w0, log2e, nwin, sX, sZZ, status, flag, src, plane,
+                    (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+    return;
+  }
+  constexpr int L = 1 << LOG_L;
+  const size_t gt = (size_t)(blockIdx.x - bulk_blocks) * blockDim.x + threadIdx.x;
+  const size_t e_raw = gt >> LOG_L;
+  const int sub = (int)(gt & (L - 1));
+  const bool active = e_raw < rem;
+  const size_t e = n_bulk + (active ? e_raw : rem - 1);  // clamp: whole lane groups stay convergent
+  const uint64_t *fx, *fy;
+  operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
+  const xyzz acc = split_accumulate<LOG_L>(fx, fy, sub, ped, w0, log2e, nwin);
+  if (!active || sub != 0) return;
+  uint8_t st = SP_HASH_OK;
+  if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
+  store_limbs(sX, plane, e, acc.X);
+  store_limbs(sZZ, plane, e, acc.ZZ);
   if (status) status[e] = st;
   if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
 }
@@ -445,11 +491,13 @@ __global__ void __launch_bounds__(256)
 ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int32_t* __restrict__ sPre,
                   size_t n, size_t T, uint64_t* __restrict__ out, size_t ostride,
                   uint8_t* __restrict__ status, unsigned* __restrict__ flag) {
+  // T is a multiple of 4 (whole DPP quads); threads t >= n own nothing and only lend their lane to the
+  // quad's shared inversion
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
-  const size_t cnt = (n - t + T - 1) / T;  // number of elements owned
+  const size_t cnt = t < n ? (n - t + T - 1) / T : 0;  // number of elements owned
   fe run = FE_ONE_M;
-  {
+  if (cnt > 0) {
     fe znext = load_limbs(sZZ, n, t);
 #pragma unroll 1
     for (size_t j = 0; j < cnt; ++j) {
@@ -476,9 +524,16 @@ ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int
     }
   }
   // the last element's operands travel while the inversion runs
-  size_t e = t + (cnt - 1) * T;
-  fe zn = load_limbs(sZZ, n, e), pn = load_limbs(sPre, n, e), xn = load_limbs(sX, n, e);
-  fe inv = fe_inv(run);
+  size_t e = cnt > 0 ? t + (cnt - 1) * T : 0;
+  fe zn = run, pn = run, xn = run;
+  if (cnt > 0) {
+    zn = load_limbs(sZZ, n, e);
+    pn = load_limbs(sPre, n, e);
+    xn = load_limbs(sX, n, e);
+  }
+  // ONE divsteps run per DPP quad: the four threads' totals are multiplied together, inverted once with the
+  // quad-split inversion and separated again (quad.hpp) - 8 k instead of 13 k instructions per lane
+  fe inv = fe_inv_shared_quad<2>(run, (int)(threadIdx.x & 3));
 #pragma unroll 1
   for (size_t j = cnt; j-- > 0;) {
     const fe z = zn, pre = pn, xv = xn;
@@ -537,6 +592,7 @@ static bool g_split_enabled = getenv("STARKPERP_NO_SPLIT") == nullptr;  // A/B s
 static bool g_fuse_enabled = getenv("STARKPERP_NO_FUSE") == nullptr;
 static bool g_quad_enabled = getenv("STARKPERP_NO_QUAD") == nullptr;
 static bool g_quad2_enabled = getenv("STARKPERP_NO_QUAD2") == nullptr;
+static bool g_level_split = getenv("STARKPERP_NO_LEVEL_SPLIT") == nullptr;
 static size_t g_quad_max = getenv("STARKPERP_QUAD_MAX") ? (size_t)atoll(getenv("STARKPERP_QUAD_MAX")) : 2048;
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
@@ -572,7 +628,7 @@ static size_t finish_threads(size_t n) {
   size_t K = (n + g_finish_lanes - 1) / g_finish_lanes;
   if (K < 1) K = 1;
   if (K > 32) K = 32;
-  return (n + K - 1) / K;
+  return ((n + K - 1) / K + 3) & ~(size_t)3;  // whole DPP quads: a quad shares one inversion
 }
 
 void release_pedersen_state() {
@@ -591,12 +647,10 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
                      const Scratch& s, const int2* src) {
   if (n == 0) return SP_OK;
   Context& c = ctx();
-  const unsigned blocksA = (unsigned)((n + 255) / 256);
-  // sp_profile_begin/_end time the DOMINANT kernel only (ped_accumulate_kernel, the one-lane-per-hash
-  // bulk launches of n > 65536 hashes): an event pair around every small launch of a tree costs ~5 us
-  // each, 7 % of a 20-tree forest
-  const bool prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size() && n > 65536;
-  if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+  // sp_profile_begin/_end time the DOMINANT kernel only (ped_accumulate_kernel: the pure one-lane-per-hash
+  // launches, levels that are whole rounds of 65 536 hashes): an event pair around every small launch of a
+  // tree costs ~5 us each, 7 % of a 20-tree forest
+  bool prof = false;
   // lanes per hash: a SIMD issues about one VALU instruction per 5 cycles whether one wave or eight
   // live on it, so a launch takes ceil(waves / 1024) x (the dependent chain of one wave).  With
   // 1 < waves/SIMD < 2 some SIMDs get two waves and the launch takes twice the chain (measured: 81 920
@@ -632,24 +686,54 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
 #undef SP_LAUNCH_QUAD
     fused = true;
   } else if (log_l == 0 && !(g_split_enabled && g_fuse_enabled && n <= 65536)) {
-    hipLaunchKernelGGL(ped_accumulate_kernel, dim3(blocksA), dim3(256), 0, st, x, y, xs, ys, n, c.ped, w0,
-                       log2e, nwin, s.X, s.ZZ, status, flag, src);
+    // A launch takes ceil(waves / 1024) x the chain of one wave, so a level that is not a whole number of
+    // waves per SIMD pays a full extra round for its last few hashes (81 920 hashes: two rounds of the
+    // ~30 k-instruction one-lane-per-hash chain).  The level is cut instead into whole rounds of 65 536
+    // hashes for the bulk kernel and a remainder of at most 32 768 hashes that goes to the lane-split kernel
+    // (2, 4 or 8 lanes per hash, a chain of 18 k, 11 k or 9 k instructions) INSIDE THE SAME LAUNCH
+    // (ped_accumulate_mixed_kernel); both write the same scratch planes and ONE finish launch serves the level.
+    size_t n_bulk = n, rem = 0;
+    int rem_l = 0;
+    if (g_level_split && g_split_enabled && n > g_split_lanes && (n % g_split_lanes) != 0 &&
+        (n % g_split_lanes) * 2 <= g_split_lanes) {
+      rem = n % g_split_lanes;
+      rem_l = rem * 8 <= g_split_lanes ? 3 : (rem * 4 <= g_split_lanes ? 2 : 1);
+      while (rem_l > 0 && nwin < (2 << rem_l)) --rem_l;
+      if (rem_l == 0) rem = 0;
+      n_bulk = n - rem;
+    }
+    if (rem == 0) {
+      prof = g_prof.enabled && g_prof.used + 2 <= g_prof.ev.size() && n > 65536;
+      if (prof) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+      hipLaunchKernelGGL(ped_accumulate_kernel, dim3((unsigned)((n_bulk + 255) / 256)), dim3(256), 0, st, x, y, xs, ys,
+                         n_bulk, c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src, n);
+    } else {
+      const unsigned bulk_blocks = (unsigned)(n_bulk / 256);  // n_bulk is a multiple of 65 536
+      const unsigned rblocks = (unsigned)(((rem << rem_l) + 255) / 256);
+#define SP_LAUNCH_MIXED(LOGL)                                                                                     \
+  hipLaunchKernelGGL((ped_accumulate_mixed_kernel<LOGL>), dim3(bulk_blocks + rblocks), dim3(256), 0, st, x, y, xs, \
+                     ys, n_bulk, rem, bulk_blocks, c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src, n)
+      if (rem_l == 3) SP_LAUNCH_MIXED(3);
+      else if (rem_l == 2) SP_LAUNCH_MIXED(2);
+      else SP_LAUNCH_MIXED(1);
+#undef SP_LAUNCH_MIXED
+    }
+    if (prof) {
+      (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+      g_prof.units.push_back(n);
+      g_prof.used += 2;
+    }
   } else {
     const unsigned blocks = (unsigned)(((n << log_l) + 255) / 256);
     fused = g_fuse_enabled && (n << log_l) <= 65536;  // at most one wave per SIMD: the inversion costs latency only
 #define SP_LAUNCH_SPLIT(LOGL, FUSEDV)                                                                      \
   hipLaunchKernelGGL((ped_accumulate_split_kernel<LOGL, FUSEDV>), dim3(blocks), dim3(256), 0, st, x, y, xs, \
-                     ys, n, c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src, out, os)
-    if (log_l == 0) SP_LAUNCH_SPLIT(0, true);  // one lane per hash with its own inversion: saves the second launch
+                     ys, n, c.ped, w0, log2e, nwin, s.X, s.ZZ, status, flag, src, out, os, n)
+    if (log_l == 0) SP_LAUNCH_SPLIT(0, true);  // one lane per hash, four hashes share one quad-split inversion
     else if (log_l == 3) { if (fused) SP_LAUNCH_SPLIT(3, true); else SP_LAUNCH_SPLIT(3, false); }
     else if (log_l == 2) { if (fused) SP_LAUNCH_SPLIT(2, true); else SP_LAUNCH_SPLIT(2, false); }
     else { if (fused) SP_LAUNCH_SPLIT(1, true); else SP_LAUNCH_SPLIT(1, false); }
 #undef SP_LAUNCH_SPLIT
-  }
-  if (prof) {
-    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
-    g_prof.units.push_back(n);
-    g_prof.used += 2;
   }
   if (!fused) {
     const size_t T = finish_threads(n);

@@ -191,4 +191,31 @@ __device__ __forceinline__ fe fe_inv_quad(const fe& a, int k) {
   return fe_mul(fe_inv_plain_quad(canon, k), FE_R3);
 }
 
+
+// One inversion for the four lanes of a quad that hold DIFFERENT values (Montgomery's trick across the
+// lanes): the quad multiplies its values together with two DPP rounds, inverts the product once with the
+// quad-split divsteps above (6.8 k instead of 4 x 12.9 k lane-private instructions, tools/ubench/lat_parts)
+// and every lane recovers its own inverse with two more multiplications.
+//   LOG_DISTINCT = 0: the four lanes hold the same value            (fe_inv_quad)
+//                  1: lanes {0,1} hold one value, lanes {2,3} another
+//                  2: four different values
+// a: Montgomery N-form, non-zero (callers replace a zero - an exceptional addition - by one beforehand:
+// a single zero would spoil the three other inverses of its quad).  All four lanes must be active.
+template <int LOG_DISTINCT>
+__device__ __forceinline__ fe fe_inv_shared_quad(const fe& a, int k) {
+  if constexpr (LOG_DISTINCT == 0) {
+    return fe_inv_quad(a, k);
+  } else if constexpr (LOG_DISTINCT == 1) {
+    const fe other = fe_dpp<quad_perm(2, 3, 0, 1)>(a);
+    const fe pinv = fe_inv_quad(fe_mul(a, other), k);
+    return fe_mul(pinv, other);
+  } else {
+    const fe nb = fe_dpp<quad_perm(1, 0, 3, 2)>(a);       // the pair partner's value
+    const fe pair = fe_mul(a, nb);                          // a0 a1 | a0 a1 | a2 a3 | a2 a3
+    const fe opp = fe_dpp<quad_perm(2, 3, 0, 1)>(pair);    // the other pair's product
+    const fe pinv = fe_inv_quad(fe_mul(pair, opp), k);
+    return fe_mul(pinv, fe_mul(nb, opp));
+  }
+}
+
 }  // namespace sp

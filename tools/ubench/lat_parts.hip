@@ -6,6 +6,32 @@
 #include "fp29.hpp"
 using namespace sp;
 
+// MODE 7: the variable-time inversion of ONE value per wave with the divsteps batches on the SCALAR unit
+// (f0, g0, eta and the transition matrix are wave-uniform: readfirstlane makes the compiler keep the whole
+// batch loop in SGPRs / SALU instructions; only the matrix application stays on the VALU)
+__device__ __forceinline__ fe inv_scalar_steps(const fe& x) {
+  fe d = FE_ZERO, e = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+  fe f = FE_P, g = x;
+  int32_t eta = -1;
+  for (int it = 0; it < 26; ++it) {
+    trans2x2 t;
+    const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane(f.l[0]);
+    const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane(g.l[0]);
+    eta = divsteps_29_var(eta, f0, g0, t);
+    gcd_update_de(d, e, t);
+    gcd_update_fg(f, g, t);
+    int32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) nz |= g.l[i];
+    if (__builtin_amdgcn_readfirstlane(nz) == 0) break;
+  }
+  const int32_t sf = f.l[NL - 1] >> 31;
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = (d.l[i] ^ sf) - sf;
+  return fe_carry(r);
+}
+
 // MODE 0: fe_inv_plain_gcd (fixed length)  1: fe_inv_plain_gcd_var  2: divsteps_29 x 18 only
 //      3: divsteps_29_var x 18 only  4: gcd_update_de + gcd_update_fg x 18 only  5: 18 fe_mul  6: 18 fe_sqr
 template <int MODE, bool SAME>
@@ -34,6 +60,7 @@ __global__ void __launch_bounds__(64) k(const int32_t* in, int32_t* out, int rep
       acc = fe_carry(fe_add(fe_add(d, e), fe_add(f, g)));
       acc.l[8] &= 0x3ffff;
     }
+    if (MODE == 7) acc = inv_scalar_steps(fe_carry(fe_add(acc, a)));
     if (MODE == 5) for (int it = 0; it < 18; ++it) acc = fe_mul(acc, a);
     if (MODE == 6) for (int it = 0; it < 18; ++it) acc = fe_sqr(acc);
   }
@@ -66,6 +93,7 @@ int main() {
     run<0, false>("fixed-length inversion, distinct values per lane", blocks, reps);
     run<1, false>("variable-time inversion, distinct values per lane", blocks, reps);
     run<1, true>("variable-time inversion, one value per wave", blocks, reps);
+    run<7, true>("variable-time inversion, one value per wave, divsteps on the SALU", blocks, reps);
     run<2, false>("18 x divsteps_29 (fixed)", blocks, reps);
     run<3, false>("18 x divsteps_29_var, distinct", blocks, reps);
     run<3, true>("18 x divsteps_29_var, one value per wave", blocks, reps);
