@@ -182,7 +182,7 @@ def _cpu_verify_chunk(items):
     return [ref_py.verify(z, r, s, q) for z, r, s, q in items]
 
 
-def cpu_baseline_ecdsa(budget_s=3.0):
+def cpu_baseline_ecdsa(budget_s=1.5):
     """CPU legs of the ECDSA figures: the oracle's `sign` and `verify`
     (oracle/ref_py.py - the reference algorithm: RFC 6979 nonce, one affine ladder per signature, three
     251-step ladders per verification, one ext-Euclid inversion per group operation) on C1's 64 + 64
@@ -638,8 +638,8 @@ def main():
 def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
     """configs[3] (N = 1: independent 2^k-row jobs alternating over streams) and configs[4] (N > 1: ONE
     trace of N * 2^k rows sharded over the ranks by starkperp.sharded_prover - LDE units spread over the
-    ranks, one bulk all-to-all into LDE-row shards with a halo, per-shard commits + all_gather of N
-    sub-roots, a two-peer exchange per fold; every root equals the single-GPU root of the same trace)."""
+    ranks, ONE bulk all-to-all into block-cyclic LDE-row shards with halos, per-block subtrees + all_gather
+    of block roots, shard-local folds; every root equals the single-GPU root of the same trace)."""
     import random
     from starkperp import stark
     if not 10 <= args.log_rows <= 24:
@@ -757,9 +757,10 @@ def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, tr
     log_lde = total_log_rows + 2
     n_roots = 2 + (log_lde - 7)
     out = {}
+    stats = {}
 
     def step():
-        out["roots"], out["final"] = sharded_prover.commit_job(ops, dist, trace, alphas, betas)
+        out["roots"], out["final"] = sharded_prover.commit_job(ops, dist, trace, alphas, betas, stats=stats)
 
     def fence():
         torch.cuda.synchronize()
@@ -812,14 +813,19 @@ def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, tr
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32x9 (29-bit limbs) mod p", "data": "synthetic",
             "config": {"workload": "ONE 2^%d-row Pedersen-step trace sharded over %d GPUs (BASELINE.json configs[4] "
-                                   "shape; 2^24 rows = --log-rows 21 on 8 GPUs): 16 LDE units spread over the ranks, "
-                                   "all-to-all into LDE-row shards + halo, per-shard commits, sharded folds"
+                                   "shape; 2^24 rows = --log-rows 21 on 8 GPUs): 16 LDE units of 4 interpolations spread over "
+                                   "the ranks, ONE all-to-all into block-cyclic LDE-row shards with halos, per-block subtrees "
+                                   "+ all_gather of block roots, shard-local folds"
                                    % (total_log_rows, world),
                        "rows_total": 1 << total_log_rows, "rows_per_gpu": 1 << args.log_rows,
                        "exchange": {"lde_all_to_all_bytes_total": lde_bytes,
-                                    "per_commit": "all_gather of %d x 32 B sub-roots + %d top hashes on every rank"
-                                                  % (world, world - 1),
-                                    "per_fold": "two-peer exchange, the layer crosses the links once",
+                                    "per_commit": "all_gather of the block roots (32 B per block of 2^%d rows) + the top "
+                                                  "levels on every rank" % stats.get("log_block", 0),
+                                    "per_fold": "none: block-cyclic row shards keep both members of every fold pair on one "
+                                                "rank; one all_gather of 2^%d felts per rank before the replicated tail"
+                                                % stats.get("log_block", 0),
+                                    "bytes_sent_by_rank0_per_job": stats.get("bytes_sent_by_this_rank"),
+                                    "interpolations_on_rank0": stats.get("interpolations"),
                                     "backend": dist.get_backend()}},
             "sharded_roots_match_single_gpu": same,
             "roofline": dict(

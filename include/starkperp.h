@@ -283,6 +283,26 @@ int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uin
  * owns the upper half of the layer). */
 int sp_fri_fold_shard_dev(const uint64_t* fa, const uint64_t* fb, uint64_t* out, unsigned log_m, size_t i0,
                           size_t count, const uint64_t* beta_host, const uint64_t* shift_host, void* stream);
+/* Block-cyclic row shards (one job over the GPUs of a node, starkperp/sharded_prover.py; SURVEY 8(e) rows "AIR
+ * eval" and "FRI"): the LDE rows / layer positions are cut into blocks of 2^log_block consecutive indices and
+ * block b belongs to rank b mod world, local block t being global block t * world + rank.  The next-row reads
+ * of the AIR stay inside a block plus a halo of one trace row, and both members (i, i + M/2) of every fold pair
+ * live on the same rank while M/2 >= world * 2^log_block - no data moves between folds.
+ *   sp_air_eval_blocks_dev   trace_lde: 4 columns col_stride felts apart, n_blocks blocks stored 2^log_block + 4
+ *                            rows apart (block + halo); out: n_blocks * 2^log_block composition values.
+ *   sp_fri_fold_blocks_dev   fa / fb: the rank's `count` positions of the lower / upper half of the layer. */
+int sp_air_eval_blocks_dev(const uint64_t* trace_lde, size_t col_stride, size_t n_blocks, unsigned log_block,
+                           unsigned world, unsigned rank, const uint64_t* periodic_lde, unsigned log_n,
+                           const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream);
+int sp_fri_fold_blocks_dev(const uint64_t* fa, const uint64_t* fb, uint64_t* out, unsigned log_m, size_t count,
+                           unsigned log_block, unsigned world, unsigned rank, const uint64_t* beta_host,
+                           const uint64_t* shift_host, void* stream);
+/* The two halves of sp_lde_dev (blowup 1) as separate calls, so that the coset transforms of one column share a
+ * single interpolation: evaluations on <w_n> -> coefficients in BIT-REVERSED order -> evaluations on
+ * shift * <w_n> (natural order).  ncols columns 2^log_n felts apart. */
+int sp_interpolate_dev(const uint64_t* in, uint64_t* coef, unsigned ncols, unsigned log_n, void* stream);
+int sp_coset_eval_dev(const uint64_t* coef, uint64_t* out, unsigned ncols, unsigned log_n,
+                      const uint64_t* shift_host, void* stream);
 /* Commit (build-defined): Pedersen-Merkle tree over the rows of a column-major table of
  * n_rows (a power of two) x n_cols felts; leaf = left-fold chain of the row's felts (one column: the
  * felt itself).  levels receives 2 n_rows - 1 felts, leaves first, root last.  Passing a status

@@ -748,16 +748,27 @@ struct AirParams {
 // Row shards (multi-GPU): the kernel evaluates `M` points whose global index starts at row0;
 // the columns are `col_stride` felts apart and, when wrap == 0, carry a halo of one trace row (4 LDE
 // rows) after the M points (received from the rank that owns the next rows).
+// Block-cyclic row shards (log_block >= 0): the M local points are blocks of B = 2^log_block consecutive
+// LDE rows, local block t being global block t * blk_mul + blk_add (blk_mul = ranks, blk_add = this rank);
+// every block is stored with its own halo, B + 4 rows apart.
 __global__ void __launch_bounds__(256)
 air_eval_kernel(const uint64_t* __restrict__ trace /* [4][col_stride] plain */, const uint64_t* __restrict__ per /* [6][2048] plain */,
-                size_t M, size_t col_stride, size_t row0, int wrap, AirParams prm, uint64_t* __restrict__ out /* [M] plain */) {
+                size_t M, size_t col_stride, size_t row0, int wrap, AirParams prm, uint64_t* __restrict__ out /* [M] plain */,
+                int log_block, size_t blk_mul, size_t blk_add) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
-  const size_t in = wrap ? ((i + 4) & (M - 1)) : i + 4;
-  const size_t gi = row0 + i;  // global LDE index: periodic tables and 1 / Z_H repeat with it
+  size_t in = wrap ? ((i + 4) & (M - 1)) : i + 4;
+  size_t gi = row0 + i;  // global LDE index: periodic tables and 1 / Z_H repeat with it
+  size_t ii = i;         // where the point's own row is stored
+  if (log_block >= 0) {
+    const size_t t = i >> log_block, off = i & (((size_t)1 << log_block) - 1);
+    ii = t * (((size_t)1 << log_block) + 4) + off;
+    in = ii + 4;
+    gi = ((t * blk_mul + blk_add) << log_block) + off;
+  }
   auto col = [&](int c, size_t r) { return ld_fe_packed(trace + 4 * ((size_t)c * col_stride + r)); };
   auto pcol = [&](int c) { return ld_fe_packed(per + 4 * ((size_t)c * 2048 + (gi & 2047))); };
-  const fe s = col(0, i), px = col(1, i), py = col(2, i), lam = col(3, i);
+  const fe s = col(0, ii), px = col(1, ii), py = col(2, ii), lam = col(3, ii);
   const fe s_n = col(0, in), px_n = col(1, in), py_n = col(2, in);
   const fe cx = pcol(0), cy = pcol(1), step = pcol(2), mid = pcol(3), end = pcol(4), z252 = pcol(5);
   const fe one = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
@@ -789,14 +800,21 @@ air_eval_kernel(const uint64_t* __restrict__ trace /* [4][col_stride] plain */, 
 // in Montgomery form, the layer values plain: two multiplications and one halving per output.
 // Row shards: `fa` / `fb` hold f at global indices i0 .. i0 + count and i0 + M/2 .. (the second array comes
 // from the rank that owns the upper half of the layer); a whole layer is fa = f, fb = f + M/2, i0 = 0.
+// Block-cyclic shards (log_block >= 0): local position i stands for the global position
+// ((i >> log_block) * blk_mul + blk_add) * 2^log_block + (i mod 2^log_block) - the pair (i, i + M/2) of such a
+// position lives on the same rank, so the fold needs no exchange (starkperp/sharded_prover.py).
 __global__ void __launch_bounds__(256)
 fri_fold_kernel(const uint64_t* __restrict__ fa, const uint64_t* __restrict__ fb, uint64_t* __restrict__ g,
-                int log_m, size_t i0, size_t count, const uint64_t* __restrict__ tw_inv, int log_tw, fe c1, fe c2) {
+                int log_m, size_t i0, size_t count, const uint64_t* __restrict__ tw_inv, int log_tw, fe c1, fe c2,
+                int log_block, size_t blk_mul, size_t blk_add) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
+  size_t gi = i0 + i;
+  if (log_block >= 0)
+    gi = (((i >> log_block) * blk_mul + blk_add) << log_block) + (i & (((size_t)1 << log_block) - 1));
   const fe a = ld_fe_packed(fa + 4 * i);
   const fe b = ld_fe_packed(fb + 4 * i);
-  const fe winv = ld_fe_packed(tw_inv + 4 * ((i0 + i) << (log_tw - log_m)));
+  const fe winv = ld_fe_packed(tw_inv + 4 * (gi << (log_tw - log_m)));
   const fe odd = fe_mul(fe_mul(fe_sub(a, b), winv), c2);
   const fe even = fe_half(fe_add(a, b));  // c1 = 1/2: a shift instead of a multiplication
   (void)c1;
@@ -878,6 +896,27 @@ static int get_twiddles(int log_n, int inverse, const uint64_t** out, hipStream_
     it = g_tab.twiddle.emplace(key, buf).first;
   }
   *out = (const uint64_t*)it->second.ptr;
+  return SP_OK;
+}
+
+// G[c] = shift^c / n for c < n (Montgomery, packed): the coset scaling of an LDE, cached per (n, shift, blowup).
+static int coset_table(int log_n, int log_blowup, const uint64_t* shift_host, const uint64_t** G, hipStream_t st) {
+  const size_t n = (size_t)1 << log_n;
+  u256 sh;
+  std::memcpy(sh.w, shift_host, 32);
+  std::vector<uint32_t> key_words(sh.w, sh.w + 8);
+  key_words.push_back((uint32_t)log_blowup);
+  auto key = std::make_pair(log_n, key_words);
+  auto it = g_tab.coset.find(key);
+  if (it == g_tab.coset.end()) {
+    const fe shift_m = fe_to_mont(fe_unpack(sh));
+    fe nm = fe_to_mont(fe{{(int32_t)(n & LMASK), (int32_t)(n >> LB), 0, 0, 0, 0, 0, 0, 0}});
+    DeviceBuffer buf;
+    int rc = build_powers(buf, n, shift_m, fe_inv(nm), st);
+    if (rc != SP_OK) return rc;
+    it = g_tab.coset.emplace(key, buf).first;
+  }
+  *G = (const uint64_t*)it->second.ptr;
   return SP_OK;
 }
 
@@ -979,21 +1018,11 @@ int sp_lde_dev(const uint64_t* in, uint64_t* out, unsigned ncols, unsigned log_n
   ctx_lock lk(ctx().mu);
   hipStream_t st = (hipStream_t)stream;
   const size_t n = (size_t)1 << log_n, m = n << log_blowup;
-  u256 sh;
-  std::memcpy(sh.w, shift_host, 32);
-  std::vector<uint32_t> key_words(sh.w, sh.w + 8);
-  key_words.push_back(log_blowup);
-  auto key = std::make_pair((int)log_n, key_words);
-  auto it = g_tab.coset.find(key);
-  if (it == g_tab.coset.end()) {
-    const fe shift_m = fe_to_mont(fe_unpack(sh));
-    fe nm = fe_to_mont(fe{{(int32_t)(n & LMASK), (int32_t)(n >> LB), 0, 0, 0, 0, 0, 0, 0}});
-    DeviceBuffer buf;
-    int rc = build_powers(buf, n, shift_m, fe_inv(nm), st);
+  const uint64_t* G;
+  {
+    int rc = coset_table((int)log_n, (int)log_blowup, shift_host, &G, st);
     if (rc != SP_OK) return rc;
-    it = g_tab.coset.emplace(key, buf).first;
   }
-  const uint64_t* G = (const uint64_t*)it->second.ptr;
   // all columns go through each pass together (grid.y = column): 7 launches instead of 7 per column
   DeviceBuffer& work = g_tab.work[st];
   SP_HIP(work.reserve((size_t)ncols * n * 32));
@@ -1070,7 +1099,8 @@ int sp_pedersen_trace_dev(const uint64_t* x, const uint64_t* y, size_t n_hashes,
 
 static int air_eval_launch(const uint64_t* trace_lde, size_t col_stride, size_t n_points, size_t row0, int wrap,
                            const uint64_t* periodic_lde, unsigned log_n, const uint64_t* alphas_host,
-                           const uint64_t* shift_host, uint64_t* out, void* stream) {
+                           const uint64_t* shift_host, uint64_t* out, void* stream, int log_block = -1,
+                           size_t blk_mul = 1, size_t blk_add = 0) {
   AirParams prm;
   for (int k = 0; k < 11; ++k) {
     u256 a;
@@ -1092,7 +1122,7 @@ static int air_eval_launch(const uint64_t* trace_lde, size_t col_stride, size_t 
   prm.shift_x = fe_unpack(PT_SHIFT_X);
   prm.shift_y = fe_unpack(PT_SHIFT_Y);
   hipLaunchKernelGGL(air_eval_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     trace_lde, periodic_lde, n_points, col_stride, row0, wrap, prm, out);
+                     trace_lde, periodic_lde, n_points, col_stride, row0, wrap, prm, out, log_block, blk_mul, blk_add);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }
@@ -1257,11 +1287,24 @@ int sp_air_eval_ecdsa_dev(const uint64_t* trace_lde, const uint64_t* periodic_ld
   return SP_OK;
 }
 
+// The inverse twiddles of a layer of 2^log_m points are every 2^(log_tw - log_m)-th entry of the table of
+// any larger size: a job builds ONE table (for its first, largest layer) and the kernel strides through it.
+static int fri_twiddles(int log_m, const uint64_t** tw, int* log_tw, hipStream_t st) {
+  int best = -1;
+  for (auto& kv : g_tab.twiddle)
+    if (kv.first.second == 1 && kv.first.first >= log_m && kv.first.first > best) best = kv.first.first;
+  if (best < 0) best = log_m;
+  *log_tw = best;
+  return get_twiddles(best, 1, tw, st);
+}
+
 static int fri_fold_launch(const uint64_t* fa, const uint64_t* fb, uint64_t* out, unsigned log_m, size_t i0,
-                           size_t count, const uint64_t* beta_host, const uint64_t* shift_host, void* stream) {
+                           size_t count, const uint64_t* beta_host, const uint64_t* shift_host, void* stream,
+                           int log_block = -1, size_t blk_mul = 1, size_t blk_add = 0) {
   hipStream_t st = (hipStream_t)stream;
   const uint64_t* tw;
-  int rc = get_twiddles((int)log_m, 1, &tw, st);
+  int log_tw = 0;
+  int rc = fri_twiddles((int)log_m, &tw, &log_tw, st);
   if (rc != SP_OK) return rc;
   u256 b, s;
   std::memcpy(b.w, beta_host, 32);
@@ -1271,7 +1314,7 @@ static int fri_fold_launch(const uint64_t* fa, const uint64_t* fb, uint64_t* out
   const fe c2 = fe_mul(fe_to_mont(fe_unpack(b)), fe_inv(fe_mul(two, fe_to_mont(fe_unpack(s)))));
   if (count == 0) return SP_OK;
   hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, fa, fb, out,
-                     (int)log_m, i0, count, tw, (int)log_m, c1, c2);
+                     (int)log_m, i0, count, tw, log_tw, c1, c2, log_block, blk_mul, blk_add);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }
@@ -1290,9 +1333,72 @@ int sp_fri_fold_dev(const uint64_t* in, uint64_t* out, unsigned log_m, const uin
 int sp_fri_fold_shard_dev(const uint64_t* fa, const uint64_t* fb, uint64_t* out, unsigned log_m, size_t i0,
                           size_t count, const uint64_t* beta_host, const uint64_t* shift_host, void* stream) {
   SP_REQUIRE_READY();
-  if (log_m < 1 || log_m > 30 || i0 + count > ((size_t)1 << (log_m - 1))) { set_error("bad fold shard"); return SP_ERR_BAD_ARGUMENT; }
+  if (log_m < 1 || log_m > 26 || i0 + count > ((size_t)1 << (log_m - 1))) { set_error("bad fold shard"); return SP_ERR_BAD_ARGUMENT; }
   ctx_lock lk(ctx().mu);
   return fri_fold_launch(fa, fb, out, log_m, i0, count, beta_host, shift_host, stream);
+}
+
+// Block-cyclic shard of one fold (multi-GPU, starkperp/sharded_prover.py): the rank holds `count` = 2^(log_m - 1)
+// / world positions of each half of the layer as blocks of 2^log_block consecutive points, local block t being
+// global block t * world + rank.  fa / fb = the rank's part of the lower / upper half; both members of every
+// pair are local, so no data moves.  Needs 2^(log_m - 1) >= world * 2^log_block.
+int sp_fri_fold_blocks_dev(const uint64_t* fa, const uint64_t* fb, uint64_t* out, unsigned log_m, size_t count,
+                           unsigned log_block, unsigned world, unsigned rank, const uint64_t* beta_host,
+                           const uint64_t* shift_host, void* stream) {
+  SP_REQUIRE_READY();
+  const size_t half = log_m >= 1 && log_m <= 26 ? (size_t)1 << (log_m - 1) : 0;
+  if (half == 0 || world == 0 || rank >= world || log_block > 26 || count * world != half ||
+      (count & (((size_t)1 << log_block) - 1)) != 0) {
+    set_error("bad block-cyclic fold shard");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  ctx_lock lk(ctx().mu);
+  return fri_fold_launch(fa, fb, out, log_m, 0, count, beta_host, shift_host, stream, (int)log_block, world, rank);
+}
+
+// Block-cyclic shard of the composition column: n_blocks blocks of 2^log_block LDE rows (local block t =
+// global block t * world + rank), every block stored with its halo of one trace row - the four trace columns
+// are col_stride felts apart and hold n_blocks * (2^log_block + 4) rows.  out: n_blocks * 2^log_block felts.
+int sp_air_eval_blocks_dev(const uint64_t* trace_lde, size_t col_stride, size_t n_blocks, unsigned log_block,
+                           unsigned world, unsigned rank, const uint64_t* periodic_lde, unsigned log_n,
+                           const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out, void* stream) {
+  SP_REQUIRE_READY();
+  const size_t B = (size_t)1 << log_block;
+  if (log_block < 2 || log_block > 26 || world == 0 || rank >= world || col_stride < n_blocks * (B + 4) ||
+      n_blocks * B * world != ((size_t)4 << log_n)) {
+    set_error("bad block-cyclic composition shard");
+    return SP_ERR_BAD_ARGUMENT;
+  }
+  ctx_lock lk(ctx().mu);
+  return air_eval_launch(trace_lde, col_stride, n_blocks * B, 0, 0, periodic_lde, log_n, alphas_host, shift_host, out,
+                         stream, (int)log_block, world, rank);
+}
+
+// The two halves of sp_lde_dev as separate calls, so that the coset transforms of one column share ONE
+// interpolation (starkperp/sharded_prover.py: the four coset units of a column).
+//   sp_interpolate_dev  evaluations on <w_n> (natural order) -> coefficients in BIT-REVERSED order
+//   sp_coset_eval_dev   those coefficients -> evaluations on shift * <w_n> (natural order)
+int sp_interpolate_dev(const uint64_t* in, uint64_t* coef, unsigned ncols, unsigned log_n, void* stream) {
+  SP_REQUIRE_READY();
+  if (log_n > 26 || ncols == 0 || ncols > 65535) { set_error("bad interpolation size"); return SP_ERR_BAD_ARGUMENT; }
+  ctx_lock lk(ctx().mu);
+  const size_t n = (size_t)1 << log_n;
+  return ntt_column(in, coef, (int)log_n, 1, 0, 0, FE_ONE_M, (hipStream_t)stream, ncols, n, n);
+}
+
+int sp_coset_eval_dev(const uint64_t* coef, uint64_t* out, unsigned ncols, unsigned log_n, const uint64_t* shift_host,
+                      void* stream) {
+  SP_REQUIRE_READY();
+  if (log_n > 26 || ncols == 0 || ncols > 65535) { set_error("bad coset size"); return SP_ERR_BAD_ARGUMENT; }
+  ctx_lock lk(ctx().mu);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)1 << log_n;
+  const uint64_t* G;
+  int rc = coset_table((int)log_n, 0, shift_host, &G, st);
+  if (rc != SP_OK) return rc;
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)((n + 255) / 256), ncols), dim3(256), 0, st, coef, out,
+                     (int)log_n, G);
+  return ntt_column(out, out, (int)log_n, 0, 1, 0, FE_ONE_M, st, ncols, n, n);
 }
 
 }  // extern "C"

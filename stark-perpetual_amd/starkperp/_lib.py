@@ -58,6 +58,16 @@ _SIGNATURES = {
     "sp_fri_fold_shard_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint,
                                              ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p]),
+    "sp_air_eval_blocks_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint,
+                                              ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_fri_fold_blocks_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint,
+                                              ctypes.c_size_t, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_interpolate_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint,
+                                          ctypes.c_void_p]),
+    "sp_coset_eval_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
     "sp_ec_ladder_trace_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                               ctypes.c_void_p, ctypes.c_void_p]),
     "sp_air_eval_ec_ladder_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,

@@ -3,32 +3,49 @@
 single-GPU job (`stark.prove_commitments`) produces for the same trace - the sharding changes where
 rows live, never what is hashed.
 
-Stages and their exchange steps (all point-to-point groups = `ncclGroupStart / Send / Recv / End` on
-RCCL, plain send / recv on gloo):
+Row layout: BLOCK-CYCLIC.  The LDE rows (and later the positions of every FRI layer) are cut into blocks
+of B = 2^log_block consecutive indices and block b belongs to rank b mod N; local block t of rank r is
+global block t N + r.  Three things follow:
+
+  AIR       the `next row` read (i + blowup) stays inside a block except for its last trace row: every
+            block carries a halo of 4 LDE rows, shipped with the block in the one bulk exchange below.
+  FRI       a fold pairs i with i + M/2, and M / (2 B) is a multiple of N while M >= 2 B N: BOTH members of
+            every pair are on the same rank ("the first log2(M/8) folds are shard-local"; the
+            block-cyclic natural order is what the bit-reversed contiguous order is there) and the folded
+            layer is block-cyclic again - NO data moves between folds.  When a layer is down to one block
+            per rank (B N points) it is all-gathered once and the remaining folds run replicated.
+  commits   stay in natural order, so every root is the single-GPU root: the bottom log_block levels of a
+            tree lie inside blocks (per-rank forest of block subtrees), the M / B block roots are
+            all-gathered (32 B each: 1 MiB for the first layer of a 2^24-row trace at B = 2^11) and every
+            rank hashes the top of the tree (a Pedersen hash is not an ncclRedOp: "tree-reduce" =
+            all_gather + local top).
+
+Exchange steps (point-to-point groups = `ncclGroupStart / Send / Recv / End` on RCCL, plain send / recv
+on gloo):
 
   LDE       The blowup-4 coset LDE of a column is four independent size-n coset transforms
-            (out[4 j + c] = f(shift * w_4n^c * w_n^j)), so the 4 columns give 16 units that are spread
-            over the ranks with no communication ("column-sharded iNTT / LDE").  ONE bulk all-to-all then
-            turns unit outputs into LDE-ROW shards: rank r receives rows [r M/N, (r + 1) M/N) of every
-            column plus a halo of one trace row (4 LDE rows) for the `next row` reads of the AIR.
-  commit    per-shard row chains and subtree, all_gather of N x 32 B sub-roots, log2 N top levels on
-            every rank (a Pedersen hash is not an ncclRedOp: "tree-reduce" = all_gather + local top).
-  AIR       row-local on the shard + halo (sp_air_eval_shard_dev).
-  FRI       the layers stay in natural order (so that every layer root equals the single-GPU one); a
-            fold pairs i with i + M/2, i.e. the new shard of rank g needs half a shard from rank g // 2
-            and half a shard from rank g // 2 + N / 2: one two-peer exchange per fold (each layer crosses
-            the links once).  Once a layer is down to `tail_rows` rows per rank it is all-gathered and the
-            rest of the folds and commits run replicated on every rank.
+            (out[4 j + c] = f(shift * w_4n^c * w_n^j)) of ONE interpolation, so the 4 columns give 16
+            units; consecutive units go to the same rank (8 ranks: the two cosets a rank owns share their
+            column's interpolation).  ONE bulk all-to-all turns unit outputs into the block-cyclic row
+            shards (with the halos): 4 x 4n x 32 B in all, (N - 1) / N of it over the links.
+  roots     one all_gather of block roots per commitment.
+  tail      one all_gather of B N felts.
+
+`commit_job` takes the constraint and folding challenges as inputs: it is the COMMIT phase of the
+benchmark job (BASELINE.json's metric), not a prover - `stark.prove*` derives its challenges from a
+transcript of the roots; threading that through here means drawing alpha after roots[0] and beta_k after
+roots[k + 1].
 
 `ops` hides the device: `GpuOps` calls the library (the product path); tests plug in the oracle on CPU
 tensors to check the orchestration with gloo.  Build-defined like the rest of the prover: parity unpinned,
 every hash is the pinned pedersen_hash.
 """
-from typing import List, Sequence
+from typing import Sequence
 
 FIELD_PRIME = 2**251 + 17 * 2**192 + 1
 FIELD_GEN = 3
 BLOWUP = 4
+DEFAULT_LOG_BLOCK = 11
 
 
 def root_of_unity(log_n: int) -> int:
@@ -47,12 +64,43 @@ class GpuOps:
     def empty(self, *shape):
         return self.torch.empty(shape, dtype=self.torch.int64, device=self.device)
 
-    def coset_evals(self, col, shift):
-        """[n, 4] evaluations over <w_n> -> [n, 4] evaluations of the interpolant over shift * <w_n>."""
-        return self.stark.lde(col.unsqueeze(0), 0, shift)[0]
+    def interpolate(self, cols):
+        """[k, n, 4] evaluations over <w_n> -> [k, n, 4] coefficients (bit-reversed order: only
+        `coset_evals` reads them)."""
+        cols = cols.contiguous()
+        k, n = cols.shape[0], cols.shape[1]
+        coef = self.empty(k, n, 4)
+        self._lib.check(self.lib.sp_interpolate_dev(cols.data_ptr(), coef.data_ptr(), k, n.bit_length() - 1,
+                                                    self._stream()), "sp_interpolate_dev")
+        return coef
+
+    def coset_evals(self, coef, shift):
+        """[n, 4] coefficients of `interpolate` -> [n, 4] evaluations over shift * <w_n>."""
+        n = coef.shape[0]
+        out = self.empty(n, 4)
+        self._lib.check(self.lib.sp_coset_eval_dev(coef.data_ptr(), out.data_ptr(), 1, n.bit_length() - 1,
+                                                   self._lib.pack_felts([shift]), self._stream()), "sp_coset_eval_dev")
+        return out
+
+    def block_roots(self, cols, log_block):
+        """cols [W, m, 4] -> [m >> log_block, 4]: roots of the subtrees over blocks of 2^log_block row leaves
+        (leaf = left-fold chain of the row's felts; one column commits the felts themselves)."""
+        cols = cols.contiguous()
+        w, m = cols.shape[0], cols.shape[1]
+        nb = m >> log_block
+        levels = self.empty(nb * ((2 << log_block) - 1), 4)
+        if w == 1:
+            levels[:m] = cols[0]
+        else:
+            self._lib.check(self.lib.sp_pedersen_chains_dev(cols.data_ptr(), m, w, levels.data_ptr(), None,
+                                                            self._stream()), "sp_pedersen_chains_dev")
+        if log_block > 0:
+            self._lib.check(self.lib.sp_merkle_forest_dev(levels.data_ptr(), nb, log_block, None, self._stream()),
+                            "sp_merkle_forest_dev")
+        return levels[levels.shape[0] - nb:]
 
     def commit_root(self, cols):
-        """cols [W, m, 4] -> [4] root of the subtree over the m row leaves."""
+        """cols [W, m, 4] -> [4] root of the tree over the m row leaves."""
         return self.stark.commit_rows(cols)[-1]
 
     def merkle_top(self, leaves):
@@ -69,13 +117,22 @@ class GpuOps:
     def periodic(self, n):
         return self.stark.periodic_lde(n, FIELD_GEN, self.device)
 
-    def air_eval_shard(self, shard, per, log_n, row0, alphas, shift):
-        """shard [4, m + 4, 4] (m rows + halo) -> [m, 4] composition values at global rows row0 .. row0 + m."""
-        m = shard.shape[1] - 4
-        out = self.empty(m, 4)
-        self._lib.check(self.lib.sp_air_eval_shard_dev(
-            shard.data_ptr(), shard.shape[1], m, row0, per.data_ptr(), log_n, self._lib.pack_felts(alphas),
-            self._lib.pack_felts([shift]), out.data_ptr(), self._stream()), "sp_air_eval_shard_dev")
+    def air_eval_blocks(self, shard, per, log_n, log_block, world, rank, alphas, shift):
+        """shard [4, nb, B + 4, 4] (blocks with their halos) -> [nb * B, 4] composition values."""
+        nb = shard.shape[1]
+        out = self.empty(nb << log_block, 4)
+        self._lib.check(self.lib.sp_air_eval_blocks_dev(
+            shard.data_ptr(), shard.shape[1] * shard.shape[2], nb, log_block, world, rank, per.data_ptr(), log_n,
+            self._lib.pack_felts(alphas), self._lib.pack_felts([shift]), out.data_ptr(), self._stream()),
+            "sp_air_eval_blocks_dev")
+        return out
+
+    def fold_blocks(self, a, b, log_m, log_block, world, rank, beta, shift):
+        cnt = a.shape[0]
+        out = self.empty(cnt, 4)
+        self._lib.check(self.lib.sp_fri_fold_blocks_dev(
+            a.data_ptr(), b.data_ptr(), out.data_ptr(), log_m, cnt, log_block, world, rank,
+            self._lib.pack_felts([beta]), self._lib.pack_felts([shift]), self._stream()), "sp_fri_fold_blocks_dev")
         return out
 
     def fold_shard(self, a, b, log_m, i0, beta, shift):
@@ -139,90 +196,117 @@ def _all_gather_rows(dist, torch, rows, world):
     return torch.cat(parts)
 
 
+def unit_owner(u: int, n_units: int, world: int) -> int:
+    """Consecutive units (the cosets of one column) go to the same rank; with more ranks than units the
+    last ranks own none."""
+    per = -(-n_units // world)
+    return u // per
+
+
 def commit_job(ops, dist, trace_cols, alphas: Sequence[int], betas: Sequence[int], shift: int = FIELD_GEN,
-               final_log: int = 6, tail_rows: int = 1024):
-    """trace_cols: [W, n, 4] full trace columns (every rank holds the columns of the units it owns; simplest
-    is all of them).  Returns (roots, final_layer) as Python ints on every rank:
-    roots = [trace, composition, fri_1, ...] exactly like stark.prove_commitments."""
+               final_log: int = 6, log_block: int = None, stats: dict = None):
+    """trace_cols: [W, n, 4] full trace columns (a rank reads only the columns of the units it owns).
+    Returns (roots, final_layer) as Python ints on every rank: roots = [trace, composition, fri_1, ...]
+    exactly like stark.prove_commitments.  `stats`, when given, receives the bytes this rank sent."""
     torch = ops.torch
     P = FIELD_PRIME
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    assert world & (world - 1) == 0 and world <= 16
+    assert world & (world - 1) == 0, "the job needs a power-of-two number of ranks"
     ncols, n = trace_cols.shape[0], trace_cols.shape[1]
     log_n = n.bit_length() - 1
     big = BLOWUP * n
-    m = big // world      # LDE rows per rank
-    jn = n // world       # trace-domain positions per rank
-    assert jn >= 512, "a rank's shard must cover whole periods of the periodic columns"
+    if log_block is None:
+        log_block = DEFAULT_LOG_BLOCK
+    log_block = max(2, min(log_block, (big // world).bit_length() - 1))
+    B = 1 << log_block
+    B4 = B // BLOWUP          # trace-domain positions per block
+    nb_tot = big // B         # blocks in all
+    assert nb_tot % world == 0 and nb_tot >= world, "every rank needs at least one block of LDE rows"
+    nb_loc = nb_tot // world  # blocks per rank
+    m = nb_loc * B            # LDE rows per rank
     w_big = root_of_unity(log_n + 2)
+    sent = 0
 
-    # ---- LDE units -> row shards ------------------------------------------------------------------
+    # ---- LDE units -> block-cyclic row shards (with halos): the one bulk exchange ---------------------
     units = [(col, c) for col in range(ncols) for c in range(BLOWUP)]
+    mine = [u for u in range(len(units)) if unit_owner(u, len(units), world) == rank]
+    my_cols = sorted({units[u][0] for u in mine})
+    coef = ops.interpolate(torch.stack([trace_cols[c] for c in my_cols])) if my_cols else None
     sends, recvs, keep = [], [], []
-    for u, (col, c) in enumerate(units):
-        if u % world == rank:
-            ev = ops.coset_evals(trace_cols[col], shift * pow(w_big, c, P) % P)  # [n, 4]: LDE rows 4 j + c
-            for r in range(world):
-                j0 = r * jn
-                halo = (j0 + jn) % n
-                chunk = torch.cat([ev[j0 : j0 + jn], ev[halo : halo + 1]])
-                keep.append(chunk)
-                sends.append((r, chunk))
-    shard = ops.empty(ncols, m + 4, 4)
+    for u in mine:
+        col, c = units[u]
+        ev = ops.coset_evals(coef[my_cols.index(col)], shift * pow(w_big, c, P) % P)  # [n, 4]: LDE rows 4 j + c
+        blocks = ev.view(nb_loc, world, B4, 4)
+        # halo of block b = the first trace position of block b + 1 (cyclically): the `next row` of its last one
+        halos = torch.roll(ev.view(nb_tot, B4, 4)[:, 0], -1, 0).view(nb_loc, world, 4)
+        for r in range(world):
+            chunk = torch.cat([blocks[:, r], halos[:, r].unsqueeze(1)], dim=1).contiguous()  # [nb_loc, B4 + 1, 4]
+            keep.append(chunk)
+            sends.append((r, chunk))
+            if r != rank:
+                sent += chunk.numel() * 8
     bufs = []
-    for u, (col, c) in enumerate(units):
-        buf = ops.empty(jn + 1, 4)
+    for u in range(len(units)):
+        buf = ops.empty(nb_loc, B4 + 1, 4)
         bufs.append(buf)
-        recvs.append((u % world, buf))
+        recvs.append((unit_owner(u, len(units), world), buf))
     if dist is not None and world > 1:
         ops.sync()
     _exchange(dist if world > 1 else None, torch, sends, recvs, rank)
-    view = shard.view(ncols, jn + 1, BLOWUP, 4)
+    shard = ops.empty(ncols, nb_loc, B + BLOWUP, 4)
+    view = shard.view(ncols, nb_loc, B4 + 1, BLOWUP, 4)
     for (col, c), buf in zip(units, bufs):
-        view[col, :, c, :] = buf
-    del keep, bufs, sends, recvs
+        view[col, :, :, c, :] = buf  # one strided copy per unit
+    del keep, bufs, sends, recvs, coef
 
-    def combine(local_root):
-        subs = _all_gather_rows(dist, torch, local_root.reshape(1, 4), world)
-        return ops.merkle_top(subs)
+    def combine(local_roots):
+        """[nb, 4] block roots of this rank (local block t = global block t N + r) -> the root of the layer."""
+        nb = local_roots.shape[0]
+        if dist is not None and world > 1:
+            ops.sync()
+        allr = _all_gather_rows(dist, torch, local_roots, world)          # [world * nb, 4], rank-major
+        subs = allr.view(world, nb, 4).transpose(0, 1).reshape(world * nb, 4) if world > 1 else allr
+        return ops.merkle_top(subs.contiguous())
 
-    roots = [combine(ops.commit_root(shard[:, :m].contiguous()))]
+    rows = shard[:, :, :B].reshape(ncols, m, 4)
+    roots = [combine(ops.block_roots(rows, log_block))]
+    sent += (world - 1) * nb_loc * 32 if world > 1 else 0
+    del rows
     # ---- composition on the shard -------------------------------------------------------------------
     per = ops.periodic(n)
-    comp = ops.air_eval_shard(shard, per, log_n, rank * m, list(alphas), shift)
+    comp = ops.air_eval_blocks(shard, per, log_n, log_block, world, rank, list(alphas), shift)
     del shard
-    roots.append(combine(ops.commit_root(comp.unsqueeze(0))))
+    roots.append(combine(ops.block_roots(comp.unsqueeze(0), log_block)))
+    sent += (world - 1) * nb_loc * 32 if world > 1 else 0
 
-    # ---- FRI: sharded folds, then the replicated tail ---------------------------------------------
+    # ---- FRI: shard-local folds, then the replicated tail ---------------------------------------------
     layer, size, sh, k = comp, big, shift, 0
     sharded = world > 1
     while size > (1 << final_log):
-        if sharded and (size // 2) // world < tail_rows:
-            if dist is not None:
-                ops.sync()
+        if sharded and size // 2 < world * B:
+            # one block per rank is left: gathered in rank order it is the layer in natural order
+            ops.sync()
+            sent += (world - 1) * layer.shape[0] * 32
             layer = _all_gather_rows(dist, torch, layer, world)
             sharded = False
+        half = layer.shape[0] // 2
         if sharded:
-            mk = size // world          # rows per rank in this layer
-            half = mk // 2              # rows per rank in the next one
-            # old rank q: its half h goes to new rank 2 (q mod N/2) + h, as `a` from the lower half of the
-            # layer (q < N/2) or as `b` from the upper half
-            sends = [(2 * (rank % (world // 2)) + h, layer[h * half : (h + 1) * half].contiguous()) for h in (0, 1)]
-            a, b = ops.empty(half, 4), ops.empty(half, 4)
-            recvs = [(rank // 2, a), (rank // 2 + world // 2, b)]
-            ops.sync()
-            # both sides order their messages by the sender's rank, then by half
-            _exchange(dist, torch, sends, recvs, rank)
-            layer = ops.fold_shard(a, b, size.bit_length() - 1, rank * half, betas[k], sh)
+            layer = ops.fold_blocks(layer[:half], layer[half:], size.bit_length() - 1, log_block, world, rank,
+                                    betas[k], sh)
         else:
-            full_half = size // 2
-            layer = ops.fold_shard(layer[:full_half], layer[full_half:], size.bit_length() - 1, 0, betas[k], sh)
+            layer = ops.fold_shard(layer[:half], layer[half:], size.bit_length() - 1, 0, betas[k], sh)
         size //= 2
         sh = sh * sh % P
         k += 1
         if size > (1 << final_log):
-            local = ops.commit_root(layer.unsqueeze(0))
-            roots.append(combine(local) if sharded else local)
+            if sharded:
+                roots.append(combine(ops.block_roots(layer.unsqueeze(0), log_block)))
+                sent += (world - 1) * (layer.shape[0] >> log_block) * 32
+            else:
+                roots.append(ops.commit_root(layer.unsqueeze(0)))
     final = ops.to_ints(layer)
+    if stats is not None:
+        stats.update({"bytes_sent_by_this_rank": sent, "log_block": log_block, "blocks_per_rank": nb_loc,
+                      "units_owned": len(mine), "interpolations": len(my_cols)})
     return [ops.to_ints(r.reshape(1, 4))[0] for r in roots], final

@@ -37,16 +37,29 @@ class OracleOps:
     def empty(self, *shape):
         return torch.zeros(shape, dtype=torch.int64)
 
-    def coset_evals(self, col, shift):
-        vals = to_ints(col)
-        n = len(vals)
-        w = S.root_of_unity(n.bit_length() - 1)
-        coeffs = S.intt(vals, w)
+    def interpolate(self, cols):
+        out = []
+        for col in cols:
+            vals = to_ints(col)
+            out.append(to_tensor(S.intt(vals, S.root_of_unity(len(vals).bit_length() - 1))))
+        return torch.stack(out)
+
+    def coset_evals(self, coef, shift):
+        coeffs = to_ints(coef)
+        w = S.root_of_unity(len(coeffs).bit_length() - 1)
         scaled, s = [], 1
         for c in coeffs:
             scaled.append(c * s % P)
             s = s * shift % P
         return to_tensor(S.ntt(scaled, w))
+
+    def block_roots(self, cols, log_block):
+        columns = [to_ints(c) for c in cols]
+        leaves = list(columns[0])
+        for col in columns[1:]:
+            leaves = cref.opt_pedersen_hash_many(leaves, list(col))[0]
+        B = 1 << log_block
+        return to_tensor([merkle_root_ints(leaves[i : i + B]) for i in range(0, len(leaves), B)])
 
     def commit_root(self, cols):
         return to_tensor([commit_ints([to_ints(c) for c in cols])])[0]
@@ -57,19 +70,32 @@ class OracleOps:
     def periodic(self, n):
         return S.periodic_lde(n)
 
-    def air_eval_shard(self, shard, per, log_n, row0, alphas, shift):
+    def air_eval_blocks(self, shard, per, log_n, log_block, world, rank, alphas, shift):
         n = 1 << log_n
-        big = 4 * n
-        cols = [to_ints(c) for c in shard]
-        m = len(cols[0]) - 4
+        B = 1 << log_block
+        nb = shard.shape[1]
+        cols = [to_ints(c.reshape(-1, 4)) for c in shard]  # blocks stored B + 4 rows apart
         w = S.root_of_unity(log_n + 2)
         zinv = [pow((pow(shift, n, P) * pow(w, n * k, P) - 1) % P, -1, P) for k in range(4)]
         out = []
-        for i in range(m):
-            gi = row0 + i
-            cv = S.constraint_values([c[i] for c in cols], [c[i + 4] for c in cols], [t[gi % 2048] for t in per])
-            out.append(sum(a * c for a, c in zip(alphas, cv)) % P * zinv[gi % 4] % P)
-        assert row0 + m <= big
+        for t in range(nb):
+            for off in range(B):
+                ii = t * (B + 4) + off
+                gi = (t * world + rank) * B + off
+                cv = S.constraint_values([c[ii] for c in cols], [c[ii + 4] for c in cols], [tb[gi % 2048] for tb in per])
+                out.append(sum(a * c for a, c in zip(alphas, cv)) % P * zinv[gi % 4] % P)
+        return to_tensor(out)
+
+    def fold_blocks(self, a, b, log_m, log_block, world, rank, beta, shift):
+        av, bv = to_ints(a), to_ints(b)
+        w = S.root_of_unity(log_m)
+        inv2 = pow(2, -1, P)
+        B = 1 << log_block
+        out = []
+        for i, (u, v) in enumerate(zip(av, bv)):
+            gi = ((i >> log_block) * world + rank) * B + (i & (B - 1))
+            x = shift * pow(w, gi, P) % P
+            out.append(((u + v) * inv2 + beta * (u - v) % P * pow(2 * x, -1, P)) % P)
         return to_tensor(out)
 
     def fold_shard(self, a, b, log_m, i0, beta, shift):

@@ -26,7 +26,7 @@ def _worker(rank, world, port, leaves, expect, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_root_matches_single(world):
     leaves = wl.leaves(16, seed=55)
     expect = R.merkle_root(leaves)
@@ -100,7 +100,7 @@ def _sharded_tree_worker(rank, world, port, height, batches, expect, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_multi_update_matches_single_tree(world):
     """Multi-update sharded by key prefix: every rank owns the subtree of its top key
     bits, sub-roots are all-gathered, the top levels are hashed everywhere - same (old, new) root

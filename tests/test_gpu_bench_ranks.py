@@ -20,14 +20,15 @@ def _free_port():
 
 
 @pytest.mark.parametrize("workload,extra", [("merkle", ["--steps", "6", "--warmup", "2"]),
-                                            ("airfri", ["--steps", "1", "--warmup", "1", "--log-rows", "14"])])
+                                            ("airfri", ["--steps", "1", "--warmup", "1", "--log-rows", "14"]),
+                                            ("airfri", ["--steps", "1", "--warmup", "0", "--log-rows", "19"])])
 def test_two_ranks_share_one_gpu(workload, extra):
     env = dict(os.environ, STARKPERP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
                STARKPERP_WINDOW_BITS="16")  # two ranks share one GPU here: small tables whatever the caller set
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--workload", workload, "--window-bits", "0", "--no-extras", "--no-cpu-baseline"] + extra
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE line
@@ -37,5 +38,6 @@ def test_two_ranks_share_one_gpu(workload, extra):
     if workload == "merkle":
         assert d["config"]["hashes_per_step"] == 2 * 65535 + 1
         assert d["combine_matches_recomputed"] is True
-    else:  # ONE 2^15-row proof over the two ranks: its roots are the single-GPU roots of the same trace
-        assert d["config"]["rows_total"] == 1 << 15 and d["sharded_roots_match_single_gpu"] is True
+    else:  # ONE 2^15- / 2^20-row proof over the two ranks: its roots are the single-GPU roots of the same trace
+        assert d["config"]["rows_total"] == 2 << int(extra[5]) and d["sharded_roots_match_single_gpu"] is True
+        assert d["config"]["exchange"]["per_fold"].startswith("none")

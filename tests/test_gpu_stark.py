@@ -337,10 +337,64 @@ def test_range_check_air_matches_oracle_and_proves(stark):
     assert ok, why
 
 
+def test_block_cyclic_kernels_reassemble_the_single_gpu_columns(stark):
+    """The block-cyclic shard kernels of the multi-GPU job, every rank emulated in this process: the
+    composition blocks of sp_air_eval_blocks_dev and the folds of sp_fri_fold_blocks_dev, scattered back to
+    their global positions, are the single-GPU composition column and fold; sp_interpolate_dev +
+    sp_coset_eval_dev give the four cosets of sp_lde_dev; block roots + top = the single tree's root."""
+    import torch
+    from starkperp import sharded_prover
+    ops = sharded_prover.GpuOps("cuda")
+    m_hashes = 8
+    g = torch.Generator().manual_seed(41)
+    xs = torch.randint(0, 2**62, (m_hashes, 4), dtype=torch.int64, generator=g).cuda()
+    ys = torch.randint(0, 2**62, (m_hashes, 4), dtype=torch.int64, generator=g).cuda()
+    rng = random.Random(42)
+    alphas = [rng.randrange(P) for _ in range(S.N_CONSTRAINTS)]
+    beta = rng.randrange(P)
+    trace = stark.pedersen_trace(xs, ys)
+    n = trace.shape[1]
+    big = 4 * n
+    t_lde = stark.lde(trace)
+    # cosets of one interpolation == the LDE
+    coef = ops.interpolate(trace)
+    w_big = pow(3, (P - 1) // big, P)
+    for c in range(4):
+        ev = ops.coset_evals(coef[1], 3 * pow(w_big, c, P) % P)
+        assert torch.equal(ev, t_lde[1, c::4])
+    per = stark.periodic_lde(n, 3, "cuda")
+    comp = stark.air_eval(t_lde, per, n, alphas)
+    folded = stark.fri_fold(comp, beta, 3)
+    want_root = stark.commit_rows(t_lde)[-1]
+    for world, log_block in ((4, 5), (8, 7), (2, 11)):
+        B = 1 << log_block
+        nb_loc = big // B // world
+        got_comp = torch.zeros_like(comp)
+        got_fold = torch.zeros_like(folded)
+        all_roots = torch.zeros((big // B, 4), dtype=torch.int64, device="cuda")
+        for rank in range(world):
+            blocks = t_lde.view(4, nb_loc, world, B, 4)[:, :, rank]                                  # [4, nb, B, 4]
+            halos = torch.roll(t_lde.view(4, big // B, B, 4)[:, :, :4], -1, 1).view(4, nb_loc, world, 4, 4)[:, :, rank]
+            shard = torch.cat([blocks, halos], dim=2).contiguous()                                    # [4, nb, B + 4, 4]
+            part = ops.air_eval_blocks(shard, per, n.bit_length() - 1, log_block, world, rank, alphas, 3)
+            got_comp.view(nb_loc, world, B, 4)[:, rank] = part.view(nb_loc, B, 4)
+            all_roots.view(nb_loc, world, 4)[:, rank] = ops.block_roots(blocks.reshape(4, nb_loc * B, 4), log_block)
+            if big // 2 >= world * B:
+                loc = comp.view(nb_loc, world, B, 4)[:, rank].reshape(nb_loc * B, 4).contiguous()
+                h = loc.shape[0] // 2
+                f = ops.fold_blocks(loc[:h], loc[h:], big.bit_length() - 1, log_block, world, rank, beta, 3)
+                got_fold.view(nb_loc // 2, world, B, 4)[:, rank] = f.view(nb_loc // 2, B, 4)
+        assert torch.equal(got_comp, comp), (world, log_block)
+        if big // 2 >= world * B:
+            assert torch.equal(got_fold, folded), (world, log_block)
+        assert torch.equal(ops.merkle_top(all_roots), want_root), (world, log_block)
+
+
 def test_sharded_prover_on_one_rank_equals_the_plain_job(stark):
     """starkperp.sharded_prover with the library's kernels (GpuOps) and no process group: LDE as 16 coset
-    units, row-shard assembly with the halo, sp_air_eval_shard_dev, sp_fri_fold_shard_dev - the roots and the
-    final layer must be those of stark.prove_commitments on the same trace (2^14 rows)."""
+    units of 4 interpolations, block-cyclic shard assembly with halos, sp_air_eval_blocks_dev, block roots +
+    top - the roots and the final layer must be those of stark.prove_commitments on the same trace (2^14 rows),
+    with the default block size and with small blocks."""
     import torch
     from starkperp import sharded_prover
     m = 32
@@ -356,6 +410,9 @@ def test_sharded_prover_on_one_rank_equals_the_plain_job(stark):
     want_roots, want_final = stark.prove_commitments(xs, ys, alphas, betas)
     roots, final = sharded_prover.commit_job(sharded_prover.GpuOps("cuda"), None, stark.pedersen_trace(xs, ys),
                                              alphas, betas)
+    assert roots == want_roots and final == want_final
+    roots, final = sharded_prover.commit_job(sharded_prover.GpuOps("cuda"), None, stark.pedersen_trace(xs, ys),
+                                             alphas, betas, log_block=6)
     assert roots == want_roots and final == want_final
 
 

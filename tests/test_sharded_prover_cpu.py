@@ -1,7 +1,8 @@
-"""One AIR+FRI commit job sharded over 2 and 4 gloo ranks (starkperp.sharded_prover: LDE units ->
-all-to-all into row shards with a halo -> per-shard commits + sub-root all_gather -> sharded folds with
-two-peer exchanges -> replicated tail) against the same job computed in one process by the oracle.
-The stage kernels are replaced by the oracle (tests/oracle_ops.py); the exchange logic is the product's."""
+"""One AIR+FRI commit job sharded over 2, 4 and 8 gloo ranks (starkperp.sharded_prover: LDE units with one
+interpolation per column -> ONE all-to-all into block-cyclic row shards with halos -> per-block subtrees +
+all_gather of block roots -> shard-LOCAL folds -> one all_gather -> replicated tail) against the same job
+computed in one process by the oracle.  The stage kernels are replaced by the oracle (tests/oracle_ops.py);
+the layout and exchange logic is the product's.  8 ranks is the world size BASELINE.json configs[4] names."""
 import os
 import random
 
@@ -15,7 +16,7 @@ import oracle_ops as O
 P = O.P
 
 
-def _worker(rank, world, port, n_hashes, tail_rows, q):
+def _worker(rank, world, port, n_hashes, log_block, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -29,24 +30,37 @@ def _worker(rank, world, port, n_hashes, tail_rows, q):
     trace, want_roots, want_final = O.single_process_job(inputs, alphas, betas) if rank == 0 else (None, None, None)
     trace = O.S.pedersen_trace(inputs) if trace is None else trace
     cols = torch.stack([O.to_tensor(c) for c in trace])
-    roots, final = SP.commit_job(O.OracleOps(), dist, cols, alphas, betas, tail_rows=tail_rows)
+    stats = {}
+    roots, final = SP.commit_job(O.OracleOps(), dist, cols, alphas, betas, log_block=log_block, stats=stats)
     # every rank must end with the same roots; rank 0 also holds the single-process answer
     gathered = [None] * world
-    dist.all_gather_object(gathered, (roots, final))
-    ok = all(g == gathered[0] for g in gathered)
+    dist.all_gather_object(gathered, (roots, final, stats))
+    ok = all(g[:2] == gathered[0][:2] for g in gathered)
     if rank == 0:
         ok = ok and roots == want_roots and final == want_final
+        # the only bulk traffic is the LDE all-to-all: (world - 1) / world of 4 columns x 4 n felts + halos,
+        # plus block roots and ONE tail gather - no per-fold exchange
+        n = 512 * n_hashes
+        B = 1 << stats["log_block"]
+        lde_bytes = 4 * 4 * n * 32
+        total_sent = sum(g[2]["bytes_sent_by_this_rank"] for g in gathered)
+        bound = lde_bytes * (world - 1) // world * (B + 4) // B + world * (world - 1) * (160 * (4 * n // B // world) + B * 32)
+        if total_sent > bound:
+            ok = "traffic %d > %d" % (total_sent, bound)
+        # the cosets a rank owns share their column's interpolation
+        if not all(g[2]["interpolations"] == -(-g[2]["units_owned"] // 4) for g in gathered):
+            ok = "interpolations %r" % [(g[2]["interpolations"], g[2]["units_owned"]) for g in gathered]
     q.put((rank, ok, len(roots)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_hashes,tail_rows", [(2, 2, 64), (4, 4, 256), (2, 4, 1024)])
-def test_sharded_job_equals_single_process_job(world, n_hashes, tail_rows):
+@pytest.mark.parametrize("world,n_hashes,log_block", [(2, 2, 6), (4, 4, 7), (2, 4, 11), (8, 2, 4), (8, 4, 8)])
+def test_sharded_job_equals_single_process_job(world, n_hashes, log_block):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 2000) + 7 * world + n_hashes
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_hashes, tail_rows, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_hashes, log_block, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in range(world)]
