@@ -150,7 +150,7 @@ int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leaves, size_t n
 /* Persistent sparse tree: merkle_multi_update{hash_ptr=pedersen_ptr} on a tree that already holds
  * state (services/perpetual/cairo/state/state.cairo:155-173; untouched siblings come from the previous
  * state, the role of `merkle_facts`, main.cairo:61-64).  The handle keeps, per level, the nodes that
- * differ from the empty-subtree root (host memory); sp_tree_update writes leaves[i] at keys[i]
+ * differ from the empty-subtree root (an open-addressing table in HBM); sp_tree_update writes leaves[i] at keys[i]
  * (strictly increasing, < 2^height, height <= 64) in one call - one gathered launch per level - and
  * returns the root before and after.  status != 0 (SP_HASH_*) leaves the tree unchanged. */
 int sp_tree_create(unsigned height, const uint64_t* empty_leaf, int* tree);
@@ -173,10 +173,13 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
  * replace the 252 doublings + 63 additions of the per-signature ladder by 7 doublings + 31 mixed additions.  Results are
  * identical to sp_ecdsa_verify_batch for every input (same pre-asserts, same False cases).
  *   sp_ecdsa_register_keys  host pointers; qy == NULL registers x-only keys; equal keys share a
- *                           slot; slots[i] receives the slot of key i; invalid keys get a slot too
- *                           (their verifications return False / SP_VERIFY_ASSERT_CURVE as before);
- *                           SP_ERR_CACHE_FULL when no slot is free (capacity: 2^17 keys = 4 GiB, or
- *                           STARKPERP_KEY_CACHE_SLOTS), in which case nothing is registered.
+ *                           slot; slots[i] receives the slot of key i; keys that are not on the curve own
+ *                           no table - they share two sentinel slots (their verifications return False /
+ *                           SP_VERIFY_ASSERT_CURVE as before) and are remembered on the host, so an
+ *                           untrusted key stream cannot fill the cache;
+ *                           SP_ERR_CACHE_FULL when no slot is free (ceiling: 2^17 keys = 4 GiB, or
+ *                           STARKPERP_KEY_CACHE_SLOTS; the tables are allocated lazily, 128 MiB first, doubling),
+ *                           in which case nothing is registered.
  *   sp_ecdsa_verify_keyed_dev  device pointers; slots[i] names the key of signature i.
  *   sp_ecdsa_verify_batch_keyed  host pointers: registers what is new, then verifies.
  * sp_ecdsa_verify_batch itself switches to the tables when at most 40 % of a batch's signatures bring
@@ -187,7 +190,11 @@ int sp_ecdsa_verify_batch_dev(const uint64_t* z, const uint64_t* r, const uint64
  *   SP_VERIFY_POLICY_LADDER  sp_ecdsa_verify_batch never looks at, fills or allocates the key cache - the
  *                            stateless-after-init function of the reference; tables only through the
  *                            explicit calls above; selecting it also forgets the keys seen so far;
- *   SP_VERIFY_POLICY_KEYED   always through the tables (falls back to the ladder only when the cache is full).
+ *   SP_VERIFY_POLICY_KEYED   always through the tables (the ladder only for a batch with more keys than the cache holds).
+ * When the policy path (AUTO / KEYED) finds the cache full it EVICTS: a new slot generation, as after
+ * sp_ecdsa_key_cache_reset - handles obtained from sp_ecdsa_register_keys before that answer SP_VERIFY_STALE_SLOT.
+ * sp_ecdsa_verify_batch_keyed runs on a host lane: the library lock is held to register new keys and to enqueue,
+ * not while the caller waits for the device.
  * STARKPERP_VERIFY_KEYED=0 / 1 in the environment selects LADDER / KEYED as the initial policy.  The verdicts do
  * not depend on the policy. */
 #define SP_VERIFY_POLICY_AUTO 0

@@ -119,6 +119,10 @@ int shard_over_contexts(size_t n, const std::function<int(size_t, size_t)>& fn) 
   return SP_OK;
 }
 
+void lane_drain(HostLane* lane) {
+  if (lane->stream) (void)hipStreamSynchronize(lane->stream);
+}
+
 void lane_release(HostLane* lane) {
   {
     std::lock_guard<std::mutex> lk(g_lane_mu);

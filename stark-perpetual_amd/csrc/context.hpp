@@ -116,6 +116,7 @@ struct HostLane {
 };
 HostLane* lane_acquire(int* ctx_index, int want_ctx);  // want_ctx < 0: any context, round-robin
 void lane_release(HostLane* lane);
+void lane_drain(HostLane* lane);  // waits for whatever is still queued on the lane's stream
 int lane_stream(HostLane* lane);  // creates the lane's stream on the current device if needed; SP_OK or SP_ERR_HIP
 void release_host_lanes();        // sp_shutdown
 // Usage in an entry point:  LaneScope ls;  SP_REQUIRE_READY();  if (ls.open() != SP_OK) return SP_ERR_HIP;
@@ -134,8 +135,17 @@ struct LaneScope {
     lane = lane_acquire(&index, shard_context());
     ctx_select(index);
   }
+  explicit LaneScope(int want_ctx) : previous_ctx(ctx_current()) {  // a lane of one particular context
+    int index = 0;
+    lane = lane_acquire(&index, want_ctx);
+    ctx_select(index);
+  }
   int open() { return lane_stream(lane); }
   ~LaneScope() {
+    // An entry point that leaves early (a failed HIP call) may still have copies into the CALLER's buffers
+    // or kernels on the lane's staging buffer in flight: drain the stream before the lane - and, on the
+    // caller's side, the buffers - can be reused.  After a normal return the stream is idle and this is free.
+    lane_drain(lane);
     lane_release(lane);
     ctx_select(previous_ctx);
   }

@@ -406,7 +406,7 @@ constexpr int COMB_ENTRIES = 128;
 constexpr int COMB_ROW_POINTS = 15;  // Q_0, 2Q_0, Q_1, 2Q_1, ..., Q_6, 2Q_6, Q_7
 // COMB_TABLES tables per key (round 2): table t is the same 128-entry signed comb built on 2^(t * COMB_COLS) Q and
 // serves the columns t * COMB_COLS .. (t + 1) * COMB_COLS - 1 of the recoded scalar, so u2 * Q costs
-// COMB_COLS - 1 = 7 doublings + 32 mixed additions instead of 31 + 32 - HBM is plentiful: 32 KiB per key.
+// COMB_COLS - 1 = 7 doublings + 31 mixed additions instead of 31 + 32 - HBM is plentiful: 32 KiB per key.
 #ifndef SP_COMB_TABLES
 #define SP_COMB_TABLES 4
 #endif
@@ -786,11 +786,21 @@ struct KeyIdHash {
     return (size_t)h;
   }
 };
+// Slots 0 and 1 are SENTINELS that own no table: every x-only key that is not on the curve shares slot 0
+// (flag KEY_INVALID_X -> the verdict of signature.py:232-235), every point key off the curve slot 1
+// (KEY_OFF_CURVE -> :241); such keys are answered from the host map `invalid` and never take a slot of
+// their own.  The tables are allocated lazily and grow by doubling up to `limit` slots (the first scalar
+// verify does not pin 4 GiB); when the AUTO policy finds the cache full it starts a new generation (every
+// table evicted, handles of earlier generations answer SP_VERIFY_STALE_SLOT) instead of falling back to
+// the ladder for good.
+constexpr uint32_t SENTINEL_INVALID_X = 0, SENTINEL_OFF_CURVE = 1, FIRST_KEY_SLOT = 2;
 struct KeyCache {
   sp::DeviceBuffer tab, c, flag, stage;
-  size_t capacity = 0, used = 0;
+  size_t capacity = 0, used = 0, limit = 0;  // allocated slots, slots handed out (sentinels included), ceiling
   uint32_t generation = 1;
   std::unordered_map<KeyId, uint32_t, KeyIdHash> slot_of;
+  std::unordered_map<KeyId, uint32_t, KeyIdHash> invalid;  // key -> sentinel slot
+  std::vector<uint32_t> free_slots;                        // slots taken back from invalid keys
 };
 static KeyCache g_keys;
 static std::unordered_map<KeyId, uint8_t, KeyIdHash> g_seen_keys;  // unregistered keys met before (verify policy)
@@ -830,8 +840,10 @@ void release_ecdsa_state() {
   g_keys.c.release();
   g_keys.flag.release();
   g_keys.stage.release();
-  g_keys.capacity = g_keys.used = 0;
+  g_keys.capacity = g_keys.used = g_keys.limit = 0;
   g_keys.slot_of.clear();
+  g_keys.invalid.clear();
+  g_keys.free_slots.clear();
   g_seen_keys.clear();
 }
 }
@@ -894,22 +906,55 @@ static int stage_in_lane(HostLane& L, const uint64_t* const* host, int count, si
   return SP_OK;
 }
 
-static int key_cache_ready() {
-  if (g_keys.capacity) return SP_OK;
-  size_t cap = (size_t)1 << 17;  // 128 Ki keys x 4 tables x 8 KiB = 4 GiB of tables
-  if (const char* env = getenv("STARKPERP_KEY_CACHE_SLOTS")) {
-    const long long v = atoll(env);
-    if (v > 0) cap = (size_t)v;
-  }
-  if (cap > SLOT_INDEX_MASK) cap = SLOT_INDEX_MASK;  // a slot handle carries 24 index bits
-  SP_HIP(g_keys.tab.reserve(cap * KEY_ENTRIES * sizeof(aff_packed)));
-  SP_HIP(g_keys.c.reserve(cap * 32));
-  SP_HIP(g_keys.flag.reserve(cap));
-  SP_HIP(hipMemset(g_keys.flag.ptr, 0, cap));
-  g_keys.capacity = cap;
-  g_keys.used = 0;
+static int key_sentinels() {
+  const uint8_t f[2] = {KEY_INVALID_X, KEY_OFF_CURVE};
+  SP_HIP(hipMemcpy(g_keys.flag.ptr, f, 2, hipMemcpyHostToDevice));
   return SP_OK;
 }
+
+// Makes room for `slots` slots: the first call allocates 4096 (128 MiB of tables), later ones double the
+// allocation and carry the existing tables over, up to the limit (2^17 slots = 4 GiB by default,
+// STARKPERP_KEY_CACHE_SLOTS).  hipFree of the old buffers waits for kernels still reading them.
+static int key_cache_reserve(size_t slots) {
+  if (g_keys.limit == 0) {
+    size_t cap = (size_t)1 << 17;  // 128 Ki keys x 4 tables x 8 KiB = 4 GiB of tables
+    if (const char* env = getenv("STARKPERP_KEY_CACHE_SLOTS")) {
+      const long long v = atoll(env);
+      if (v > 0) cap = (size_t)v + FIRST_KEY_SLOT;
+    }
+    if (cap > SLOT_INDEX_MASK) cap = SLOT_INDEX_MASK;  // a slot handle carries 24 index bits
+    g_keys.limit = cap;
+  }
+  if (slots > g_keys.limit) slots = g_keys.limit;
+  if (slots <= g_keys.capacity) return SP_OK;
+  size_t cap = g_keys.capacity ? g_keys.capacity * 2 : 4096;
+  while (cap < slots) cap *= 2;
+  if (cap > g_keys.limit) cap = g_keys.limit;
+  DeviceBuffer tab, c, flag;
+  SP_HIP(tab.reserve(cap * KEY_ENTRIES * sizeof(aff_packed)));
+  SP_HIP(c.reserve(cap * 32));
+  SP_HIP(flag.reserve(cap));
+  SP_HIP(hipMemset(flag.ptr, 0, cap));
+  if (g_keys.used) {
+    SP_HIP(hipMemcpy(tab.ptr, g_keys.tab.ptr, g_keys.used * KEY_ENTRIES * sizeof(aff_packed), hipMemcpyDeviceToDevice));
+    SP_HIP(hipMemcpy(c.ptr, g_keys.c.ptr, g_keys.used * 32, hipMemcpyDeviceToDevice));
+    SP_HIP(hipMemcpy(flag.ptr, g_keys.flag.ptr, g_keys.used, hipMemcpyDeviceToDevice));
+  }
+  g_keys.tab.release();
+  g_keys.c.release();
+  g_keys.flag.release();
+  g_keys.tab = tab;
+  g_keys.c = c;
+  g_keys.flag = flag;
+  const bool first = g_keys.capacity == 0;
+  g_keys.capacity = cap;
+  if (first) {
+    g_keys.used = FIRST_KEY_SLOT;
+    return key_sentinels();
+  }
+  return SP_OK;
+}
+static int key_cache_ready() { return g_keys.capacity ? SP_OK : key_cache_reserve(4096); }
 
 // Builds the tables of keys [first, first + count) of the `fresh` list (host arrays), synchronously.
 static int build_key_tables(const std::vector<uint64_t>& qx, const std::vector<uint64_t>& qy,
@@ -956,18 +1001,39 @@ int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uin
   std::vector<uint8_t> fh;
   std::vector<uint32_t> fs;
   std::vector<KeyId> added;
+  std::vector<size_t> pending;  // items whose slot is decided after the tables are built
+  auto roll_back = [&]() {
+    for (size_t j = 0; j < added.size(); ++j) {
+      g_keys.slot_of.erase(added[j]);
+      g_keys.free_slots.push_back(fs[j]);
+    }
+  };
   for (size_t i = 0; i < n; ++i) {
     const KeyId id = key_id(qx + 4 * i, qy ? qy + 4 * i : nullptr);
+    auto bad = g_keys.invalid.find(id);
+    if (bad != g_keys.invalid.end()) {  // known not to be a key: the shared sentinel slot, no table
+      slots[i] = (g_keys.generation << SLOT_INDEX_BITS) | bad->second;
+      continue;
+    }
     auto it = g_keys.slot_of.find(id);
     if (it == g_keys.slot_of.end()) {
-      if (g_keys.used == g_keys.capacity) {
-        for (const KeyId& k : added) g_keys.slot_of.erase(k);  // roll this call back
-        g_keys.used -= added.size();
-        set_error("key-table cache is full (" + std::to_string(g_keys.capacity) +
-                  " slots; STARKPERP_KEY_CACHE_SLOTS, sp_ecdsa_key_cache_reset)");
-        return SP_ERR_CACHE_FULL;
+      uint32_t slot;
+      if (!g_keys.free_slots.empty()) {
+        slot = g_keys.free_slots.back();
+        g_keys.free_slots.pop_back();
+      } else {
+        if (g_keys.used == g_keys.capacity && g_keys.capacity < g_keys.limit) {
+          rc = key_cache_reserve(g_keys.used + 1);
+          if (rc != SP_OK) { roll_back(); return rc; }
+        }
+        if (g_keys.used >= g_keys.capacity) {
+          roll_back();
+          set_error("key-table cache is full (" + std::to_string(g_keys.limit - FIRST_KEY_SLOT) +
+                    " slots; STARKPERP_KEY_CACHE_SLOTS, sp_ecdsa_key_cache_reset)");
+          return SP_ERR_CACHE_FULL;
+        }
+        slot = (uint32_t)g_keys.used++;
       }
-      const uint32_t slot = (uint32_t)g_keys.used++;
       it = g_keys.slot_of.emplace(id, slot).first;
       added.push_back(id);
       fx.insert(fx.end(), qx + 4 * i, qx + 4 * i + 4);
@@ -977,11 +1043,39 @@ int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uin
       fs.push_back(slot);
     }
     slots[i] = (g_keys.generation << SLOT_INDEX_BITS) | it->second;
+    pending.push_back(i);
   }
   rc = build_key_tables(fx, fy, fh, fs);
   if (rc != SP_OK) {  // leave no slot behind whose table was never built
-    for (const KeyId& k : added) g_keys.slot_of.erase(k);
-    g_keys.used -= added.size();
+    roll_back();
+    return rc;
+  }
+  // A new key that turned out not to be one (x-only and x^3 + x + beta a non-residue, or a point off the
+  // curve: flagged by key_rows_kernel) gives its slot back and is remembered in the host map: an untrusted
+  // key stream cannot fill the cache with keys that will never verify anything.
+  if (!fs.empty()) {
+    std::vector<uint8_t> flags(fs.size());
+    bool any_bad = false;
+    for (size_t j = 0; j < fs.size(); ++j) {
+      SP_HIP(hipMemcpy(&flags[j], (const uint8_t*)g_keys.flag.ptr + fs[j], 1, hipMemcpyDeviceToHost));
+      any_bad |= flags[j] == KEY_INVALID_X || flags[j] == KEY_OFF_CURVE;
+    }
+    if (any_bad) {
+      for (size_t j = 0; j < fs.size(); ++j) {
+        if (flags[j] != KEY_INVALID_X && flags[j] != KEY_OFF_CURVE) continue;
+        const uint32_t sentinel = flags[j] == KEY_INVALID_X ? SENTINEL_INVALID_X : SENTINEL_OFF_CURVE;
+        g_keys.slot_of.erase(added[j]);
+        if (g_keys.invalid.size() > ((size_t)1 << 20)) g_keys.invalid.clear();
+        g_keys.invalid.emplace(added[j], sentinel);
+        const uint8_t zero = KEY_EMPTY;
+        SP_HIP(hipMemcpy((uint8_t*)g_keys.flag.ptr + fs[j], &zero, 1, hipMemcpyHostToDevice));
+        g_keys.free_slots.push_back(fs[j]);
+      }
+      for (size_t i : pending) {
+        auto bad = g_keys.invalid.find(key_id(qx + 4 * i, qy ? qy + 4 * i : nullptr));
+        if (bad != g_keys.invalid.end()) slots[i] = (g_keys.generation << SLOT_INDEX_BITS) | bad->second;
+      }
+    }
   }
   return rc;
 }
@@ -989,8 +1083,10 @@ int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uin
 int sp_ecdsa_key_cache_info(size_t* capacity, size_t* used) {
   SP_REQUIRE_READY();
   ctx_lock lk(ctx().mu);
-  if (capacity) *capacity = g_keys.capacity;
-  if (used) *used = g_keys.used;
+  // capacity: the ceiling of the cache in keys (the allocation grows towards it); used: keys that own a table
+  if (g_keys.limit == 0 && key_cache_reserve(0) != SP_OK) return SP_ERR_HIP;
+  if (capacity) *capacity = g_keys.limit - FIRST_KEY_SLOT;
+  if (used) *used = g_keys.capacity ? g_keys.used - FIRST_KEY_SLOT - g_keys.free_slots.size() : 0;
   return SP_OK;
 }
 
@@ -999,9 +1095,14 @@ int sp_ecdsa_key_cache_reset(void) {
   ctx_lock lk(ctx().mu);
   SP_HIP(hipDeviceSynchronize());
   g_keys.slot_of.clear();
-  g_keys.used = 0;
+  g_keys.invalid.clear();
+  g_keys.free_slots.clear();
+  g_keys.used = g_keys.capacity ? FIRST_KEY_SLOT : 0;
   g_keys.generation = g_keys.generation % 255u + 1u;
-  if (g_keys.capacity) SP_HIP(hipMemset(g_keys.flag.ptr, 0, g_keys.capacity));
+  if (g_keys.capacity) {
+    SP_HIP(hipMemset(g_keys.flag.ptr, 0, g_keys.capacity));
+    return key_sentinels();
+  }
   return SP_OK;
 }
 
@@ -1039,9 +1140,15 @@ static bool use_key_tables(const uint64_t* qx, const uint64_t* qy, size_t n) {
   if (g_verify_policy == SP_VERIFY_POLICY_LADDER) return false;  // nothing remembered, nothing allocated
   if (key_cache_ready() != SP_OK) return false;
   std::unordered_map<KeyId, int, KeyIdHash> fresh;  // unregistered keys of this batch -> occurrences
-  for (size_t i = 0; i < n; ++i) {
-    const KeyId id = key_id(qx + 4 * i, qy ? qy + 4 * i : nullptr);
-    if (g_keys.slot_of.find(id) == g_keys.slot_of.end()) ++fresh[id];
+  size_t registered = 0;                            // distinct keys of this batch that own a table already
+  {
+    std::unordered_map<KeyId, int, KeyIdHash> known;
+    for (size_t i = 0; i < n; ++i) {
+      const KeyId id = key_id(qx + 4 * i, qy ? qy + 4 * i : nullptr);
+      if (g_keys.invalid.find(id) != g_keys.invalid.end()) continue;  // answered from the sentinel slots
+      if (g_keys.slot_of.find(id) == g_keys.slot_of.end()) ++fresh[id];
+      else if (++known[id] == 1) ++registered;
+    }
   }
   size_t first_sightings = 0;  // signatures whose key is new to the library and unique in the batch
   for (const auto& kv : fresh) {
@@ -1049,9 +1156,14 @@ static bool use_key_tables(const uint64_t* qx, const uint64_t* qy, size_t n) {
   }
   if (g_seen_keys.size() > ((size_t)1 << 20)) g_seen_keys.clear();
   for (const auto& kv : fresh) g_seen_keys.emplace(kv.first, 1);
-  if (g_keys.used + fresh.size() > g_keys.capacity) return false;
-  if (g_verify_policy == SP_VERIFY_POLICY_KEYED) return true;
-  return first_sightings * 5 <= n * 2;
+  const bool keyed = g_verify_policy == SP_VERIFY_POLICY_KEYED || first_sightings * 5 <= n * 2;
+  if (!keyed) return false;
+  if (fresh.size() + registered + FIRST_KEY_SLOT > g_keys.limit) return false;  // more keys in one batch than the cache holds
+  if (g_keys.used - g_keys.free_slots.size() + fresh.size() > g_keys.limit) {
+    // full: evict everything (new generation) rather than leave the tables to the keys that came first
+    if (sp_ecdsa_key_cache_reset() != SP_OK) return false;
+  }
+  return true;
 }
 
 int sp_ecdsa_set_verify_policy(int policy) {
@@ -1076,22 +1188,31 @@ int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint
                                 const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
-  ctx_lock lk(ctx().mu);
+  // The key cache lives on the primary context: take a host lane of that context.  The lock covers the
+  // bookkeeping (registration of new keys, the launch against the current tables); the copies and the
+  // kernel run on the lane's stream and the lock is NOT held while the caller waits for them.
+  LaneScope ls(0);
+  if (ls.open() != SP_OK) return SP_ERR_HIP;
+  HostLane& L = *ls.lane;
   std::vector<uint32_t> slots(n);
-  int rc = sp_ecdsa_register_keys(qx, qy, n, slots.data());
-  if (rc != SP_OK) return rc;
-  const uint64_t* host[3] = {z, r, s};
-  uint64_t* dev[3];
-  char* extra;
-  rc = stage_in(host, 3, n, dev, n * 4 + n, &extra);
-  if (rc != SP_OK) return rc;
-  uint32_t* d_slots = (uint32_t*)extra;
-  uint8_t* d_res = (uint8_t*)(extra + n * 4);
-  SP_HIP(hipMemcpy(d_slots, slots.data(), n * 4, hipMemcpyHostToDevice));
-  rc = sp_ecdsa_verify_keyed_dev(dev[0], dev[1], dev[2], d_slots, d_res, n, 0);
-  if (rc != SP_OK) return rc;
-  SP_HIP(hipDeviceSynchronize());
-  SP_HIP(hipMemcpy(result, d_res, n, hipMemcpyDeviceToHost));
+  uint8_t* d_res = nullptr;
+  {
+    ctx_lock lk(ctx().mu);
+    int rc = sp_ecdsa_register_keys(qx, qy, n, slots.data());
+    if (rc != SP_OK) return rc;
+    const uint64_t* host[3] = {z, r, s};
+    uint64_t* dev[3];
+    char* extra;
+    rc = stage_in_lane(L, host, 3, n, dev, n * 4 + n, &extra);
+    if (rc != SP_OK) return rc;
+    uint32_t* d_slots = (uint32_t*)extra;
+    d_res = (uint8_t*)(extra + n * 4);
+    SP_HIP(hipMemcpyAsync(d_slots, slots.data(), n * 4, hipMemcpyHostToDevice, L.stream));
+    rc = sp_ecdsa_verify_keyed_dev(dev[0], dev[1], dev[2], d_slots, d_res, n, L.stream);
+    if (rc != SP_OK) return rc;
+    SP_HIP(hipMemcpyAsync(result, d_res, n, hipMemcpyDeviceToHost, L.stream));
+  }
+  SP_HIP(hipStreamSynchronize(L.stream));  // `slots` stays alive until the copy that reads it has run
   return SP_OK;
 }
 
@@ -1100,8 +1221,13 @@ int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* 
   if (shard_context() < 0) {  // (a slice of a sharded batch: the policy has spoken for the whole batch)
     SP_REQUIRE_READY();
     if (n == 0) return SP_OK;
-    ctx_lock lk(ctx().mu);  // the policy reads and fills the key cache: shared state (primary context), one caller at a time
-    if (use_key_tables(qx, qy, n)) return sp_ecdsa_verify_batch_keyed(z, r, s, qx, qy, result, n);
+    bool keyed;
+    {
+      ctx_lock lk(ctx().mu);  // the policy reads the key cache: shared state (primary context), one caller at a time
+      keyed = use_key_tables(qx, qy, n);
+    }
+    // the lock is NOT held across the call: the keyed path takes it only to register keys and to enqueue
+    if (keyed) return sp_ecdsa_verify_batch_keyed(z, r, s, qx, qy, result, n);
   }
   if (ctx_count() > 1 && shard_context() < 0 && n >= SHARD_MIN_ITEMS) {  // one slice per device, side by side
     return shard_over_contexts(n, [&](size_t off, size_t cnt) {

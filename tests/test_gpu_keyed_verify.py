@@ -122,8 +122,12 @@ def test_invalid_keys_and_cache_bookkeeping(batch):
     r, s = R.sign(z, d)
     bad_x = next(x for x in range(2, 100) if not R.is_quad_residue(x**3 + x + R.BETA))
     off_curve = (q[0], (q[1] + 1) % P)
-    assert batch.register_keys([q[0], bad_x, q[0]])[0] == batch.register_keys([q[0]])[0]
-    assert batch.key_cache_info()[1] == 2
+    slots = batch.register_keys([q[0], bad_x, q[0]])
+    assert slots[0] == slots[2] == batch.register_keys([q[0]])[0]
+    # a key that is not on the curve owns no table: it shares the sentinel slot 0 of its generation and the
+    # cache counts only q (an untrusted key stream must not be able to fill the cache)
+    assert slots[1] & 0xFFFFFF == 0 and batch.register_keys([bad_x]) == [slots[1]]
+    assert batch.key_cache_info()[1] == 1
     assert batch.verify_codes([z, z], [r, r], [s, s], [q[0], bad_x], key_tables=True) == [1, 0]
     assert batch.verify_codes([z, z], [r, r], [s, s], [q, off_curve], key_tables=True) == [1, 6]
     # pre-asserts still come first (signature.py:219-227 before :241)
@@ -131,7 +135,12 @@ def test_invalid_keys_and_cache_bookkeeping(batch):
     assert batch.verify_codes([2**251], [r], [s], [off_curve], key_tables=True) == [5]
     # msg_hash == 0 is False only after the key checks
     assert batch.verify_codes([0, 0], [r, r], [s, s], [q, off_curve], key_tables=True) == [0, 6]
-    assert batch.key_cache_info()[1] == 4
+    assert batch.key_cache_info()[1] == 2  # q as an x-only key and q as a point key; the two invalid keys none
+    # many invalid keys, seen twice each: the cache does not fill and real keys keep their tables
+    junk = [x for x in range(100, 400) if not R.is_quad_residue(x**3 + x + R.BETA)][:64]
+    for _ in range(2):
+        assert batch.verify_codes([z] * len(junk), [r] * len(junk), [s] * len(junk), junk, key_tables=True) == [0] * len(junk)
+    assert batch.key_cache_info()[1] == 2
     batch.key_cache_reset()
     assert batch.key_cache_info()[1] == 0
     assert batch.verify_codes([z], [r], [s], [q[0]], key_tables=True) == [1]
@@ -219,7 +228,8 @@ def test_stale_and_foreign_slot_handles_are_refused(batch):
 def test_full_cache_is_reported_and_the_host_entry_point_falls_back():
     """A 4-slot cache (STARKPERP_KEY_CACHE_SLOTS, read when the cache is first used - hence the
     subprocess): registering a fifth key fails with SP_ERR_CACHE_FULL and registers nothing, the
-    plain verify entry point quietly uses the ladder, and a reset makes room again."""
+    plain verify entry point quietly uses the ladder for a batch that cannot fit, a reset makes room again,
+    and the policy path evicts (new generation) rather than stay on the ladder for good."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -245,6 +255,18 @@ assert batch.verify_codes(zs, [r for r, _ in sigs], [s for _, s in sigs], keys) 
 batch.key_cache_reset()
 assert batch.verify_codes(zs[4:], [r for r, _ in sigs[4:]], [s for _, s in sigs[4:]], keys[4:], key_tables=True) == [1, 1]
 assert batch.key_cache_info() == (4, 2)
+# a full cache is not the end of the tables: when the policy wants them and the batch fits, the cache
+# starts a new generation (everything evicted) instead of sending every later batch to the ladder
+batch.key_cache_reset()
+batch.set_verify_policy(batch.VERIFY_POLICY_KEYED)
+rs, ss = [r for r, _ in sigs], [s for _, s in sigs]
+assert batch.verify_codes(zs[:3], rs[:3], ss[:3], keys[:3]) == [1, 1, 1]
+assert batch.key_cache_info() == (4, 3)
+old_handles = batch.register_keys(keys[:3])
+assert batch.verify_codes(zs[3:], rs[3:], ss[3:], keys[3:]) == [1, 1, 1]   # 3 + 3 > 4: rolled
+assert batch.key_cache_info() == (4, 3)
+assert batch.register_keys(keys[3:]) != old_handles                         # a new generation
+assert batch.verify_codes(zs[:3], rs[:3], ss[:3], keys[:3]) == [1, 1, 1]   # and again
 print("ok")
 ''' % (root, os.path.join(root, "stark-perpetual_amd"))
     env = dict(os.environ, STARKPERP_KEY_CACHE_SLOTS="4", STARKPERP_WINDOW_BITS="16")
