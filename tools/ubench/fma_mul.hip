@@ -25,8 +25,15 @@ struct dpf {
 };
 
 __device__ __forceinline__ void set_round_toward_zero_f64() {
-  // MODE register (hwreg id 1), bits [3:2] = rounding of f64 / f16 operations: 3 = toward zero
-  __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);
+  // MODE register (hwreg id 1), bits [3:2] = rounding of f64 / f16 operations: 3 = toward zero.  Inline asm on
+  // purpose: with __builtin_amdgcn_s_setreg the backend's mode-register pass "repairs" the mode (it emits
+  // s_setreg ... 0 in front of the first v_fma_f64 it sees), so the FMAs below are inline asm as well.
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
+}
+__device__ __forceinline__ double fma_rz(double a, double b, double c) {
+  double r;
+  asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
 __device__ __forceinline__ uint64_t bits_of(double d) { return (uint64_t)__double_as_longlong(d); }
@@ -35,14 +42,17 @@ __device__ __forceinline__ uint64_t bits_of(double d) { return (uint64_t)__doubl
 __device__ __forceinline__ void dpf_product_raw(const dpf& a, const dpf& b, uint64_t col[10]) {
   const double C1 = __longlong_as_double(0x4670000000000000LL);  // 2^104
   const double C2 = __longlong_as_double(0x4670000000000001LL);  // 2^104 + 2^52
+  // set here, not once per kernel: the backend's mode-register pass puts the default rounding back after
+  // the u64 -> f64 conversions of the operand generator (one SALU instruction per product)
+  set_round_toward_zero_f64();
 #pragma unroll
   for (int k = 0; k < 10; ++k) col[k] = 0;
 #pragma unroll
   for (int i = 0; i < 5; ++i)
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      const double hi = __builtin_fma(a.l[i], b.l[j], C1);
-      const double lo = __builtin_fma(a.l[i], b.l[j], C2 - hi);
+      const double hi = fma_rz(a.l[i], b.l[j], C1);
+      const double lo = fma_rz(a.l[i], b.l[j], C2 - hi);
       col[i + j + 1] += bits_of(hi);
       col[i + j] += bits_of(lo);
     }
@@ -139,6 +149,17 @@ __global__ void __launch_bounds__(64) check_kernel(unsigned long long* mismatche
     bool same = true;
     for (int i = 0; i < 17; ++i) same &= w29[i] == w52[i];
     bad += same ? 0 : 1;
+    if (!same && r == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+      printf("a52:"); for (int i = 0; i < 5; ++i) printf(" %llx", (unsigned long long)da.l[i]);
+      printf("\nb52:"); for (int i = 0; i < 5; ++i) printf(" %llx", (unsigned long long)db.l[i]);
+      printf("\na29:"); for (int i = 0; i < 9; ++i) printf(" %x", fa.l[i]);
+      printf("\nb29:"); for (int i = 0; i < 9; ++i) printf(" %x", fb.l[i]);
+      printf("\ncol52:"); for (int i = 0; i < 10; ++i) printf(" %llx", (unsigned long long)col[i]);
+      printf("\ncol29:"); for (int i = 0; i < 17; ++i) printf(" %llx", (unsigned long long)t.c[i]);
+      printf("\nw29:"); for (int i = 0; i < 17; ++i) printf(" %x", w29[i]);
+      printf("\nw52:"); for (int i = 0; i < 17; ++i) printf(" %x", w52[i]);
+      printf("\n");
+    }
   }
   if (bad) atomicAdd(mismatches, bad);
 }
@@ -160,16 +181,26 @@ __global__ void __launch_bounds__(64) time_kernel(uint32_t* out, int reps) {
       cols t;
       cols_zero(t);
       cols_mac(t, fa, fb);
-      // feed a few low bits back so that the products form a chain and cannot be hoisted
-      fa.l[0] = (fa.l[0] ^ (int32_t)((uint32_t)t.c[16] & 1u)) & LMASK;
-      fa.l[4] = (fa.l[4] ^ (int32_t)((uint32_t)t.c[8] & 1u)) & LMASK;
-      sink += (uint32_t)t.c[3];
+      // feed one bit of every column back into every limb: the products form a chain and no partial product
+      // is loop-invariant (with two limbs fed the compiler hoisted 49 of the 81 products out of the loop)
+#pragma unroll
+      for (int k = 0; k < NL; ++k)
+        fa.l[k] = (fa.l[k] ^ (int32_t)((uint32_t)(t.c[k] ^ (k + 8 < 17 ? t.c[k + 8] : 0)) & 1u)) & LMASK;
+      fe_pin(fa);  // as fe_mul's results are: every product stays ONE v_mad_i64_i32 (fp29.hpp)
+      int64_t all = 0;  // every column is live (16 extra 64-bit xors)
+#pragma unroll
+      for (int k = 0; k < 17; ++k) all ^= t.c[k];
+      sink += (uint32_t)all;
     } else {
       uint64_t col[10];
       dpf_product_raw(da, db, col);
-      da.l[0] = __longlong_as_double(__double_as_longlong(da.l[0]) ^ (long long)(col[9] & 1u));
-      da.l[2] = __longlong_as_double(__double_as_longlong(da.l[2]) ^ (long long)(col[4] & 1u));
-      sink += (uint32_t)col[2];
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        da.l[k] = __longlong_as_double(__double_as_longlong(da.l[k]) ^ (long long)((col[k] ^ col[k + 5]) & 1u));
+      uint64_t all = 0;  // every column is live (9 extra 64-bit xors)
+#pragma unroll
+      for (int k = 0; k < 10; ++k) all ^= col[k];
+      sink += (uint32_t)all;
     }
   }
   for (int i = 0; i < NL; ++i) sink += (uint32_t)fa.l[i];
@@ -208,8 +239,9 @@ int main() {
   printf("DPF product columns vs integer columns (cols_mac) on %d random 260-bit pairs: %llu mismatches\n", 256 * 64 * 64, h);
   for (int blocks : {256, 4096, 8192}) {
     run<0>("fe_mul (81 + 30 mads + carries = 174 instr), chained", blocks, 2000);
-    run<1>("cols_mac only (81 v_mad_i64_i32): product phase of fe_mul", blocks, 2000);
-    run<2>("DPF product phase (25 x (2 fma + sub + 2 add64) = 125 instr)", blocks, 2000);
+    // (MODE 1, the integer product phase alone, is not printed: with only one bit of every column live the
+    // compiler legitimately narrows the 81 products to v_mul_lo_u32 - fe_mul above is the honest integer figure)
+    run<2>("DPF product phase (125 instr) + 15 feedback ops", blocks, 2000);
   }
   return h == 0 ? 0 : 1;
 }
