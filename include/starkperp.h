@@ -271,6 +271,23 @@ int sp_range_check_trace_dev(const uint64_t* values, size_t n_values, uint64_t* 
 int sp_air_eval_range_check_dev(const uint64_t* trace_lde, const uint64_t* periodic_lde, unsigned log_n,
                                 const uint64_t* alphas_host, const uint64_t* shift_host, uint64_t* out,
                                 void* stream);
+/* The range-check BUILTIN as an AIR segment (oracle/stark_ref.py "rc16"; what the Cairo program's
+ * `range_check` builtin - services/perpetual/cairo/main.cairo:1, used at order/order.cairo:53-56 - asserts):
+ * a value < 2^128 is eight 16-bit limbs, 8 rows of the columns a (limb), acc (running value) and s (the limb
+ * column SORTED: neighbours differ by 0 or 1, first = rc_min, last = rc_max); after these are committed a
+ * challenge z is drawn and the second-phase column p_i = prod_{j <= i} (z - a_j) / (z - s_j) proves that s is a
+ * permutation of a.  sp_rc16_trace_dev writes a and acc (cols = 2 columns of 8 * n_values felts; the caller
+ * sorts a into s); sp_rc16_product_dev writes p (n felts); sp_air_eval_rc16_dev the rc16 part of the
+ * composition column (cols: a, acc, s of 4 * 2^log_n felts each; periodic_lde: 2 tables of 32 felts;
+ * alphas_host: 8 felts) - transition, all-but-last-row and boundary constraints.  sp_felt_add_dev sums the
+ * composition parts of the segments of a combined trace. */
+int sp_rc16_trace_dev(const uint64_t* values, size_t n_values, uint64_t* cols, void* stream);
+int sp_rc16_product_dev(const uint64_t* a, const uint64_t* s, size_t n, const uint64_t* z_host, uint64_t* p,
+                        void* stream);
+int sp_air_eval_rc16_dev(const uint64_t* cols, const uint64_t* p, const uint64_t* periodic_lde, unsigned log_n,
+                         const uint64_t* alphas_host, const uint64_t* shift_host, const uint64_t* z_host,
+                         uint64_t rc_min, uint64_t rc_max, uint64_t* out, void* stream);
+int sp_felt_add_dev(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, void* stream);
 /* ECDSA-verification AIR (what verify() mimics, signature.py:217-260): three linked EC ladders per
  * signature - z G from MINUS_SHIFT_POINT, r Q and w B from SHIFT_POINT with B = zG + rQ (:252-254) - and
  * x(wB - SHIFT_POINT) == r (:255); 1024 rows of ten columns m, px, py, qx, qy, la, ld, cx, cy, cr per

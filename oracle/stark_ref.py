@@ -529,3 +529,254 @@ def verify_proof(proof, hash2=R.pedersen_hash, final_log=6, air=None):
             s = s * s % P
             mk //= 2
     return True, "ok"
+
+
+# =================================================================================================
+# Range-check BUILTIN encoding and the combined builtin trace (build-defined, parity
+# unpinned).  The Cairo program is `%builtins output pedersen range_check ecdsa`
+# (services/perpetual/cairo/main.cairo:1); its range checks sit on the order path
+# (order/order.cairo:53-56: assert_nn / assert_nn_le of the 128-bit fields of the message hash).
+#
+# rc16 AIR.  A range-checked value is eight 16-bit limbs; every limb is one cell of the column `a`, and the
+# statement "every cell lies in [rc_min, rc_max] (a sub-range of [0, 2^16))" is proved as the builtin proves
+# it: a second column `s` holds the same cells SORTED, neighbours differ by 0 or 1, s starts at rc_min and ends
+# at rc_max, and a permutation argument ties the two columns together - after the two columns are committed a
+# challenge z is drawn and a third column p (the SECOND committed phase) accumulates
+#     p_i = prod_{j <= i} (z - a_j) / (z - s_j),      p_{n-1} = 1.
+# Holes between rc_min and rc_max are filled by the prover with extra range-checked values (the builtin's
+# unused cells).  Columns: a (limb), acc (running value: acc = a on limb 0, acc' = 2^16 acc + a' inside a
+# value, acc on limb 7 = the 128-bit value), s; phase 2: p.  Rows: 8 per value.
+#   C0  first8 (acc - a)                                    / Z_H
+#   C1  step8 (acc' - 2^16 acc - a')                        / Z_H
+#   C2  (s' - s)(s' - s - 1)              (x - g^(n-1))     / Z_H      every row but the last
+#   C3  (p' (z - s') - p (z - a'))        (x - g^(n-1))     / Z_H
+#   C4  p (z - s) - (z - a)               / (x - 1)                    first row
+#   C5  p - 1                             / (x - g^(n-1))              last row
+#   C6  s - rc_min                        / (x - 1)
+#   C7  s - rc_max                        / (x - g^(n-1))
+# =================================================================================================
+RC16_LIMBS = 8
+RC16_BITS = 16
+N_RC16_CONSTRAINTS = 8
+
+
+def rc16_fill(values, total_values):
+    """values (each < 2^128) -> (padded list of `total_values` values, rc_min, rc_max): the padding values'
+    limbs fill the holes of the limb range so that the sorted column can walk it in steps of 0 or 1."""
+    assert all(0 <= v < 1 << (RC16_LIMBS * RC16_BITS) for v in values) and values
+    limbs = {(v >> (RC16_BITS * k)) & 0xFFFF for v in values for k in range(RC16_LIMBS)}
+    lo, hi = min(limbs), max(limbs)
+    holes = [x for x in range(lo, hi + 1) if x not in limbs]
+    pads = []
+    for i in range(0, len(holes), RC16_LIMBS):
+        group = holes[i : i + RC16_LIMBS]
+        group += [lo] * (RC16_LIMBS - len(group))
+        pads.append(sum(l << (RC16_BITS * (RC16_LIMBS - 1 - k)) for k, l in enumerate(group)))
+    assert len(values) + len(pads) <= total_values, "the trace is too short to fill the holes of the limb range"
+    filler = sum(lo << (RC16_BITS * k) for k in range(RC16_LIMBS))
+    return list(values) + pads + [filler] * (total_values - len(values) - len(pads)), lo, hi
+
+
+def rc16_trace(values):
+    """[a, acc, s] for an already padded list of values (rc16_fill)."""
+    a, acc = [], []
+    for v in values:
+        for k in range(RC16_LIMBS):
+            run = v >> (RC16_BITS * (RC16_LIMBS - 1 - k))
+            acc.append(run)
+            a.append(run & 0xFFFF)
+    return [a, acc, sorted(a)]
+
+
+def rc16_product_column(a, s, z):
+    p, run = [], 1
+    for x, y in zip(a, s):
+        run = run * ((z - x) % P) % P * pow((z - y) % P, -1, P) % P
+        p.append(run)
+    return p
+
+
+def rc16_periodic_columns():
+    return [[1, 0, 0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1, 0]]
+
+
+def rc16_constraint_values(cur, nxt, per, pcur, pnxt, z, rc_min, rc_max):
+    """[C0 .. C7] numerators (see the table above); cur / nxt = (a, acc, s) at the row and the next one."""
+    a, acc, s = cur
+    an, accn, sn = nxt
+    first8, step8 = per
+    d = (sn - s) % P
+    return [first8 * (acc - a) % P,
+            step8 * (accn - (acc << RC16_BITS) - an) % P,
+            d * (d - 1) % P,
+            (pnxt * (z - sn) - pcur * (z - an)) % P,
+            (pcur * (z - s) - (z - a)) % P,
+            (pcur - 1) % P,
+            (s - rc_min) % P,
+            (s - rc_max) % P]
+
+
+def rc16_composition_value(alphas, cv, x, zinv, g_last):
+    """The rc16 part of the composition column at the point x (zinv = 1 / (x^n - 1))."""
+    trans = (alphas[0] * cv[0] + alphas[1] * cv[1] + (alphas[2] * cv[2] + alphas[3] * cv[3]) % P * (x - g_last)) % P
+    first = (alphas[4] * cv[4] + alphas[6] * cv[6]) % P * pow((x - 1) % P, -1, P)
+    last = (alphas[5] * cv[5] + alphas[7] * cv[7]) % P * pow((x - g_last) % P, -1, P)
+    return (trans * zinv + first + last) % P
+
+
+def rc16_composition_on_coset(cols_lde, p_lde, n, alphas, z, rc_min, rc_max, shift=GEN):
+    m = BLOWUP * n
+    w = root_of_unity(m.bit_length() - 1)
+    g_last = pow(root_of_unity(n.bit_length() - 1), n - 1, P)
+    per_lde = [lde(col, BLOWUP, pow(shift, n // 8, P)) for col in rc16_periodic_columns()]
+    zinv = [pow((pow(shift, n, P) * pow(w, n * k, P) - 1) % P, -1, P) for k in range(BLOWUP)]
+    out, x = [], shift
+    for i in range(m):
+        j = (i + BLOWUP) % m
+        cv = rc16_constraint_values([c[i] for c in cols_lde], [c[j] for c in cols_lde], [t[i % 32] for t in per_lde],
+                                    p_lde[i], p_lde[j], z, rc_min, rc_max)
+        out.append(rc16_composition_value(alphas, cv, x, zinv[i % BLOWUP], g_last))
+        x = x * w % P
+    return out
+
+
+# ---- one trace for the three builtins ------------------------------------------------------------
+# Segments side by side at fixed ratios: per 1024 rows two Pedersen hashes (4 columns), one ECDSA verification
+# (10 columns) and 128 rc16 cells = 16 range-checked values (3 columns + 1 in the second phase).  The
+# composition is the sum of the three AIRs' compositions with independent coefficients.
+BUILTIN_SEGMENTS = [("pedersen", 4, N_CONSTRAINTS), ("ecdsa", 10, N_ECDSA_CONSTRAINTS), ("rc16", 3, N_RC16_CONSTRAINTS)]
+
+
+def builtin_layout(segments):
+    """[(air, first column, columns, first alpha, alphas)] for the named segments, in BUILTIN_SEGMENTS order."""
+    out, col, al = [], 0, 0
+    for air, ncols, nalpha in BUILTIN_SEGMENTS:
+        if air in segments:
+            out.append((air, col, ncols, al, nalpha))
+            col += ncols
+            al += nalpha
+    return out
+
+
+def verify_builtins_proof(proof, hash2=R.pedersen_hash, final_log=6):
+    """Verifier of starkperp.stark.prove_builtins: two committed phases (the builtin columns, then the
+    permutation product of the range-check segment drawn after the challenge z), one composition over all
+    segments, FRI.  Returns (ok, reason)."""
+    n, seed, shift = proof["n"], proof["seed"], proof["shift"]
+    segments = proof["segments"]
+    layout = builtin_layout(segments)
+    if [s for s, *_ in layout] != list(segments) or not layout:
+        return False, "segments"
+    n_cols = sum(c for _, _, c, _, _ in layout)
+    n_alphas = sum(a for *_, a in layout)
+    has_rc = "rc16" in segments
+    pub = proof["public_inputs"]
+    if has_rc:
+        rc_min, rc_max = pub["rc_min"], pub["rc_max"]
+        if not (0 <= rc_min <= rc_max < 1 << RC16_BITS) or n % 8:
+            return False, "public inputs"
+    if "ecdsa" in segments:
+        sigs = pub["signatures"]
+        if n % 1024 or len(sigs) != n // 1024:
+            return False, "public inputs"
+        for z_, r_, s_, qx, qy in sigs:
+            if not (1 <= s_ < R.EC_ORDER and 1 <= r_ < 2**251 and 0 < z_ < 2**251 and R.is_point_on_curve(qx, qy)):
+                return False, "public inputs"
+            if not 1 <= R.inv_mod_curve_size(s_) < 2**251:
+                return False, "public inputs"
+    if "pedersen" in segments and n % 512:
+        return False, "public inputs"
+    m = BLOWUP * n
+    log_m = m.bit_length() - 1
+    n_layers = log_m - final_log
+    roots, final = proof["layer_roots"], proof["final_layer"]
+    if len(roots) != n_layers or len(final) != 1 << final_log:
+        return False, "shape"
+    flat_pub = [len(segments)] + [BUILTIN_SEGMENTS.index(next(b for b in BUILTIN_SEGMENTS if b[0] == s)) for s in segments]
+    if has_rc:
+        flat_pub += [rc_min, rc_max]
+    if "ecdsa" in segments:
+        flat_pub += [v for sig in pub["signatures"] for v in sig]
+    tr = Transcript("builtins", n, shift, seed, flat_pub)
+    tr.absorb("phase1_root", proof["phase1_root"])
+    z = tr.challenge("rc16_z") if has_rc else 0
+    if has_rc:
+        tr.absorb("phase2_root", proof["phase2_root"])
+    alphas = [tr.challenge("alpha", k) for k in range(n_alphas)]
+    betas = []
+    for k in range(n_layers):
+        tr.absorb("layer_root", roots[k])
+        betas.append(tr.challenge("beta", k + 1))
+    tr.absorb("final_layer", *final)
+    w = root_of_unity(log_m)
+    g_last = pow(root_of_unity(n.bit_length() - 1), n - 1, P)
+    zinv = [pow((pow(shift, n, P) * pow(w, n * k, P) - 1) % P, -1, P) for k in range(BLOWUP)]
+    pers = {}
+    for air, *_ in layout:
+        pers[air] = ([lde(c, BLOWUP, pow(shift, n // 8, P)) for c in rc16_periodic_columns()] if air == "rc16"
+                     else periodic_lde(n, shift, air))
+    fshift = shift
+    for _ in range(n_layers):
+        fshift = fshift * fshift % P
+    if not poly_degree_bound_check(final, fshift, (3 * n >> n_layers) - 1):
+        return False, "final layer degree"
+    for qi, q in enumerate(proof["queries"]):
+        j = tr.challenge("query", qi, modulus=m // 2)
+        if q["index"] != j:
+            return False, "query index"
+        want_rows = [j, (j + BLOWUP) % m, j + m // 2, (j + m // 2 + BLOWUP) % m]
+        if [t["row"] for t in q["phase1"]] != want_rows or (has_rc and [t["row"] for t in q["phase2"]] != want_rows):
+            return False, "opened rows"
+        for t in q["phase1"]:
+            if len(t["values"]) != n_cols:
+                return False, "opened rows"
+            leaf = t["values"][0]
+            for v in t["values"][1:]:
+                leaf = hash2(leaf, v)
+            if _root_from_path(leaf, t["row"], t["path"], hash2) != proof["phase1_root"]:
+                return False, "phase 1 path"
+        if has_rc:
+            for t in q["phase2"]:
+                if _root_from_path(t["value"], t["row"], t["path"], hash2) != proof["phase2_root"]:
+                    return False, "phase 2 path"
+        for side, pos in enumerate((j, j + m // 2)):
+            cur, nxt = q["phase1"][2 * side]["values"], q["phase1"][2 * side + 1]["values"]
+            x = shift * pow(w, pos, P) % P
+            expect = 0
+            for air, c0, nc, a0, na in layout:
+                al = alphas[a0 : a0 + na]
+                if air == "rc16":
+                    pv = [tab[pos % 32] for tab in pers[air]]
+                    cv = rc16_constraint_values(cur[c0 : c0 + nc], nxt[c0 : c0 + nc], pv, q["phase2"][2 * side]["value"],
+                                                q["phase2"][2 * side + 1]["value"], z, rc_min, rc_max)
+                    expect += rc16_composition_value(al, cv, x, zinv[pos % BLOWUP], g_last)
+                else:
+                    spec = AIRS[air]
+                    pv = [tab[pos % (BLOWUP * spec["period"])] for tab in pers[air]]
+                    cv = spec["constraints"](cur[c0 : c0 + nc], nxt[c0 : c0 + nc], pv)
+                    expect += sum(a * c for a, c in zip(al, cv)) % P * zinv[pos % BLOWUP]
+            if q["layers"][0][side]["value"] != expect % P:
+                return False, "composition value"
+        jk, s, mk = j, shift, m
+        for k in range(n_layers):
+            jk %= mk // 2
+            a, b = q["layers"][k]
+            if (a["pos"], b["pos"]) != (jk, jk + mk // 2):
+                return False, "layer positions"
+            for o in (a, b):
+                if _root_from_path(o["value"], o["pos"], o["path"], hash2) != roots[k]:
+                    return False, "layer path"
+            wk = root_of_unity(mk.bit_length() - 1)
+            xk = s * pow(wk, jk, P) % P
+            folded = ((a["value"] + b["value"]) * pow(2, -1, P)
+                      + betas[k] * (a["value"] - b["value"]) % P * pow(2 * xk, -1, P)) % P
+            if k + 1 < n_layers:
+                nxt_pair = q["layers"][k + 1]
+                nxt_val = nxt_pair[0]["value"] if jk < mk // 4 else nxt_pair[1]["value"]
+            else:
+                nxt_val = final[jk]
+            if folded != nxt_val:
+                return False, "fold consistency at layer %d" % k
+            s = s * s % P
+            mk //= 2
+    return True, "ok"

@@ -30,6 +30,7 @@ namespace sp {
 void release_pedersen_state();  // per-stream scratch, profiling events (pedersen.hip)
 void release_merkle_state();    // sparse-update staging (merkle.hip)
 void release_stark_state();     // twiddle / coset tables, work buffers (stark.hip)
+void release_builtin_state();   // work buffers of the builtin segments (builtins.hip)
 void release_ecdsa_state();     // per-signature window tables (ecdsa.hip)
 void release_tree_state();      // persistent sparse trees (merkle.hip)
 
@@ -486,6 +487,7 @@ void sp_shutdown(void) {
   sp::release_pedersen_state();
   sp::release_merkle_state();
   sp::release_stark_state();
+  sp::release_builtin_state();
   sp::release_ecdsa_state();
   sp::release_tree_state();
   sp::release_host_lanes();

@@ -133,6 +133,18 @@ AIRS = {
 }
 
 
+def rc16_periodic_columns():
+    """first8 (limb 0 of a value), step8 (the next row belongs to the same value): oracle/stark_ref.py rc16."""
+    return [[1, 0, 0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1, 0]]
+
+
+N_RC16_CONSTRAINTS = 8
+RC16_LIMBS = 8
+AIRS["rc16"] = {"n_cols": 3, "period": 8, "n_constraints": N_RC16_CONSTRAINTS, "periodic": rc16_periodic_columns,
+                "eval": None}  # evaluated by air_eval_rc16 (it needs the second-phase column and the challenge z)
+BUILTIN_SEGMENTS = ["pedersen", "ecdsa", "rc16"]  # column order of a combined builtin trace
+
+
 def periodic_lde(n, shift=FIELD_GEN, device="cuda", air="pedersen"):
     """[k, 4 * period, 4]: the periodic columns on the LDE coset (they repeat with period 4 * period)."""
     torch = _torch()
@@ -380,3 +392,196 @@ def prove_trace(trace, air: str, n_queries: int = 8, seed: int = 0, final_log: i
         queries.append(entry)
     return {"n": n, "air": air, "seed": seed, "shift": shift, "public_inputs": list(public_inputs),
             "trace_root": root_t, "layer_roots": roots, "final_layer": final, "queries": queries}
+
+
+# ---- the range-check builtin's encoding and ONE trace for the three builtins --------------------
+# Definition: oracle/stark_ref.py ("rc16", BUILTIN_SEGMENTS, verify_builtins_proof).  The Cairo program is
+# `%builtins output pedersen range_check ecdsa` (services/perpetual/cairo/main.cairo:1); no VM is needed for the
+# builtin segments - the instance lists (hash inputs, signatures, range-checked values) are the input.
+def rc16_fill(values, total_values):
+    """values (each < 2^128) -> (padded list of total_values values, rc_min, rc_max); the padding values' limbs
+    fill the holes of the limb range (the builtin's unused cells)."""
+    limbs = set()
+    for v in values:
+        assert 0 <= v < 1 << 128
+        for k in range(RC16_LIMBS):
+            limbs.add((v >> (16 * k)) & 0xFFFF)
+    lo, hi = min(limbs), max(limbs)
+    holes = [x for x in range(lo, hi + 1) if x not in limbs]
+    pads = []
+    for i in range(0, len(holes), RC16_LIMBS):
+        group = holes[i : i + RC16_LIMBS]
+        group += [lo] * (RC16_LIMBS - len(group))
+        pads.append(sum(l << (16 * (RC16_LIMBS - 1 - k)) for k, l in enumerate(group)))
+    if len(values) + len(pads) > total_values:
+        raise ValueError("the trace is too short to fill the %d holes of the limb range" % len(holes))
+    filler = sum(lo << (16 * k) for k in range(RC16_LIMBS))
+    return list(values) + pads + [filler] * (total_values - len(values) - len(pads)), lo, hi
+
+
+def rc16_columns(values):
+    """values: [k, 4] device tensor (already padded, rc16_fill) -> [3, 8 k, 4]: a (limb), acc (running value), s
+    (the limb column sorted)."""
+    torch = _torch()
+    lib = _lib.ensure_init()
+    k = values.shape[0]
+    cols = torch.zeros((3, RC16_LIMBS * k, 4), dtype=torch.int64, device=values.device)
+    _lib.check(lib.sp_rc16_trace_dev(values.data_ptr(), k, cols.data_ptr(), _stream()), "sp_rc16_trace_dev")
+    cols[2, :, 0] = torch.sort(cols[0, :, 0]).values  # limbs are < 2^16: the low word is the felt
+    return cols
+
+
+def rc16_product(a, s, z):
+    """The second-phase column p_i = prod_{j <= i} (z - a_j) / (z - s_j) (a, s: [n, 4] device tensors)."""
+    torch = _torch()
+    lib = _lib.ensure_init()
+    n = a.shape[0]
+    p = torch.empty((n, 4), dtype=torch.int64, device=a.device)
+    _lib.check(lib.sp_rc16_product_dev(a.contiguous().data_ptr(), s.contiguous().data_ptr(), n, pack_felts([z]),
+                                       p.data_ptr(), _stream()), "sp_rc16_product_dev")
+    return p
+
+
+def air_eval_rc16(cols_lde, p_lde, per_lde, n, alphas, z, rc_min, rc_max, shift=FIELD_GEN):
+    torch = _torch()
+    lib = _lib.ensure_init()
+    assert cols_lde.shape[0] == 3 and cols_lde.shape[1] == 4 * n and len(alphas) == N_RC16_CONSTRAINTS
+    out = torch.empty((4 * n, 4), dtype=torch.int64, device=cols_lde.device)
+    _lib.check(lib.sp_air_eval_rc16_dev(cols_lde.data_ptr(), p_lde.data_ptr(), per_lde.data_ptr(), n.bit_length() - 1,
+                                        pack_felts(alphas), pack_felts([shift]), pack_felts([z]), rc_min, rc_max,
+                                        out.data_ptr(), _stream()), "sp_air_eval_rc16_dev")
+    return out
+
+
+def felt_add(a, b):
+    torch = _torch()
+    lib = _lib.ensure_init()
+    out = torch.empty_like(a)
+    _lib.check(lib.sp_felt_add_dev(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], _stream()), "sp_felt_add_dev")
+    return out
+
+
+def _cycle(items, count):
+    return [items[i % len(items)] for i in range(count)]
+
+
+def prove_builtins(hash_inputs=None, signatures=None, rc_values=None, n_queries: int = 8, seed: int = 0,
+                   final_log: int = 6, shift: int = FIELD_GEN, log_rows: int = None):
+    """ONE trace, ONE composition, ONE proof for the builtin usage of a batch: Pedersen hashes
+    (hash_inputs: [(x, y)]), ECDSA verifications (signatures: [(z, r, s, (Qx, Qy))]) and range checks (rc_values:
+    ints < 2^128) laid side by side at fixed ratios - per 1024 rows two hashes, one verification and 128 rc16
+    cells (16 values).  The trace length is the power of two the largest segment needs; the other segments repeat
+    their instances (unused builtin cells).  Two committed phases: the builtin columns, then - after the
+    challenge z - the permutation product of the range-check segment.  Benchmark-grade like prove_trace (no
+    boundary constraint ties the instances to the public inputs except rc_min / rc_max; ~2 bits per query).
+    Verifier: oracle/stark_ref.verify_builtins_proof."""
+    torch = _torch()
+    dev = "cuda"
+    P = FIELD_PRIME
+    segments = [name for name, arg in zip(BUILTIN_SEGMENTS, (hash_inputs, signatures, rc_values)) if arg]
+    assert segments, "no builtin instance given"
+    need = 8
+    if hash_inputs:
+        need = max(need, 512 * len(hash_inputs))
+    if signatures:
+        need = max(need, 1024 * len(signatures))
+    rc_need = 0
+    if rc_values:
+        limbs = {(v >> (16 * k)) & 0xFFFF for v in rc_values for k in range(RC16_LIMBS)}
+        rc_need = len(rc_values) + -(-(max(limbs) - min(limbs) + 1 - len(limbs)) // RC16_LIMBS)
+        need = max(need, RC16_LIMBS * rc_need)
+    n = 1 << max((need - 1).bit_length(), log_rows or 0)
+    M = n << BLOWUP_LOG
+    groups, public, flat_pub = [], {}, [len(segments)] + [BUILTIN_SEGMENTS.index(s) for s in segments]
+    rc_min = rc_max = 0
+    if rc_values:
+        padded, rc_min, rc_max = rc16_fill(list(rc_values), n // RC16_LIMBS)
+        public.update({"rc_min": rc_min, "rc_max": rc_max})
+        flat_pub += [rc_min, rc_max]
+    if signatures:
+        sigs = _cycle(list(signatures), n // 1024)
+        ws = [pow(s_, -1, EC_ORDER) for _, _, s_, _ in sigs]
+        for (z_, r_, _, _), w_ in zip(sigs, ws):
+            assert 0 < z_ < 2**251 and 1 <= r_ < 2**251 and 1 <= w_ < 2**251
+        public["signatures"] = [[z_, r_, s_, q[0], q[1]] for z_, r_, s_, q in sigs]
+        flat_pub += [v for sig in public["signatures"] for v in sig]
+    if hash_inputs:
+        hs = _cycle(list(hash_inputs), n // 512)
+        groups.append(pedersen_trace(felts_to_tensor([x for x, _ in hs], dev), felts_to_tensor([y for _, y in hs], dev)))
+    if signatures:
+        groups.append(ecdsa_trace(*(felts_to_tensor(v, dev) for v in (
+            [z_ for z_, _, _, _ in sigs], [r_ for _, r_, _, _ in sigs], ws, [q[0] for *_, q in sigs],
+            [q[1] for *_, q in sigs]))))
+    if rc_values:
+        groups.append(rc16_columns(felts_to_tensor(padded, dev)))
+    trace = torch.cat(groups)
+    del groups
+    n_cols = trace.shape[0]
+    tr = Transcript("builtins", n, shift, seed, flat_pub)
+    # ---- phase 1: the builtin columns ----
+    trace_lde = lde(trace)
+    lv1 = commit_rows(trace_lde)
+    root1 = root_of(lv1)
+    tr.absorb("phase1_root", root1)
+    # ---- phase 2: the permutation product of the range-check segment, after its challenge ----
+    z, p_lde, lv2, root2 = 0, None, None, None
+    if rc_values:
+        z = tr.challenge("rc16_z")
+        p = rc16_product(trace[n_cols - 3], trace[n_cols - 1], z)
+        p_lde = lde(p.unsqueeze(0))[0]
+        lv2 = commit_rows(p_lde.unsqueeze(0))
+        root2 = root_of(lv2)
+        tr.absorb("phase2_root", root2)
+    del trace
+    n_alphas = sum(AIRS[s]["n_constraints"] for s in segments)
+    alphas = [tr.challenge("alpha", k) for k in range(n_alphas)]
+    comp, c0, a0 = None, 0, 0
+    for seg in segments:
+        spec = AIRS[seg]
+        sl = trace_lde[c0 : c0 + spec["n_cols"]]
+        al = alphas[a0 : a0 + spec["n_constraints"]]
+        per = periodic_lde(n, shift, dev, seg)
+        part = (air_eval_rc16(sl, p_lde, per, n, al, z, rc_min, rc_max, shift) if seg == "rc16"
+                else air_eval(sl, per, n, al, shift, seg))
+        comp = part if comp is None else felt_add(comp, part)
+        c0 += spec["n_cols"]
+        a0 += spec["n_constraints"]
+    layers, level_bufs, roots = [comp], [], []
+    s = shift
+    while True:
+        cur = layers[-1]
+        lv = commit_rows(cur.unsqueeze(0))
+        level_bufs.append(lv)
+        roots.append(root_of(lv))
+        tr.absorb("layer_root", roots[-1])
+        beta = tr.challenge("beta", len(roots))
+        nxt = fri_fold(cur, beta, s)
+        s = s * s % P
+        layers.append(nxt)
+        if nxt.shape[0] <= (1 << final_log):
+            break
+    final = tensor_to_felts(layers[-1])
+    tr.absorb("final_layer", *final)
+    queries = []
+    for q in range(n_queries):
+        j = tr.challenge("query", q, modulus=M // 2)
+        entry = {"index": j, "phase1": [], "phase2": [], "layers": []}
+        for pos in (j, j + M // 2):
+            for row in (pos, (pos + (1 << BLOWUP_LOG)) % M):
+                entry["phase1"].append({"row": row, "values": tensor_to_felts(trace_lde[:, row]),
+                                        "path": _gather_felts(lv1, _path_indices(M, row))})
+                if rc_values:
+                    entry["phase2"].append({"row": row, "value": tensor_to_felts(p_lde[row : row + 1])[0],
+                                            "path": _gather_felts(lv2, _path_indices(M, row))})
+        jk = j
+        for k, (layer, lv) in enumerate(zip(layers[:-1], level_bufs)):
+            mk = layer.shape[0]
+            jk %= mk // 2
+            pair = []
+            for pos in (jk, jk + mk // 2):
+                pair.append({"pos": pos, "value": tensor_to_felts(layer[pos : pos + 1])[0],
+                             "path": _gather_felts(lv, _path_indices(mk, pos))})
+            entry["layers"].append(pair)
+        queries.append(entry)
+    return {"n": n, "air": "builtins", "segments": segments, "seed": seed, "shift": shift, "public_inputs": public,
+            "phase1_root": root1, "phase2_root": root2, "layer_roots": roots, "final_layer": final, "queries": queries}

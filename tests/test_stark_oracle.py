@@ -2,6 +2,8 @@
 prover, so these replace golden vectors for rows A10-A13 ("parity unpinned")."""
 import random
 
+import pytest
+
 from oracle import ref_py as R
 from oracle import stark_ref as S
 
@@ -183,3 +185,39 @@ def test_ecdsa_air_trace_and_degree():
     import pytest
     with pytest.raises(AssertionError):
         S.ecdsa_instance(z + 1, insts[0][1], R.sign(z, 5)[1], q)
+
+
+def test_rc16_builtin_air_oracle():
+    """The range-check builtin's encoding: the composition of a valid two-phase trace is a
+    polynomial of degree < 2n, a corrupted limb / a sorted column that is no permutation / a wrong limb range
+    are not; the padding fills the holes of the limb range."""
+    import random
+    rng = random.Random(5)
+    vals = [sum(rng.randrange(100, 140) << (16 * k) for k in range(8)) for _ in range(12)]
+    padded, lo, hi = S.rc16_fill(vals, 16)
+    assert padded[:12] == vals and (lo, hi) == (100, 139)
+    cols = S.rc16_trace(padded)
+    n = len(cols[0])
+    assert n == 128 and sorted(set(cols[0])) == list(range(lo, hi + 1))
+    assert [cols[1][8 * v + 7] for v in range(16)] == padded
+    z = rng.randrange(S.P)
+    p = S.rc16_product_column(cols[0], cols[2], z)
+    assert p[-1] == 1
+    alphas = [rng.randrange(S.P) for _ in range(S.N_RC16_CONSTRAINTS)]
+
+    def low_degree(c, pc, rc_lo=lo, rc_hi=hi):
+        comp = S.rc16_composition_on_coset([S.lde(x) for x in c], S.lde(pc), n, alphas, z, rc_lo, rc_hi)
+        return S.poly_degree_bound_check(comp, S.GEN, 2 * n)
+    assert low_degree(cols, p)
+    bad = [list(c) for c in cols]
+    bad[0][5] += 1                                   # a limb that is not in the pool any more
+    assert not low_degree(bad, p)
+    assert not low_degree(bad, S.rc16_product_column(bad[0], bad[2], z))   # ... even with its own product column
+    bad = [list(c) for c in cols]
+    bad[1][9] += 1                                   # the running value does not follow the limbs
+    assert not low_degree(bad, p)
+    assert not low_degree(cols, p, rc_lo=lo + 1) and not low_degree(cols, p, rc_hi=hi + 1)
+    with pytest.raises(AssertionError):
+        S.rc16_fill([1 << 128], 4)
+    with pytest.raises(AssertionError):
+        S.rc16_fill([0, 0xFFFF], 16)                 # 65 534 holes do not fit 16 values
