@@ -52,6 +52,7 @@ extern "C" {
 #define SP_HASH_OK 0
 #define SP_HASH_OUT_OF_RANGE 1 /* an input was not in [0, p): signature.py:307 assertion */
 #define SP_HASH_UNHASHABLE 2   /* exceptional point collision: signature.py:313 ("Unhashable input.") */
+#define SP_TREE_NOT_COMMITTED 0x80 /* sp_order_batch: a signature did not verify - the tree was left as it was */
 
 /* per-item result of sp_ecdsa_verify_* (signature.py:217-260) */
 #define SP_VERIFY_FALSE 0
@@ -154,10 +155,26 @@ int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leaves, size_t n
  * (strictly increasing, < 2^height, height <= 64) in one call - one gathered launch per level - and
  * returns the root before and after.  status != 0 (SP_HASH_*) leaves the tree unchanged. */
 int sp_tree_create(unsigned height, const uint64_t* empty_leaf, int* tree);
+/* The same on context `context` of sp_init_devices (0 = the primary, what sp_tree_create uses): the tree's table,
+ * stream and work buffer live on that device; every sp_tree_* call on the handle runs there. */
+int sp_tree_create_on(int context, unsigned height, const uint64_t* empty_leaf, int* tree);
 int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_t n, uint64_t* old_root,
                    uint64_t* new_root, uint8_t* status);
 int sp_tree_get(int tree, const uint64_t* keys, size_t n, uint64_t* leaves);
 int sp_tree_root(int tree, uint64_t* root);
+/* Threading of the sp_tree_* calls: a tree has its own HIP stream, work buffer and mutex.  An operation holds
+ * the tree's mutex from start to end and the library lock only while it enqueues; the device work of an update
+ * (the level launches) runs without the library lock, so other trees and the stateless batches go on meanwhile. */
+/* BASELINE.json configs[2] in one call (services/perpetual/cairo/order/limit_order.cairo:24-52, order.cairo:23-31,
+ * :122-124): message-hash chains of n orders (words: depth x n felts, word-major; z_out receives the hashes) ->
+ * verification of (z mod 2^251, r, s, key) through the key tables (verdicts as sp_ecdsa_verify_batch; qy == NULL:
+ * x-only keys) -> order id = bits [id_shift, id_shift + 64) of z (187 for the 251-bit message: the top 64 bits) ->
+ * update of the orders tree `tree` with leaves[i] at order id i.  Verification and tree hashing overlap on the
+ * device; the new nodes are committed only when every signature verified, otherwise *tree_status =
+ * SP_TREE_NOT_COMMITTED and new_root = old_root.  Two orders with one id: SP_ERR_BAD_ARGUMENT. */
+int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t* r, const uint64_t* s,
+                   const uint64_t* qx, const uint64_t* qy, int tree, const uint64_t* leaves, unsigned id_shift,
+                   uint64_t* z_out, uint8_t* verdicts, uint64_t* old_root, uint64_t* new_root, uint8_t* tree_status);
 int sp_tree_destroy(int tree);
 
 /* ---- Stark-curve ECDSA ------------------------------------------------------------------------ */

@@ -1054,10 +1054,11 @@ int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uin
   // curve: flagged by key_rows_kernel) gives its slot back and is remembered in the host map: an untrusted
   // key stream cannot fill the cache with keys that will never verify anything.
   if (!fs.empty()) {
-    std::vector<uint8_t> flags(fs.size());
+    std::vector<uint8_t> all_flags(g_keys.used), flags(fs.size());  // ONE copy (<= 128 KiB), not one per new key
+    SP_HIP(hipMemcpy(all_flags.data(), g_keys.flag.ptr, g_keys.used, hipMemcpyDeviceToHost));
     bool any_bad = false;
     for (size_t j = 0; j < fs.size(); ++j) {
-      SP_HIP(hipMemcpy(&flags[j], (const uint8_t*)g_keys.flag.ptr + fs[j], 1, hipMemcpyDeviceToHost));
+      flags[j] = all_flags[fs[j]];
       any_bad |= flags[j] == KEY_INVALID_X || flags[j] == KEY_OFF_CURVE;
     }
     if (any_bad) {

@@ -8,9 +8,13 @@
 // integer bookkeeping of which two children feed each induced node (the merkle_tree.py part),
 // the GPU does every hash: per level one pair of Pedersen launches whose accumulate kernel picks its
 // operands through the host's child-index list (gathered mode of csrc/pedersen.hip).
+#include <algorithm>
 #include <climits>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -368,34 +372,77 @@ tree_rehash_kernel(const TreeSlot* __restrict__ old, uint64_t old_slots, TreeSlo
 struct SparseTree {
   unsigned height = 0;
   uint64_t empty_leaf[4] = {0, 0, 0, 0};
+  int ctx_index = 0;           // the context (device) the tree lives on
   TreeSlot* table = nullptr;   // HBM
   uint64_t slots = 0;          // power of two
   uint64_t entries = 0;        // used slots as of the last read of d_entries
   unsigned long long* d_entries = nullptr;  // device counter of claimed slots (insert kernels add to it)
   bool has_root = false;
   uint64_t root[4] = {0, 0, 0, 0};
+  // Every tree has its OWN stream and work buffer and its own mutex: an operation holds the tree's mutex from
+  // start to end (updates of one tree are ordered anyway) and takes the library lock only to enqueue - the
+  // copies and the ~3 ms of level launches of a height-64 update run without it, so hash / verify batches and
+  // updates of OTHER trees proceed meanwhile (round 2: null stream, library lock across everything).
+  hipStream_t stream = nullptr;
+  DeviceBuffer buf;
+  std::mutex mu;
 };
 
-static std::map<int, SparseTree> g_trees;
+static std::map<int, std::shared_ptr<SparseTree>> g_trees;
 static int g_next_tree = 1;
-static DeviceBuffer g_tree_buf;
 
 static void tree_free(SparseTree& t) {
+  if (t.stream) {
+    (void)hipStreamSynchronize(t.stream);
+    (void)hipStreamDestroy(t.stream);
+  }
   if (t.table) (void)hipFree(t.table);
   if (t.d_entries) (void)hipFree(t.d_entries);
+  t.buf.release();
+  t.stream = nullptr;
   t.table = nullptr;
   t.d_entries = nullptr;
   t.slots = 0;
 }
-// room for `extra` more entries at a load factor of at most 1/2
+
+// Looks the handle up, selects the tree's context and device for this host thread and locks the tree.
+struct TreeScope {
+  std::shared_ptr<SparseTree> t;
+  int previous_ctx = -1;
+  int previous_dev = -1;
+  bool switched_dev = false;
+  std::unique_lock<std::mutex> held;
+  int open(int handle) {
+    {
+      ctx_lock lk(global_mu());
+      auto it = g_trees.find(handle);
+      if (it == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
+      t = it->second;
+    }
+    held = std::unique_lock<std::mutex>(t->mu);
+    previous_ctx = ctx_current();
+    ctx_select(t->ctx_index);
+    const int dev = ctx().device;
+    if (hipGetDevice(&previous_dev) == hipSuccess && previous_dev != dev) switched_dev = hipSetDevice(dev) == hipSuccess;
+    if (!t->stream) SP_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    return SP_OK;
+  }
+  ~TreeScope() {
+    if (previous_ctx >= 0) ctx_select(previous_ctx);
+    if (switched_dev) (void)hipSetDevice(previous_dev);
+  }
+};
+
+// room for `extra` more entries at a load factor of at most 1/2 (tree mutex held)
 static int tree_reserve(SparseTree& t, uint64_t extra) {
   if (!t.d_entries) {
     SP_HIP(hipMalloc(&t.d_entries, sizeof(unsigned long long)));
-    SP_HIP(hipMemset(t.d_entries, 0, sizeof(unsigned long long)));
+    SP_HIP(hipMemsetAsync(t.d_entries, 0, sizeof(unsigned long long), t.stream));
   }
   if (t.slots && 2 * (t.entries + extra) > t.slots) {  // would not fit by the last known count: refresh it
     unsigned long long used = 0;
-    SP_HIP(hipMemcpy(&used, t.d_entries, sizeof(used), hipMemcpyDeviceToHost));
+    SP_HIP(hipMemcpyAsync(&used, t.d_entries, sizeof(used), hipMemcpyDeviceToHost, t.stream));
+    SP_HIP(hipStreamSynchronize(t.stream));
     t.entries = used;
   }
   uint64_t want = t.slots ? t.slots : ((uint64_t)1 << 16);
@@ -403,12 +450,12 @@ static int tree_reserve(SparseTree& t, uint64_t extra) {
   if (want == t.slots) return SP_OK;
   TreeSlot* fresh = nullptr;
   SP_HIP(hipMalloc(&fresh, want * sizeof(TreeSlot)));
-  SP_HIP(hipMemsetAsync(fresh, 0, want * sizeof(TreeSlot), 0));
+  SP_HIP(hipMemsetAsync(fresh, 0, want * sizeof(TreeSlot), t.stream));
   if (t.table) {
-    hipLaunchKernelGGL(tree_rehash_kernel, dim3((unsigned)((t.slots + 255) / 256)), dim3(256), 0, 0, t.table, t.slots,
-                       fresh, want - 1);
+    hipLaunchKernelGGL(tree_rehash_kernel, dim3((unsigned)((t.slots + 255) / 256)), dim3(256), 0, t.stream, t.table,
+                       t.slots, fresh, want - 1);
     SP_HIP(hipGetLastError());
-    SP_HIP(hipDeviceSynchronize());
+    SP_HIP(hipStreamSynchronize(t.stream));
     (void)hipFree(t.table);
   }
   t.table = fresh;
@@ -416,53 +463,12 @@ static int tree_reserve(SparseTree& t, uint64_t extra) {
   return SP_OK;
 }
 
-namespace sp {
-void release_tree_state() {
-  for (auto& kv : g_trees) tree_free(kv.second);
-  g_trees.clear();
-  g_tree_buf.release();
-}
-}  // namespace sp
-
-extern "C" {
-
-int sp_tree_create(unsigned height, const uint64_t* empty_leaf, int* tree) {
-  SP_REQUIRE_READY();
-  if (height < 1 || height > 64) { set_error("height must be in 1..64"); return SP_ERR_BAD_ARGUMENT; }
-  // an out-of-range empty leaf would poison the cached empty-subtree roots (their chain flags
-  // SP_HASH_OUT_OF_RANGE once, later calls hit the cache and never see the flag again)
-  if (!felt_below_p(empty_leaf)) { set_error("empty leaf must be a field element (< p)"); return SP_ERR_BAD_ARGUMENT; }
-  ctx_lock lk(ctx().mu);
-  SparseTree t;
-  t.height = height;
-  std::memcpy(t.empty_leaf, empty_leaf, 32);
-  const int id = g_next_tree++;
-  g_trees.emplace(id, t);
-  *tree = id;
-  return SP_OK;
-}
-
-int sp_tree_destroy(int tree) {
-  SP_REQUIRE_READY();
-  ctx_lock lk(ctx().mu);
-  auto it = g_trees.find(tree);
-  if (it == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
-  SP_HIP(hipDeviceSynchronize());
-  tree_free(it->second);
-  g_trees.erase(it);
-  return SP_OK;
-}
-
-int sp_tree_root(int tree, uint64_t* root) {
-  SP_REQUIRE_READY();
-  ctx_lock lk(ctx().mu);
-  auto it = g_trees.find(tree);
-  if (it == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
-  SparseTree& t = it->second;
+static int tree_root_locked(SparseTree& t, uint64_t* root) {
   if (t.has_root) {
     std::memcpy(root, t.root, 32);
     return SP_OK;
   }
+  ctx_lock lk(global_mu());  // the cache of empty-subtree roots and the scratch map are shared
   Scratch s;
   int rc = get_scratch_public(1, s, 0);
   if (rc != SP_OK) return rc;
@@ -473,52 +479,22 @@ int sp_tree_root(int tree, uint64_t* root) {
   return SP_OK;
 }
 
-int sp_tree_get(int tree, const uint64_t* keys, size_t n, uint64_t* leaves) {
-  SP_REQUIRE_READY();
-  ctx_lock lk(ctx().mu);
-  auto it = g_trees.find(tree);
-  if (it == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
-  const SparseTree& t = it->second;
-  for (size_t i = 0; i < n; ++i) {
-    if (t.height < 64 && (keys[i] >> t.height) != 0) { set_error("key out of range for height"); return SP_ERR_BAD_ARGUMENT; }
-  }
-  if (n == 0) return SP_OK;
-  if (!t.table) {
-    for (size_t i = 0; i < n; ++i) std::memcpy(leaves + 4 * i, t.empty_leaf, 32);
-    return SP_OK;
-  }
-  if (n > 0xffffffffull) { set_error("too many keys"); return SP_ERR_BAD_ARGUMENT; }
-  SP_HIP(g_tree_buf.reserve(n * 40 + 64));
-  uint64_t* d_keys = (uint64_t*)g_tree_buf.ptr;
-  uint64_t* d_emp = d_keys + n;
-  uint64_t* d_out = d_emp + 4;
-  SP_HIP(hipMemcpy(d_keys, keys, n * 8, hipMemcpyHostToDevice));
-  SP_HIP(hipMemcpy(d_emp, t.empty_leaf, 32, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(tree_get_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, t.table, t.slots - 1, d_keys,
-                     (unsigned)n, d_emp, d_out);
-  SP_HIP(hipGetLastError());
-  SP_HIP(hipMemcpy(leaves, d_out, n * 32, hipMemcpyDeviceToHost));
-  return SP_OK;
-}
-
-int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_t n, uint64_t* old_root,
-                   uint64_t* new_root, uint8_t* status) {
-  SP_REQUIRE_READY();
-  Context& c = ctx();
-  ctx_lock lk(c.mu);
-  auto tit = g_trees.find(tree);
-  if (tit == g_trees.end()) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
-  SparseTree& t = tit->second;
+// The update itself (tree mutex held, context selected).  `may_commit`, when given, is asked once every new
+// node has been hashed and before anything is written to the table: false leaves the tree as it was
+// (*status = SP_TREE_NOT_COMMITTED).
+static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_t* leaves, size_t n, uint64_t* old_root,
+                              uint64_t* new_root, uint8_t* status, const std::function<bool()>* may_commit) {
   const unsigned height = t.height;
   for (size_t i = 0; i < n; ++i) {
     if (i > 0 && keys[i] <= keys[i - 1]) { set_error("keys must be strictly increasing"); return SP_ERR_BAD_ARGUMENT; }
     if (height < 64 && (keys[i] >> height) != 0) { set_error("key out of range for height"); return SP_ERR_BAD_ARGUMENT; }
   }
-  int rc = sp_tree_root(tree, old_root);
+  int rc = tree_root_locked(t, old_root);
   if (rc != SP_OK) return rc;
   if (status) *status = 0;
   if (n == 0) {
     std::memcpy(new_root, old_root, 32);
+    if (may_commit && !(*may_commit)() && status) *status = SP_TREE_NOT_COMMITTED;
     return SP_OK;
   }
   // ---- host: only the node COUNT of every level (merkle_tree.py:18-26 on the keys alone): level l has one node
@@ -558,50 +534,225 @@ int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_
   if (rc != SP_OK) return rc;
   const size_t emp_bytes = ((size_t)height + 1) * 32;
   const size_t felt_bytes = felts * 32, idx_bytes = idxs * 8, src_bytes = srcs * sizeof(int2);
-  SP_HIP(g_tree_buf.reserve(emp_bytes + felt_bytes + idx_bytes + src_bytes + 1024));
-  char* b = (char*)g_tree_buf.ptr;
+  SP_HIP(t.buf.reserve(emp_bytes + felt_bytes + idx_bytes + src_bytes + 1024));
+  char* b = (char*)t.buf.ptr;
   uint64_t* d_emp = (uint64_t*)b;
   uint64_t* d_felts = (uint64_t*)(b + emp_bytes);
   uint64_t* d_idx = (uint64_t*)(b + emp_bytes + felt_bytes);
   int2* d_src = (int2*)(b + emp_bytes + felt_bytes + idx_bytes);
+  hipStream_t st = t.stream;
   Scratch s;
-  rc = get_scratch_public(n, s, 0);
-  if (rc != SP_OK) return rc;
-  SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), 0));
-  const std::vector<uint64_t>* emp = nullptr;
-  rc = empty_roots(t.empty_leaf, s, &emp);
-  if (rc != SP_OK) return rc;
-  SP_HIP(hipMemcpyAsync(d_emp, emp->data(), emp_bytes, hipMemcpyHostToDevice, 0));
-  SP_HIP(hipMemcpyAsync(d_felts, leaves, n * 32, hipMemcpyHostToDevice, 0));
-  SP_HIP(hipMemcpyAsync(d_idx, keys, n * 8, hipMemcpyHostToDevice, 0));
-  // ---- device: the structure of every level and the sibling lookups in one launch, then the hashes ----
-  hipLaunchKernelGGL(tree_level_nodes_kernel, dim3(height), dim3(1024), 0, 0, lv, d_idx, d_idx);
-  hipLaunchKernelGGL(tree_children_kernel, dim3((unsigned)((total - cnt[height] + 255) / 256)), dim3(256), 0, 0, lv, d_idx,
-                     d_src, (unsigned)(total - cnt[height]));
-  hipLaunchKernelGGL(tree_lookup_kernel, dim3((unsigned)((srcs + 255) / 256)), dim3(256), 0, 0, lv, d_idx, t.table,
-                     t.slots - 1, d_felts, d_src, (unsigned)srcs);
-  SP_HIP(hipGetLastError());
-  for (unsigned l = 0; l < height; ++l) {
-    rc = enqueue_pedersen(d_felts, 1, d_emp + 4 * l, 1, d_felts + 4 * (size_t)lv.val_base[l + 1], 1, nullptr, s.flag,
-                          cnt[l + 1], 0, s, d_src + lv.src_off[l]);
+  {
+    // ---- enqueue under the library lock: scratch map, empty-root cache, launch bookkeeping ----
+    ctx_lock lk(global_mu());
+    rc = get_scratch_public(n, s, st);
     if (rc != SP_OK) return rc;
+    SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
+    const std::vector<uint64_t>* emp = nullptr;
+    rc = empty_roots(t.empty_leaf, s, &emp);
+    if (rc != SP_OK) return rc;
+    SP_HIP(hipMemcpyAsync(d_emp, emp->data(), emp_bytes, hipMemcpyHostToDevice, st));
+    SP_HIP(hipMemcpyAsync(d_felts, leaves, n * 32, hipMemcpyHostToDevice, st));
+    SP_HIP(hipMemcpyAsync(d_idx, keys, n * 8, hipMemcpyHostToDevice, st));
+    // the structure of every level and the sibling lookups, then the hashes level by level
+    hipLaunchKernelGGL(tree_level_nodes_kernel, dim3(height), dim3(1024), 0, st, lv, d_idx, d_idx);
+    hipLaunchKernelGGL(tree_children_kernel, dim3((unsigned)((total - cnt[height] + 255) / 256)), dim3(256), 0, st, lv,
+                       d_idx, d_src, (unsigned)(total - cnt[height]));
+    hipLaunchKernelGGL(tree_lookup_kernel, dim3((unsigned)((srcs + 255) / 256)), dim3(256), 0, st, lv, d_idx, t.table,
+                       t.slots - 1, d_felts, d_src, (unsigned)srcs);
+    SP_HIP(hipGetLastError());
+    for (unsigned l = 0; l < height; ++l) {
+      rc = enqueue_pedersen(d_felts, 1, d_emp + 4 * l, 1, d_felts + 4 * (size_t)lv.val_base[l + 1], 1, nullptr, s.flag,
+                            cnt[l + 1], st, s, d_src + lv.src_off[l]);
+      if (rc != SP_OK) return rc;
+    }
   }
+  // ---- the device runs; nobody waits on the library lock for it ----
   unsigned f = 0;
-  SP_HIP(hipMemcpy(&f, s.flag, sizeof(unsigned), hipMemcpyDeviceToHost));  // waits for the stream
+  SP_HIP(hipMemcpyAsync(&f, s.flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  SP_HIP(hipStreamSynchronize(st));
   if (status) *status = (uint8_t)f;
   if (f != 0) {  // an input out of range or an unhashable pair: nothing was written, the tree is as it was
     std::memcpy(new_root, old_root, 32);
     return SP_OK;
   }
+  if (may_commit && !(*may_commit)()) {
+    if (status) *status = SP_TREE_NOT_COMMITTED;
+    std::memcpy(new_root, old_root, 32);
+    return SP_OK;
+  }
   // ---- commit: every new node into the table, one launch ----
-  hipLaunchKernelGGL(tree_insert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, t.table, t.slots - 1, lv,
+  hipLaunchKernelGGL(tree_insert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, t.table, t.slots - 1, lv,
                      d_idx, d_felts, (unsigned)total, t.d_entries);
   SP_HIP(hipGetLastError());
-  SP_HIP(hipMemcpy(t.root, d_felts + 4 * (size_t)lv.val_base[height], 32, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpyAsync(t.root, d_felts + 4 * (size_t)lv.val_base[height], 32, hipMemcpyDeviceToHost, st));
+  SP_HIP(hipStreamSynchronize(st));
   t.has_root = true;
   t.entries += total;  // upper bound until tree_reserve reads the device counter again
   std::memcpy(new_root, t.root, 32);
   return SP_OK;
+}
+
+namespace sp {
+void release_tree_state() {
+  for (auto& kv : g_trees) tree_free(*kv.second);
+  g_trees.clear();
+}
+}  // namespace sp
+
+extern "C" {
+
+int sp_tree_create_on(int context, unsigned height, const uint64_t* empty_leaf, int* tree) {
+  SP_REQUIRE_READY();
+  if (height < 1 || height > 64) { set_error("height must be in 1..64"); return SP_ERR_BAD_ARGUMENT; }
+  if (context < 0 || context >= ctx_count() || !ctx_at(context).ready) { set_error("no such context"); return SP_ERR_BAD_ARGUMENT; }
+  // an out-of-range empty leaf would poison the cached empty-subtree roots (their chain flags
+  // SP_HASH_OUT_OF_RANGE once, later calls hit the cache and never see the flag again)
+  if (!felt_below_p(empty_leaf)) { set_error("empty leaf must be a field element (< p)"); return SP_ERR_BAD_ARGUMENT; }
+  ctx_lock lk(global_mu());
+  auto t = std::make_shared<SparseTree>();
+  t->height = height;
+  t->ctx_index = context;
+  std::memcpy(t->empty_leaf, empty_leaf, 32);
+  const int id = g_next_tree++;
+  g_trees.emplace(id, t);
+  *tree = id;
+  return SP_OK;
+}
+
+int sp_tree_create(unsigned height, const uint64_t* empty_leaf, int* tree) {
+  return sp_tree_create_on(0, height, empty_leaf, tree);
+}
+
+int sp_tree_destroy(int tree) {
+  SP_REQUIRE_READY();
+  std::shared_ptr<SparseTree> keep;
+  {
+    TreeScope ts;
+    int rc = ts.open(tree);
+    if (rc != SP_OK) return rc;
+    keep = ts.t;
+    {
+      ctx_lock lk(global_mu());
+      g_trees.erase(tree);
+    }
+    tree_free(*ts.t);  // waits for the tree's stream
+  }
+  return SP_OK;
+}
+
+int sp_tree_root(int tree, uint64_t* root) {
+  SP_REQUIRE_READY();
+  TreeScope ts;
+  int rc = ts.open(tree);
+  if (rc != SP_OK) return rc;
+  return tree_root_locked(*ts.t, root);
+}
+
+int sp_tree_get(int tree, const uint64_t* keys, size_t n, uint64_t* leaves) {
+  SP_REQUIRE_READY();
+  TreeScope ts;
+  int rc = ts.open(tree);
+  if (rc != SP_OK) return rc;
+  SparseTree& t = *ts.t;
+  for (size_t i = 0; i < n; ++i) {
+    if (t.height < 64 && (keys[i] >> t.height) != 0) { set_error("key out of range for height"); return SP_ERR_BAD_ARGUMENT; }
+  }
+  if (n == 0) return SP_OK;
+  if (!t.table) {
+    for (size_t i = 0; i < n; ++i) std::memcpy(leaves + 4 * i, t.empty_leaf, 32);
+    return SP_OK;
+  }
+  if (n > 0xffffffffull) { set_error("too many keys"); return SP_ERR_BAD_ARGUMENT; }
+  SP_HIP(t.buf.reserve(n * 40 + 64));
+  uint64_t* d_keys = (uint64_t*)t.buf.ptr;
+  uint64_t* d_emp = d_keys + n;
+  uint64_t* d_out = d_emp + 4;
+  SP_HIP(hipMemcpyAsync(d_keys, keys, n * 8, hipMemcpyHostToDevice, t.stream));
+  SP_HIP(hipMemcpyAsync(d_emp, t.empty_leaf, 32, hipMemcpyHostToDevice, t.stream));
+  hipLaunchKernelGGL(tree_get_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, t.stream, t.table, t.slots - 1,
+                     d_keys, (unsigned)n, d_emp, d_out);
+  SP_HIP(hipGetLastError());
+  SP_HIP(hipMemcpyAsync(leaves, d_out, n * 32, hipMemcpyDeviceToHost, t.stream));
+  SP_HIP(hipStreamSynchronize(t.stream));
+  return SP_OK;
+}
+
+int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_t n, uint64_t* old_root,
+                   uint64_t* new_root, uint8_t* status) {
+  SP_REQUIRE_READY();
+  TreeScope ts;
+  int rc = ts.open(tree);
+  if (rc != SP_OK) return rc;
+  return tree_update_locked(*ts.t, keys, leaves, n, old_root, new_root, status, nullptr);
+}
+
+// BASELINE.json configs[2] in ONE call: message-hash chains -> keyed signature verification -> order ids ->
+// orders-tree update, without returning to the caller between the stages (services/perpetual/cairo/order:
+// limit_order.cairo:24-52 hashes the order, order.cairo:23-31 takes the order id from the top 64 bits of the
+// message hash, :122-124 writes the fulfilled amount at that id, verify_ecdsa_signature checks the signature).
+//   words      depth x n felts, word-major (word k of order i at words + 4 (k n + i)): the chain
+//              h = H(...H(H(w0, w1), w2)..., w_{depth-1}) is the message hash z_i (written to z_out)
+//   r, s, qx, qy   the signatures and public keys (qy == NULL: x-only keys), verified against z_i mod 2^251
+//              through the key tables; verdicts[i] as sp_ecdsa_verify_batch
+//   leaves     the new orders-tree leaf of order i; its key is bits [id_shift, id_shift + 64) of z_i
+// The verification runs on a host lane WHILE the tree update's levels are hashed on the tree's stream; the new
+// nodes are committed only if every signature verified (the batch is all-or-nothing in the Cairo program),
+// otherwise *tree_status = SP_TREE_NOT_COMMITTED and the tree is unchanged.  Two orders with the same id are an
+// error (the caller squashes them first, state/state.cairo:67-96).
+int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t* r, const uint64_t* s,
+                   const uint64_t* qx, const uint64_t* qy, int tree, const uint64_t* leaves, unsigned id_shift,
+                   uint64_t* z_out, uint8_t* verdicts, uint64_t* old_root, uint64_t* new_root, uint8_t* tree_status) {
+  SP_REQUIRE_READY();
+  if (depth < 1 || id_shift > 192) { set_error("sp_order_batch: bad chain depth or id shift"); return SP_ERR_BAD_ARGUMENT; }
+  uint8_t chain_status = 0;
+  int rc = sp_pedersen_chains(words, n, depth, z_out, &chain_status);
+  if (rc != SP_OK) return rc;
+  if (chain_status != 0) {  // a word out of range / an unhashable pair: nothing else runs
+    if (tree_status) *tree_status = chain_status;
+    for (size_t i = 0; i < n; ++i) verdicts[i] = 0;
+    return sp_tree_root(tree, old_root) == SP_OK ? (std::memcpy(new_root, old_root, 32), SP_OK) : SP_ERR_BAD_ARGUMENT;
+  }
+  // order ids, sorted, with the leaves in the same order
+  std::vector<std::pair<uint64_t, size_t>> ids(n);
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t* z = z_out + 4 * i;
+    const unsigned w = id_shift >> 6, sh = id_shift & 63;
+    uint64_t v = z[w] >> sh;
+    if (sh && w + 1 < 4) v |= z[w + 1] << (64 - sh);
+    ids[i] = {v, i};
+  }
+  std::sort(ids.begin(), ids.end());
+  std::vector<uint64_t> keys(n), sorted_leaves(4 * n), z_sig(4 * n);
+  for (size_t j = 0; j < n; ++j) {
+    if (j > 0 && ids[j].first == ids[j - 1].first) { set_error("sp_order_batch: two orders share an order id"); return SP_ERR_BAD_ARGUMENT; }
+    keys[j] = ids[j].first;
+    std::memcpy(&sorted_leaves[4 * j], leaves + 4 * ids[j].second, 32);
+  }
+  for (size_t i = 0; i < n; ++i) {  // the signed message is z mod 2^251 (SIGNED_MESSAGE_BOUND)
+    std::memcpy(&z_sig[4 * i], z_out + 4 * i, 32);
+    z_sig[4 * i + 3] &= ((uint64_t)1 << 59) - 1;
+  }
+  int vrc = SP_OK;
+  std::thread verifier([&] { vrc = sp_ecdsa_verify_batch_keyed(z_sig.data(), r, s, qx, qy, verdicts, n); });
+  bool joined = false;
+  const std::function<bool()> all_verified = [&]() {
+    verifier.join();
+    joined = true;
+    if (vrc != SP_OK) return false;
+    for (size_t i = 0; i < n; ++i)
+      if (verdicts[i] != 1) return false;
+    return true;
+  };
+  {
+    TreeScope ts;
+    rc = ts.open(tree);
+    if (rc == SP_OK)
+      rc = tree_update_locked(*ts.t, keys.data(), sorted_leaves.data(), n, old_root, new_root, tree_status, &all_verified);
+  }
+  if (!joined) verifier.join();
+  if (rc != SP_OK) return rc;
+  return vrc;
 }
 
 }  // extern "C"

@@ -96,6 +96,10 @@ _SIGNATURES = {
     "sp_commit_rows_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p]),
     "sp_tree_create": (ctypes.c_int, [ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_tree_create_on": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]),
+    "sp_order_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_tree_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_tree_get": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

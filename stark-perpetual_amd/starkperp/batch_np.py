@@ -134,3 +134,29 @@ def limit_order_words(asset_sell, asset_buy, asset_fee, amount_sell, amount_buy,
 def limit_order_msgs(*args) -> np.ndarray:
     """Message hashes of n limit orders: four batched launches, arrays in and out."""
     return pedersen_chains(limit_order_words(*args))
+
+
+TREE_NOT_COMMITTED = 0x80  # include/starkperp.h SP_TREE_NOT_COMMITTED
+
+
+def order_batch(words, r, s, qx, tree, leaves, qy=None, id_shift=187):
+    """BASELINE.json configs[2] in ONE library call (sp_order_batch): message-hash chains of the n orders
+    (words uint64[depth, n, 4], e.g. limit_order_words) -> verification of (z mod 2^251, r, s, key) through the
+    key tables -> order ids (the top 64 bits of the 251-bit hash) -> update of `tree` (a state.LibrarySparseTree)
+    with leaves[i] at order id i.  The verification overlaps the tree's level hashing on the device; the tree
+    is committed only when every signature verified.
+    Returns (z uint64[n, 4], verdict codes uint8[n], old_root, new_root, committed)."""
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    assert w.ndim == 3 and w.shape[2] == 4 and w.shape[0] >= 2
+    depth, n = w.shape[0], w.shape[1]
+    r, s, qx, leaves = _felts(r, n), _felts(s, n), _felts(qx, n), _felts(leaves, n)
+    qy = None if qy is None else _felts(qy, n)
+    z = np.empty((n, 4), dtype=np.uint64)
+    verdicts = np.zeros(n, dtype=np.uint8)
+    old, new, st = _lib.new_felts(1), _lib.new_felts(1), np.zeros(1, dtype=np.uint8)
+    _lib.check(_lib.ensure_init().sp_order_batch(_ptr(w), depth, n, _ptr(r), _ptr(s), _ptr(qx),
+                                                 None if qy is None else _ptr(qy), tree._handle, _ptr(leaves), id_shift,
+                                                 _ptr(z), _ptr(verdicts), old, new, _ptr(st)), "sp_order_batch")
+    if st[0] & (HASH_OUT_OF_RANGE | HASH_UNHASHABLE):
+        _raise_hash_status(HASH_UNHASHABLE if st[0] & 2 else HASH_OUT_OF_RANGE)
+    return z, verdicts, _lib.unpack_felts(old, 1)[0], _lib.unpack_felts(new, 1)[0], st[0] == 0

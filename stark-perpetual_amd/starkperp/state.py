@@ -146,14 +146,15 @@ class LibrarySparseTree:
     instead of 270.  Same interface as SparseMerkleTree (`update`, `get`, `root`); node preimages
     are not exposed (the library stores nodes by position, not by hash)."""
 
-    def __init__(self, height: int, empty_leaf: int = 0):
+    def __init__(self, height: int, empty_leaf: int = 0, context: int = 0):
+        """context: which device of sp_init_devices keeps the tree (0 = the primary; one process per GPU has only that)."""
         import ctypes
         from . import _lib
         self._lib, self._ct = _lib, ctypes
         self.height = height
         handle = ctypes.c_int()
-        _lib.check(_lib.ensure_init().sp_tree_create(height, _lib.pack_felts([empty_leaf]), ctypes.byref(handle)),
-                   "sp_tree_create")
+        _lib.check(_lib.ensure_init().sp_tree_create_on(context, height, _lib.pack_felts([empty_leaf]),
+                                                        ctypes.byref(handle)), "sp_tree_create_on")
         self._handle = handle.value
 
     @property

@@ -244,3 +244,57 @@ def test_library_tree_large_batches_and_table_growth():
                 lib_tree.update_arrays(np.array(list(bad), dtype=np.uint64), bn.felts_from_ints(list(bad.values())))
             assert lib_tree.root == root and lib_tree.get_many(probe) == ref_tree.get_many(probe)
     lib_tree.close()
+
+
+def test_order_batch_in_one_call_matches_the_separate_calls():
+    """sp_order_batch (BASELINE configs[2] in one library call): message hashes, verdicts and the orders-tree roots
+    equal those of the separate entry points; a bad signature leaves the tree uncommitted; equal order ids are an
+    error; concurrent updates of two trees from two threads do not disturb each other."""
+    import threading
+    import numpy as np
+    import workloads as wl
+    from starkperp import batch, batch_np as bn, perpetual_messages as pm, state
+    orders = wl.limit_orders(512, seed=21)
+    keys = wl.private_keys(64, seed=22)
+    pubs = batch.public_keys_many(keys)
+    args = [wl.order_args(o) for o in orders]
+    words = np.stack([bn.felts_from_ints(col) for col in zip(*[pm._limit_order_words(*a) for a in args])])
+    zs = pm.limit_order_msgs_many(args)
+    sigs = batch.sign_many([z % 2**251 for z in zs], [keys[o["key_index"] % 64] for o in orders])
+    r, s = bn.felts_from_ints([a for a, _ in sigs]), bn.felts_from_ints([b for _, b in sigs])
+    qx = bn.felts_from_ints([pubs[o["key_index"] % 64][0] for o in orders])
+    leaves = bn.felts_from_ints([o["amount_synthetic"] + 1 for o in orders])
+    tree, twin = state.LibrarySparseTree(64, 0), state.LibrarySparseTree(64, 0)
+    seedling = {5: 7, 2**63 + 11: 9}
+    tree.update(seedling), twin.update(seedling)
+    z, verdicts, old, new, committed = bn.order_batch(words, r, s, qx, tree, leaves)
+    assert committed and bn.ints_from_felts(z) == zs and verdicts.tolist() == [1] * 512
+    want_old, want_new = twin.update({state.order_id_of(zz): o["amount_synthetic"] + 1 for zz, o in zip(zs, orders)})
+    assert (old, new) == (want_old, want_new) and tree.root == twin.root
+    # one bad signature: verdict 0, nothing committed
+    s_bad = s.copy()
+    s_bad[17, 0] ^= np.uint64(2)
+    leaves2 = bn.felts_from_ints([o["amount_synthetic"] + 2 for o in orders])
+    z2, verdicts2, old2, new2, committed2 = bn.order_batch(words, r, s_bad, qx, tree, leaves2)
+    assert not committed2 and verdicts2[17] == 0 and int(verdicts2.sum()) == 511 and old2 == new2 == want_new
+    assert tree.root == want_new and tree.get(state.order_id_of(zs[3])) == orders[3]["amount_synthetic"] + 1
+    # two orders with the same id
+    dup = np.concatenate([words[:, :4], words[:, :1]], axis=1)
+    pick = [0, 1, 2, 3, 0]
+    with pytest.raises(Exception):
+        bn.order_batch(dup, r[pick], s[pick], qx[pick], tree, leaves[pick])
+    assert tree.root == want_new
+    # two trees updated from two threads at once (each on its own stream, no library lock across the levels)
+    rng = random.Random(4)
+    batches = [{rng.randrange(2**64): rng.randrange(1, 2**64) for _ in range(2048)} for _ in range(4)]
+    got = {}
+
+    def run(name, t):
+        got[name] = [t.update(b) for b in batches]
+    ts = [threading.Thread(target=run, args=(nm, t)) for nm, t in (("a", tree), ("b", twin))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert got["a"] == got["b"] and tree.root == twin.root
+    tree.close(), twin.close()

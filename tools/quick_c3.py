@@ -8,5 +8,5 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 from starkperp import _lib
 lib = _lib.ensure_init(0, 26)
 e = b.extras(torch, lib, _lib, torch.device("cuda", 0), torch.cuda.current_stream().cuda_stream)
-for k in ("c3_4096_orders_host_inclusive_seconds", "c3_4096_orders_numpy_entry_points_seconds", "state_update_2048_positions_4096_orders_seconds", "single_tree_rebuild_ms_one_stream"):
+for k in ("c3_4096_orders_host_inclusive_seconds", "c3_4096_orders_numpy_entry_points_seconds", "c3_4096_orders_one_call_seconds", "state_update_2048_positions_4096_orders_seconds", "single_tree_rebuild_ms_one_stream"):
     print(k, json.dumps(e[k]))
