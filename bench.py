@@ -294,7 +294,7 @@ VALU_PEAK_SIMDS, VALU_NOMINAL_GHZ, VALU_CYCLES_PER_INSTR = 1024, 2.4, 4.0
 def _valu_counts(window_bits):
     """SQ_INSTS_VALU per hash of the bulk kernels (rocprofv3 --pmc, profiles/r0N_valu_issue.json, newest
     first); None when there is no measurement for this window width."""
-    for name in ("r02_valu_issue.json", "r01_valu_issue.json"):
+    for name in ("r03_valu_issue.json", "r02_valu_issue.json", "r01_valu_issue.json"):
         try:
             m = json.load(open(os.path.join(ROOT, "profiles", name)))
             w = m["window_bits"][str(window_bits)]
@@ -330,7 +330,7 @@ def valu_issue(hashes_per_sec, window_bits, workload, include_finish=True):
             "unit": "wave64 VALU instr/s", "frac": achieved / peak, "frac_at_2_cycle_peak": achieved / (2 * peak)}
 
 
-def pmc_traffic(kernel, this_config, files=("r02_pmc_traffic.json", "r01_pmc_traffic.json")):
+def pmc_traffic(kernel, this_config, files=("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE
     and --pmc WRITE_SIZE runs, tools/pmc_traffic.py; units and gfx950 calibration in its docstring), and
     the configuration those passes ran - traffic is only comparable with this run when they agree."""
@@ -742,8 +742,8 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
                 peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value),
                 hashes_in_timed_launches=int(k_units.value), avg_launch_us=avg_launch_s * 1e6,
                 timing="HIP events around every ped_accumulate_kernel launch inside the timed region",
-                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)) or {}).get("bytes_per_launch"),
-                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
+                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
+                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
                 hbm={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS}),
             "cpu_baseline": (cpu_airfri_baseline(10) if (world == 1 and not args.no_cpu_baseline) else None),
@@ -836,8 +836,8 @@ def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, tr
                 or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None},
                 kernel="ped_accumulate_kernel (row chains and commit-tree levels above 65 536 hashes)",
                 peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value), avg_launch_us=avg_launch_s * 1e6,
-                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)) or {}).get("bytes_per_launch"),
-                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
+                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
+                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
                 hbm={"bound": "hbm", "achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}),
             "cpu_baseline": None,
@@ -943,7 +943,7 @@ def airfri_object(torch, lib, _lib, dev, with_cpu):
                          "algorithmic_bytes": algo[k], "hbm_gb_per_s": algo[k] / phase_s[k] / 1e9,
                          "hbm_frac_of_8_tb_per_s": algo[k] / phase_s[k] / 1e9 / HBM_PEAK_GBS,
                          "traffic_per_launch_of_dominant_kernel": pmc_traffic(
-                             "sp::" + dominant[k][0], "airfri", ("r02_pmc_traffic_airfri.json",))} for k in phase_s}
+                             "sp::" + dominant[k][0], "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json"))} for k in phase_s}
     n_l = max(int(k_launches.value), 1)
     rate = (k_units.value / n_l) / ((k_ms.value / 1e3) / n_l) if k_ms.value > 0 else 0.0
     roof = valu_issue(rate, int(lib.sp_window_bits()),
@@ -952,8 +952,8 @@ def airfri_object(torch, lib, _lib, dev, with_cpu):
     roof.update({"kernel": "ped_accumulate_kernel (row chains and the tree levels above 65 536 hashes: %.0f %% of the "
                            "job's hashes)" % (100.0 * k_units.value / (3.0 * hashes)),
                  "launches": int(k_launches.value), "avg_launch_us": (k_ms.value / n_l) * 1e3,
-                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)) or {}).get("bytes_per_launch"),
-                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r02_pmc_traffic_airfri.json",)),
+                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
+                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
                  "hbm": {"achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}})
     out["roofline"] = roof

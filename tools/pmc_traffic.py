@@ -34,7 +34,12 @@ def per_kernel(path, counter):
     return acc
 
 
-TIMED_LAUNCHES = 4  # bulk launches of the timed region of `bench.py --steps 20` (one forest: levels 0..3)
+import os
+
+# bulk launches of the timed regions of the profiled `bench.py --steps 20` run: round 2 timed ONE forest (levels
+# 0..3 = 4 launches); round 3 repeats the region until 50 ms are timed and only levels 0 and 1 are pure
+# ped_accumulate_kernel launches (2 per region) - pass the count bench.py printed as roofline.launches
+TIMED_LAUNCHES = int(os.environ.get("PMC_TIMED_LAUNCHES", "4"))
 
 
 def main():
