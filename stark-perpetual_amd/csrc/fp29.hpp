@@ -613,6 +613,150 @@ SP_HD fe fe_inv_plain_gcd_var(const fe& x) {
   return r;
 }
 
+// ---- inversion steered by doubles (Lehmer's gcd, nearest-integer quotients) -------------------------
+// The divsteps batches above work from the LOW limb: 29 divsteps cost ~7.5 data-dependent iterations of
+// ~36 instructions and take ~14 bits off f g, so an inversion is 18.4 batches (matrix applications) and
+// ~140 iterations.  Working from the TOP with the FP64 unit is shorter on this chip (v_fma_f64 issues at the
+// rate of an integer multiply-add): per batch A and B become doubles by Horner (a 53-bit relative
+// approximation, no search for the leading limb), Euclid with nearest-integer quotients runs on the doubles
+// while the divisor stays above 2^-27 of the batch's larger input - ~10 steps of ~15 instructions, every
+// cofactor an exact integer below 2^29 - and the integer 2x2 matrix is applied to (A, B) exactly and to
+// their Bezout cofactors (D, E).  10 batches and ~100 Euclid steps per inversion
+// (tools/sim/lehmer_inverse_model.py is the executable model: counts, bounds, edge inputs).
+//   * Any quotient sequence gives a unimodular matrix, so the doubles only steer: a quotient that is off
+//     by one (rounding of a * rcp(b)) costs progress, never correctness.  Every remainder a - q b is exact
+//     in the fma (|a - q b| <= b/2 is a multiple of ulp(b)), so the doubles follow Euclid on the rounded
+//     pair exactly; applied to the true integers the last remainder is off by < 2^-22 of the input.
+//   * D x = A, E x = B (mod p) start as (0, 1) and need NO reduction: |E| <= 2p / |A| for remainders that
+//     at least halve (A E - B D = +-p is invariant), and the limbs hold 2^260.
+//   * A batch that starts with min(A, B) < 2^-27 max(A, B) would need a partial quotient no int32 matrix
+//     holds (x = 1, 2, ...; probability ~2^-27 per batch on random input): lehmer_batch reports it and the
+//     caller redoes the value with the divsteps inversion.
+// Variable time: public data only, like divsteps_29_var.
+struct lehmer_rows {
+  double ua, va, ub, vb;  // new A = ua A + va B, new B = ub A + vb B
+};
+SP_HD uint64_t lehmer_bits(double v) {
+  uint64_t u;
+  __builtin_memcpy(&u, &v, 8);
+  return u;
+}
+SP_HD double lehmer_from_bits(uint64_t u) {
+  double v;
+  __builtin_memcpy(&v, &u, 8);
+  return v;
+}
+// v with its sign flipped when s is negative (one 32-bit xor on the device)
+SP_HD double lehmer_flip(double v, double s) {
+  return lehmer_from_bits(lehmer_bits(v) ^ (lehmer_bits(s) & 0x8000000000000000ull));
+}
+// signed-limb integer (limbs 0..7 in [0, 2^29), limb 8 signed) -> nearest-ish double (7 roundings)
+SP_HD double lehmer_to_double(const fe& a) {
+  double s = (double)a.l[NL - 1];
+#pragma unroll
+  for (int i = NL - 2; i >= 0; --i) s = __builtin_fma(s, 536870912.0, (double)a.l[i]);
+  return s;
+}
+// a <- |a - q b| with q = nearest integer to a / b; the row (ua, va) follows.  b > 0.
+SP_HD void lehmer_step(double& a, double& ua, double& va, const double b, const double ub, const double vb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double rc = __builtin_amdgcn_rcp(b);
+#else
+  double rc = 1.0 / b;
+#endif
+  rc = __builtin_fma(rc, __builtin_fma(-b, rc, 1.0), rc);  // one Newton step: the quotient is good to ~2^-40
+  const double q = __builtin_rint(a * rc);
+  const double r = __builtin_fma(-q, b, a);
+  a = __builtin_fabs(r);
+  ua = lehmer_flip(__builtin_fma(-q, ub, ua), r);
+  va = lehmer_flip(__builtin_fma(-q, vb, va), r);
+}
+// a, b >= 0.  Returns false when the batch cannot be represented (see above); b == 0 gives the identity.
+SP_HD bool lehmer_batch(double a, double b, lehmer_rows& m) {
+  double ua = 1.0, va = 0.0, ub = 0.0, vb = 1.0;
+  const double lim = __builtin_fmax(a, b) * 0x1p-27;
+  const bool done = b == 0.0;
+  const bool ok = done | !(__builtin_fmin(a, b) < lim);
+  const double thresh = (ok & !done) ? __builtin_fmax(lim, 0.5) : __builtin_inf();
+  bool odd = false;
+  while (b >= thresh) {
+    lehmer_step(a, ua, va, b, ub, vb);
+    if (!(a >= thresh)) {
+      odd = true;
+      break;
+    }
+    lehmer_step(b, ub, vb, a, ua, va);
+  }
+  // the last (smaller) remainder goes to the B row: "B == 0" is the end test
+  m.ua = odd ? ub : ua;
+  m.va = odd ? vb : va;
+  m.ub = odd ? ua : ub;
+  m.vb = odd ? va : vb;
+  return ok;
+}
+// cx x + cy y as signed-limb integer (no shift, no reduction); |cx|, |cy| < 2^29
+SP_HD fe lehmer_row(const fe& x, const fe& y, int32_t cx, int32_t cy) {
+  const int64_t a = cx, b = cy;
+  int64_t c = 0;
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) {
+    c += a * x.l[i] + b * y.l[i];
+    r.l[i] = (int32_t)((uint32_t)c & LMASK);
+    c >>= LB;
+  }
+  c += a * x.l[NL - 1] + b * y.l[NL - 1];
+  SP_CHK32(c);
+  r.l[NL - 1] = (int32_t)c;
+  fe_pin(r);
+  return r;
+}
+// d * sign in (-3p, 3p) -> canonical
+SP_HD fe lehmer_finish(const fe& d, int32_t sf) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = (d.l[i] ^ sf) - sf;
+  r = fe_carry(r);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    if (r.l[8] < 0) r = fe_carry(fe_add(r, FE_P));
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (fe_geq_p_canon_limbs(r)) r = fe_carry(fe_sub(r, FE_P));
+  }
+  return r;
+}
+// Plain integer inverse, one value per lane: x canonical in [0, p) -> canonical x^-1 mod p (0 -> 0).
+SP_HD fe fe_inv_plain_lehmer(const fe& x) {
+  fe A = FE_P, B = x, D = FE_ZERO, E = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+  double ad = 0.0;
+  bool ok = true;
+  for (int it = 0; it < 24; ++it) {
+    ad = lehmer_to_double(A);
+    const double bd = lehmer_to_double(B);
+    lehmer_rows m;
+    ok &= lehmer_batch(__builtin_fabs(ad), __builtin_fabs(bd), m);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__all(bd == 0.0 || !ok)) break;
+#else
+    if (bd == 0.0 || !ok) break;
+#endif
+    // the batch ran on (|A|, |B|) = (sa A, sb B): fold the signs into the columns
+    const int32_t ua = (int32_t)lehmer_flip(m.ua, ad), va = (int32_t)lehmer_flip(m.va, bd);
+    const int32_t ub = (int32_t)lehmer_flip(m.ub, ad), vb = (int32_t)lehmer_flip(m.vb, bd);
+    const fe A2 = lehmer_row(A, B, ua, va), B2 = lehmer_row(A, B, ub, vb);
+    const fe D2 = lehmer_row(D, E, ua, va), E2 = lehmer_row(D, E, ub, vb);
+    A = A2; B = B2; D = D2; E = E2;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__any(!ok)) return fe_inv_plain_gcd_var(x);
+#else
+  if (!ok) return fe_inv_plain_gcd_var(x);
+#endif
+  return lehmer_finish(D, ad < 0.0 ? -1 : 0);  // A = +-1 (or p with D = 0 for x = 0)
+}
+
 // R^3 mod p: turns the plain inverse of a Montgomery value (a R)^-1 = a^-1 R^-1 into a^-1 R.
 constexpr fe FE_R3 = {{0x18c6c71b, 0x1f4501b7, 0xd98e2e, 0x677ffcc, 0x3aa2b83, 0xd8c0006, 0xc2709f0,
                        0x13c0a666, 0x7bcc3}};

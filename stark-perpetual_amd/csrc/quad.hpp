@@ -153,7 +153,8 @@ __device__ __forceinline__ void quad_gcd_update(fe& own, const trans2x2& t, int 
 }
 
 // x canonical in [0, p), identical on the four lanes of every quad -> canonical x^-1 mod p on every lane.
-__device__ __forceinline__ fe fe_inv_plain_quad(const fe& x, int k) {
+// (Round 3: the fallback of fe_inv_plain_quad below; until then the inversion of every small level.)
+__device__ __forceinline__ fe fe_inv_plain_quad_divsteps(const fe& x, int k) {
   const fe one = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
   fe own = k == 0 ? FE_P : (k == 1 ? x : (k == 2 ? FE_ZERO : one));  // f | g | d | e
   int32_t eta = -1;
@@ -183,6 +184,43 @@ __device__ __forceinline__ fe fe_inv_plain_quad(const fe& x, int k) {
     if (fe_geq_p_canon_limbs(r)) r = fe_carry(fe_sub(r, FE_P));
   }
   return r;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double f64_dpp(double v) {
+  const uint64_t u = lehmer_bits(v);
+  int32_t lo = __builtin_amdgcn_mov_dpp((int32_t)(uint32_t)u, CTRL, 0xF, 0xF, true);
+  int32_t hi = __builtin_amdgcn_mov_dpp((int32_t)(uint32_t)(u >> 32), CTRL, 0xF, 0xF, true);
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  return lehmer_from_bits((uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32));
+}
+
+// The same quad split for the double-steered inversion (fp29.hpp "inversion steered by doubles"): lane 0 keeps
+// A, 1: B, 2: D, 3: E.  Per batch every lane turns its own vector into a double (lanes 0 and 1 broadcast
+// theirs), all four run the same ~10 Euclid steps on the doubles, and each applies its own row of the integer
+// matrix: 18 multiply-adds and one carry chain.  ~10 batches instead of the 18.4 of the divsteps form, ~100
+// FP64 Euclid steps instead of ~140 integer divstep iterations of twice the length.
+// x canonical in [0, p), identical on the four lanes of every quad -> canonical x^-1 mod p on every lane.
+__device__ __forceinline__ fe fe_inv_plain_quad(const fe& x, int k) {
+  const fe one = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+  const bool odd = (k & 1) != 0;
+  fe own = k == 0 ? FE_P : (k == 1 ? x : (k == 2 ? FE_ZERO : one));  // A | B | D | E
+  double ad = 0.0;
+  bool ok = true;
+  for (int it = 0; it < 24; ++it) {
+    const double od = lehmer_to_double(own);
+    ad = f64_dpp<quad_perm(0, 0, 0, 0)>(od);
+    const double bd = f64_dpp<quad_perm(1, 1, 1, 1)>(od);
+    lehmer_rows m;
+    ok &= lehmer_batch(__builtin_fabs(ad), __builtin_fabs(bd), m);
+    if (__all(bd == 0.0 || !ok)) break;  // B == 0 on every quad of the wave (or the wave falls back)
+    // the batch ran on (|A|, |B|): the signs of A and B go into the columns of the matrix
+    const double co = odd ? lehmer_flip(m.vb, bd) : lehmer_flip(m.ua, ad);
+    const double cp = odd ? lehmer_flip(m.ub, ad) : lehmer_flip(m.va, bd);
+    own = lehmer_row(own, fe_dpp<quad_perm(1, 0, 3, 2)>(own), (int32_t)co, (int32_t)cp);
+  }
+  if (__any(!ok)) return fe_inv_plain_quad_divsteps(x, k);  // a partial quotient above 2^27 somewhere in the wave
+  return lehmer_finish(fe_dpp<quad_perm(2, 2, 2, 2)>(own), ad < 0.0 ? -1 : 0);  // A = +-1; D x = A
 }
 
 // Montgomery-form inverse; a (N-form, |value| < 16p) must be identical on the four lanes of every quad.

@@ -23,6 +23,14 @@ void t_fn_inv_fermat(const uint32_t* a, uint32_t* out) { from_mn(fn_inv_fermat(t
 void t_fe_inv_gcd(const uint32_t* a, uint32_t* out) { from_m(fe_inv_gcd(to_m(a)), out); }
 void t_fe_inv_gcd_var(const uint32_t* a, uint32_t* out) { from_m(fe_inv_gcd_var(to_m(a)), out); }
 void t_fe_inv_plain_gcd_var(const uint32_t* a, uint32_t* out) { store_plain(fe_inv_plain_gcd_var(load_plain(a)), out); }
+void t_fe_inv_plain_lehmer(const uint32_t* a, uint32_t* out) { store_plain(fe_inv_plain_lehmer(load_plain(a)), out); }
+// one batch of the double-steered Euclid on (|A|, |B|): rows out, returns 1 when the batch is representable
+int t_lehmer_batch(const uint32_t* a, const uint32_t* b, double* rows) {
+  lehmer_rows m;
+  const bool ok = lehmer_batch(__builtin_fabs(lehmer_to_double(load_plain(a))), __builtin_fabs(lehmer_to_double(load_plain(b))), m);
+  rows[0] = m.ua; rows[1] = m.va; rows[2] = m.ub; rows[3] = m.vb;
+  return ok ? 1 : 0;
+}
 void t_fe_half(const uint32_t* a, const uint32_t* b, uint32_t* out) {
   // half of (a - b) as plain integers: exercises negative and lazy inputs
   store_plain(fe_canon(fe_half(fe_sub(load_plain(a), load_plain(b)))), out);

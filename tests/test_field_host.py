@@ -267,3 +267,33 @@ def test_repeated_modified_jacobian_doubling(shim):
                 want = R.ec_double(want, a)
             assert (I(outs[0]), I(outs[1])) == want, (trial, k, "mjac")
             assert (I(outs[2]), I(outs[3])) == want, (trial, k, "jac")
+
+
+def test_fe_inv_lehmer(shim):
+    """The double-steered (Lehmer, nearest-integer quotients) inversion of the latency path: random values,
+    the edge values that need the divsteps fallback (a partial quotient above 2^27: small x, p - small,
+    powers of two), and one batch looked at from outside: unimodular integer rows below 2^29 that leave
+    a last remainder at least 22 bits below the larger input."""
+    rng = random.Random(11)
+    out = (ctypes.c_uint32 * 8)()
+    vals = [1, 2, 3, 4, 5, P - 1, P - 2, 2**251, 2**192 + 1, (P + 1) // 2, 2**29, 2**29 - 1, 2**58 + 1, P - 2**29]
+    vals += [2**k for k in range(0, 252, 7)] + [P - 2**k for k in range(1, 251, 11)]
+    vals += [rng.randrange(1, P) for _ in range(6000)] + [rng.randrange(1, 2**k) for k in (30, 53, 54, 64, 100, 128, 200) for _ in range(60)]
+    vals += [P // k for k in range(2, 40)] + [P // k + 1 for k in range(2, 40)]
+    for a in vals:
+        shim.t_fe_inv_plain_lehmer(W(a), out)
+        assert I(out) == pow(a, -1, P), hex(a)
+    shim.t_fe_inv_plain_lehmer(W(0), out)
+    assert I(out) == 0
+    rows = (ctypes.c_double * 4)()
+    for _ in range(500):
+        a = rng.randrange(2**200, 2**252)
+        b = rng.randrange(2**199, a)
+        assert shim.t_lehmer_batch(W(a), W(b), rows) == 1
+        ua, va, ub, vb = (int(v) for v in rows)
+        assert all(float(int(v)) == v for v in rows) and max(abs(ua), abs(va), abs(ub), abs(vb)) < 2**29
+        assert abs(ua * vb - va * ub) == 1
+        na, nb = ua * a + va * b, ub * a + vb * b
+        assert abs(nb) < a >> 22 and abs(na) < a      # B is the last remainder: below (2^-27 + 2^-23) A on the true integers
+    assert shim.t_lehmer_batch(W(P), W(1), rows) == 0          # partial quotient 2^251: not representable
+    assert shim.t_lehmer_batch(W(12345), W(0), rows) == 1 and list(rows) == [1.0, 0.0, 0.0, 1.0]
