@@ -625,7 +625,7 @@ SP_HD fe fe_inv_plain_gcd_var(const fe& x) {
 // (tools/sim/lehmer_inverse_model.py is the executable model: counts, bounds, edge inputs).
 //   * Any quotient sequence gives a unimodular matrix, so the doubles only steer: a quotient that is off
 //     by one (rounding of a * rcp(b)) costs progress, never correctness.  Every remainder a - q b is exact
-//     in the fma (|a - q b| <= b/2 is a multiple of ulp(b)), so the doubles follow Euclid on the rounded
+//     in the fma (|a - q b| <= |b| / 2 is a multiple of ulp(b)), so the doubles follow Euclid on the rounded
 //     pair exactly; applied to the true integers the last remainder is off by < 2^-22 of the input.
 //   * D x = A, E x = B (mod p) start as (0, 1) and need NO reduction: |E| <= 2p / |A| for remainders that
 //     at least halve (A E - B D = +-p is invariant), and the limbs hold 2^260.
@@ -657,19 +657,22 @@ SP_HD double lehmer_to_double(const fe& a) {
   for (int i = NL - 2; i >= 0; --i) s = __builtin_fma(s, 536870912.0, (double)a.l[i]);
   return s;
 }
-// a <- |a - q b| with q = nearest integer to a / b; the row (ua, va) follows.  b > 0.
-SP_HD void lehmer_step(double& a, double& ua, double& va, const double b, const double ub, const double vb) {
+// a <- a - q b with q = nearest integer to a / b (0 when `live` is false: a no-op); the row (ua, va) follows.
+// Remainders are SIGNED (|a - q b| <= |b| / 2): no absolute values and no sign flips in the loop, the matrix is
+// unimodular all the same.  b != 0 when live.  The quotient comes from the bare v_rcp_f64: its error only
+// matters at half-integers or for quotients above 2^20, and there it costs progress (a remainder above b / 2,
+// picked up by the next step), never correctness.
+SP_HD void lehmer_step(double& a, double& ua, double& va, const double b, const double ub, const double vb,
+                       const bool live) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double rc = __builtin_amdgcn_rcp(b);
+  const double rc = __builtin_amdgcn_rcp(b);
 #else
-  double rc = 1.0 / b;
+  const double rc = 1.0 / b;
 #endif
-  rc = __builtin_fma(rc, __builtin_fma(-b, rc, 1.0), rc);  // one Newton step: the quotient is good to ~2^-40
-  const double q = __builtin_rint(a * rc);
-  const double r = __builtin_fma(-q, b, a);
-  a = __builtin_fabs(r);
-  ua = lehmer_flip(__builtin_fma(-q, ub, ua), r);
-  va = lehmer_flip(__builtin_fma(-q, vb, va), r);
+  const double q = live ? __builtin_rint(a * rc) : 0.0;
+  a = __builtin_fma(-q, b, a);
+  ua = __builtin_fma(-q, ub, ua);
+  va = __builtin_fma(-q, vb, va);
 }
 // a, b >= 0.  Returns false when the batch cannot be represented (see above); b == 0 gives the identity.
 SP_HD bool lehmer_batch(double a, double b, lehmer_rows& m) {
@@ -678,16 +681,14 @@ SP_HD bool lehmer_batch(double a, double b, lehmer_rows& m) {
   const bool done = b == 0.0;
   const bool ok = done | !(__builtin_fmin(a, b) < lim);
   const double thresh = (ok & !done) ? __builtin_fmax(lim, 0.5) : __builtin_inf();
-  bool odd = false;
-  while (b >= thresh) {
-    lehmer_step(a, ua, va, b, ub, vb);
-    if (!(a >= thresh)) {
-      odd = true;
-      break;
-    }
-    lehmer_step(b, ub, vb, a, ua, va);
+  // Two steps per trip so that a and b keep their registers; the second one is switched off (q = 0) when
+  // the first already went below the threshold.  Straight-line body: one exec-mask update per trip.
+  while (__builtin_fmin(__builtin_fabs(a), __builtin_fabs(b)) >= thresh) {
+    lehmer_step(a, ua, va, b, ub, vb, true);
+    lehmer_step(b, ub, vb, a, ua, va, __builtin_fabs(a) >= thresh);
   }
   // the last (smaller) remainder goes to the B row: "B == 0" is the end test
+  const bool odd = __builtin_fabs(a) < __builtin_fabs(b);
   m.ua = odd ? ub : ua;
   m.va = odd ? vb : va;
   m.ub = odd ? ua : ub;
@@ -727,9 +728,11 @@ SP_HD fe lehmer_finish(const fe& d, int32_t sf) {
   }
   return r;
 }
-// Plain integer inverse, one value per lane: x canonical in [0, p) -> canonical x^-1 mod p (0 -> 0).
-SP_HD fe fe_inv_plain_lehmer(const fe& x) {
-  fe A = FE_P, B = x, D = FE_ZERO, E = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+// Bezout cofactor of x for gcd(modulus, x), one value per lane: on return (true) D sign = x^-1 (mod modulus)
+// with |D| < 2 modulus and sign = sf ? -1 : +1 (x = 0 gives D = 0).  false: the value needs the divsteps form.
+SP_HD bool lehmer_bezout(const fe& modulus, const fe& x, fe& D, int32_t& sf) {
+  fe A = modulus, B = x, E = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
+  D = FE_ZERO;
   double ad = 0.0;
   bool ok = true;
   for (int it = 0; it < 24; ++it) {
@@ -749,12 +752,19 @@ SP_HD fe fe_inv_plain_lehmer(const fe& x) {
     const fe D2 = lehmer_row(D, E, ua, va), E2 = lehmer_row(D, E, ub, vb);
     A = A2; B = B2; D = D2; E = E2;
   }
+  sf = ad < 0.0 ? -1 : 0;  // A = +-1 (or the modulus, with D = 0, for x = 0)
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (__any(!ok)) return fe_inv_plain_gcd_var(x);
+  return !__any(!ok);
 #else
-  if (!ok) return fe_inv_plain_gcd_var(x);
+  return ok;
 #endif
-  return lehmer_finish(D, ad < 0.0 ? -1 : 0);  // A = +-1 (or p with D = 0 for x = 0)
+}
+// Plain integer inverse, one value per lane: x canonical in [0, p) -> canonical x^-1 mod p (0 -> 0).
+SP_HD fe fe_inv_plain_lehmer(const fe& x) {
+  fe D;
+  int32_t sf;
+  if (!lehmer_bezout(FE_P, x, D, sf)) return fe_inv_plain_gcd_var(x);
+  return lehmer_finish(D, sf);
 }
 
 // R^3 mod p: turns the plain inverse of a Montgomery value (a R)^-1 = a^-1 R^-1 into a^-1 R.
@@ -926,10 +936,26 @@ SP_HD fe fn_inv(const fe& a) {
   return fn_mul(r, FN_R3);
 }
 
+// d * sign in (-3N, 3N) -> Montgomery form of the canonical value
+SP_HD fe fn_inv_finish(const fe& d, int32_t sf) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.l[i] = (d.l[i] ^ sf) - sf;
+  r = fe_carry(r);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    if (r.l[8] < 0) r = fe_carry(fe_add(r, FN_N));
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (limbs_geq(r, FN_N)) r = fe_carry(fe_sub(r, FN_N));
+  }
+  return fn_mul(r, FN_R3);
+}
+
 // Variable-time twin of fn_inv for PUBLIC scalars (w = s^-1 of a signature being verified): the same
 // divsteps_29_var batches as fe_inv_plain_gcd_var, transition matrices applied modulo N.
-SP_HD fe fn_inv_var(const fe& a) {
-  const fe x = fn_canon(fn_mul(a, FN_ONE_M));
+SP_HD fe fn_inv_plain_divsteps_var(const fe& x) {
   fe d = FE_ZERO, e = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
   fe f = FN_N, g = x;
   int32_t eta = -1;
@@ -947,20 +973,16 @@ SP_HD fe fn_inv_var(const fe& a) {
     if (nz == 0) break;
 #endif
   }
-  const int32_t sf = f.l[NL - 1] >> 31;
-  fe r;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) r.l[i] = (d.l[i] ^ sf) - sf;
-  r = fe_carry(r);
-#pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    if (r.l[8] < 0) r = fe_carry(fe_add(r, FN_N));
-  }
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    if (limbs_geq(r, FN_N)) r = fe_carry(fe_sub(r, FN_N));
-  }
-  return fn_mul(r, FN_R3);
+  return fn_inv_finish(d, f.l[NL - 1] >> 31);
+}
+// Round 3: the double-steered inversion (lehmer_bezout: the modulus only enters as the start value of A, the
+// cofactors need no reduction), the divsteps form above as its fallback.
+SP_HD fe fn_inv_var(const fe& a) {
+  const fe x = fn_canon(fn_mul(a, FN_ONE_M));
+  fe D;
+  int32_t sf;
+  if (!lehmer_bezout(FN_N, x, D, sf)) return fn_inv_plain_divsteps_var(x);
+  return fn_inv_finish(D, sf);
 }
 
 // a^(N-2) by square-and-multiply over the bits of N-2 (kept as a cross-check of fn_inv).

@@ -71,6 +71,7 @@ void t_fe_expr(const uint32_t* a, const uint32_t* b, const uint32_t* c, const ui
 void t_fn_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) { from_mn(fn_mul(to_mn(a), to_mn(b)), out); }
 void t_fn_inv(const uint32_t* a, uint32_t* out) { from_mn(fn_inv(to_mn(a)), out); }
 void t_fn_inv_var(const uint32_t* a, uint32_t* out) { from_mn(fn_inv_var(to_mn(a)), out); }
+void t_fn_inv_divsteps_var(const uint32_t* a, uint32_t* out) { from_mn(fn_inv_plain_divsteps_var(fn_canon(fn_mul(to_mn(a), FN_ONE_M))), out); }
 
 static void xyzz_to_aff_plain(const xyzz& p, uint32_t* x, uint32_t* y) {
   fe izzz = fe_inv(p.ZZZ);

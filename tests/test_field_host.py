@@ -208,8 +208,12 @@ def test_fn_inv_variable_time(shim):
     rng = random.Random(13)
     out = (ctypes.c_uint32 * 8)()
     vals = [1, 2, 3, N - 1, N - 2, 2**251, 2**250 + 1, (N + 1) // 2] + [rng.randrange(1, N) for _ in range(2000)]
+    vals += [2**k for k in range(0, 251, 9)] + [N - 2**k for k in range(0, 250, 13)] + [N // k for k in range(2, 30)]
     for a in vals:
-        shim.t_fn_inv_var(W(a), out)
+        shim.t_fn_inv_var(W(a), out)                 # double-steered form, divsteps fallback for the edge values
+        assert I(out) == pow(a, -1, N), hex(a)
+    for a in vals[:400]:
+        shim.t_fn_inv_divsteps_var(W(a), out)        # the fallback on its own
         assert I(out) == pow(a, -1, N), hex(a)
 
 

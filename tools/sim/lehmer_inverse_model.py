@@ -46,27 +46,30 @@ def exact_fnma(q, b, a, clamped):
 
 
 def euclid_batch(a, b, stats):
-    """a, b >= 0 doubles.  Returns rows (ua, va), (ub, vb) and parity so that
-    new_a = ua*a + va*b, new_b = ub*a + vb*b (as integers on the true values)."""
+    """a, b >= 0 doubles.  Returns the rows (ua, va), (ub, vb) with new_a = ua*a + va*b, new_b = ub*a + vb*b
+    (as integers on the true values), or None when the batch is not representable.  Remainders are signed
+    (nearest-integer quotients): no absolute values inside the loop, exactly as lehmer_batch does it."""
     ua, va, ub, vb = 1.0, 0.0, 0.0, 1.0
     a0 = max(a, b)
     thresh = max(a0 * 2.0**-27, 0.5)
-    steps = 0
     if min(a, b) < a0 * 2.0**-27:
         return None  # a partial quotient above 2^27: the caller falls back to the divsteps inversion
-    while b >= thresh:
-        rc = 1.0 / b
-        q = float(round(a * rc))  # rndne
-        r = exact_fnma(q, b, a, False)
-        nu = ua - q * ub
-        nv = va - q * vb
-        if r < 0:
-            r, nu, nv = -r, -nu, -nv
-        a, ua, va, b, ub, vb = b, ub, vb, r, nu, nv
+    steps = 0
+    while min(abs(a), abs(b)) >= thresh:
+        q = float(round(a * (1.0 / b)))  # rndne of a * rcp(b)
+        a = exact_fnma(q, b, a, False)
+        ua, va = ua - q * ub, va - q * vb
         steps += 1
-        assert abs(nu) < 2**53 and abs(nv) < 2**53
+        if abs(a) >= thresh:             # the second step of a trip is a no-op otherwise
+            q = float(round(b * (1.0 / a)))
+            b = exact_fnma(q, a, b, False)
+            ub, vb = ub - q * ua, vb - q * va
+            steps += 1
+        assert max(abs(ua), abs(va), abs(ub), abs(vb)) < 2**53
     stats["steps"] += steps
     stats["maxsteps"] = max(stats["maxsteps"], steps)
+    if abs(a) < abs(b):                  # the smaller remainder is the new B
+        ua, va, ub, vb = ub, vb, ua, va
     return ua, va, ub, vb
 
 
