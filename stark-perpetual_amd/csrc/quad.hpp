@@ -200,7 +200,9 @@ __device__ __forceinline__ double f64_dpp(double v) {
 // theirs), all four run the same ~10 Euclid steps on the doubles, and each applies its own row of the integer
 // matrix: 18 multiply-adds and one carry chain.  ~10 batches instead of the 18.4 of the divsteps form, ~100
 // FP64 Euclid steps instead of ~140 integer divstep iterations of twice the length.
-// x canonical in [0, p), identical on the four lanes of every quad -> canonical x^-1 mod p on every lane.
+// x: any N-form integer (limbs 0..7 in [0, 2^29), |value| < 16 p), identical on the four lanes of every quad
+// -> canonical x^-1 mod p on every lane (0 for a multiple of p).  The gcd does not care whether x is reduced:
+// A E - B D = +-p holds from the start, so |D| < 2p whatever the size of x.
 __device__ __forceinline__ fe fe_inv_plain_quad(const fe& x, int k) {
   const fe one = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
   const bool odd = (k & 1) != 0;
@@ -219,20 +221,24 @@ __device__ __forceinline__ fe fe_inv_plain_quad(const fe& x, int k) {
     const double cp = odd ? lehmer_flip(m.ub, ad) : lehmer_flip(m.va, bd);
     own = lehmer_row(own, fe_dpp<quad_perm(1, 0, 3, 2)>(own), (int32_t)co, (int32_t)cp);
   }
-  if (__any(!ok)) return fe_inv_plain_quad_divsteps(x, k);  // a partial quotient above 2^27 somewhere in the wave
-  return lehmer_finish(fe_dpp<quad_perm(2, 2, 2, 2)>(own), ad < 0.0 ? -1 : 0);  // A = +-1; D x = A
+  if (__any(!ok)) {  // a partial quotient above 2^27 somewhere in the wave: the divsteps form wants [0, p)
+    return fe_inv_plain_quad_divsteps(fe_canon(fe_mul(x, FE_ONE_M)), k);  // x * R / R: the value, reduced
+  }
+  const fe d = __builtin_fabs(ad) == 1.0 ? fe_dpp<quad_perm(2, 2, 2, 2)>(own) : FE_ZERO;  // gcd = p: x = 0 mod p
+  return lehmer_finish(d, ad < 0.0 ? -1 : 0);  // A = +-1; D x = A
 }
 
 // Montgomery-form inverse; a (N-form, |value| < 16p) must be identical on the four lanes of every quad.
+// The plain inverse of the representative a R is a^-1 R^-1; times R^3 (Montgomery product) gives a^-1 R.
 __device__ __forceinline__ fe fe_inv_quad(const fe& a, int k) {
-  const fe canon = fe_canon(fe_mul(a, FE_ONE_M));
-  return fe_mul(fe_inv_plain_quad(canon, k), FE_R3);
+  return fe_mul(fe_inv_plain_quad(a, k), FE_R3);
 }
 
 
 // One inversion for the four lanes of a quad that hold DIFFERENT values (Montgomery's trick across the
 // lanes): the quad multiplies its values together with two DPP rounds, inverts the product once with the
-// quad-split divsteps above (6.8 k instead of 4 x 12.9 k lane-private instructions, tools/ubench/lat_parts)
+// quad-split inversion above (divsteps form: 6.8 k instead of 4 x 12.9 k lane-private instructions; the
+// double-steered form: ~2.8 k, tools/ubench/inv_quad.hip)
 // and every lane recovers its own inverse with two more multiplications.
 //   LOG_DISTINCT = 0: the four lanes hold the same value            (fe_inv_quad)
 //                  1: lanes {0,1} hold one value, lanes {2,3} another

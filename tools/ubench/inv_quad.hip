@@ -50,8 +50,12 @@ __global__ void __launch_bounds__(64) check(const int32_t* in, int* bad, int spe
   const fe canon = fe_canon(a);
   const fe i0 = fe_inv_plain_quad_divsteps(canon, kq), i1 = fe_inv_plain_quad(canon, kq);
   const fe i2 = fe_inv_plain_lehmer(canon), i3 = fe_inv_plain_gcd_var(canon);
+  // unreduced representatives (x + 3p, x - 2p: what the callers hand over in N-form) must give the same inverse
+  const fe i4 = fe_inv_plain_quad(fe_carry(fe_add(fe_add(canon, FE_P), fe_dbl(FE_P))), kq);
+  const fe i5 = fe_inv_plain_quad(fe_carry(fe_sub(canon, fe_dbl(FE_P))), kq);
   int diff = 0;
-  for (int i = 0; i < NL; ++i) diff |= (i0.l[i] ^ i1.l[i]) | (i0.l[i] ^ i2.l[i]) | (i0.l[i] ^ i3.l[i]);
+  for (int i = 0; i < NL; ++i)
+    diff |= (i0.l[i] ^ i1.l[i]) | (i0.l[i] ^ i2.l[i]) | (i0.l[i] ^ i3.l[i]) | (i0.l[i] ^ i4.l[i]) | (i0.l[i] ^ i5.l[i]);
   // x * x^-1 == 1 (plain values: to Montgomery, multiply, back)
   const fe prod = fe_from_mont(fe_mul(fe_to_mont(canon), fe_to_mont(i1)));
   int one = prod.l[0] ^ 1;
@@ -89,7 +93,7 @@ int main() {
   check<<<1024, 64>>>(in, bad, 1);
   int h = -1;
   hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
-  printf("check: %d mismatching lanes over 262144 random + 65536 special lanes (four inversion forms, x * x^-1 == 1)\n", h);
+  printf("check: %d mismatching lanes over 262144 random + 65536 special lanes (four inversion forms + unreduced inputs, x * x^-1 == 1)\n", h);
   const int reps = 8;
   for (int blocks : {256, 1024, 2048}) {
     run<0, true>("quad-split divsteps, one value per wave", blocks, reps);
