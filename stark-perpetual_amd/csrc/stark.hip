@@ -26,27 +26,141 @@ namespace sp {
 constexpr int TILE_LOG = 11;
 constexpr int TILE = 1 << TILE_LOG;  // 2048 felts = 72 KiB of LDS as 9 x int32 planes
 #ifndef SP_NTT_THREADS
-#define SP_NTT_THREADS 512
+#define SP_NTT_THREADS 256
 #endif
-constexpr int NTT_THREADS = SP_NTT_THREADS;  // two blocks per CU (LDS): 512 threads = 4 waves per SIMD to cover the per-stage barriers
+constexpr int NTT_THREADS = SP_NTT_THREADS;  // 256 threads x 8 felts in registers = one radix-8 step of a tile; two blocks per CU (LDS)
 
+// Slot of tile element e inside a limb plane: bank bit i = e_i ^ e_(i+3).  The lanes of a wave walk the tile
+// with their six index bits at e3..e8 (radix-8 group of stages 0-2), at e0..e2 + e6..e8 (stages 3-5), at e0..e5
+// (stages 6+, loads, stores) or at e2..e7 (zero padding): each of these maps onto the five bank bits with rank 5,
+// i.e. two lanes per bank - what a wave64 access costs anyway.  The plain layout put the first two patterns on
+// 8 banks (68 % of the LDS cycles of the contiguous passes were bank conflicts, SQ_LDS_BANK_CONFLICT).
+__device__ __forceinline__ int lds_slot(int e) { return e ^ ((e >> 3) & 31); }
 __device__ __forceinline__ fe lds_get(const int32_t* lds, int e) {
+  const int s = lds_slot(e);
   fe v;
 #pragma unroll
-  for (int l = 0; l < NL; ++l) v.l[l] = lds[l * TILE + e];
+  for (int l = 0; l < NL; ++l) v.l[l] = lds[l * TILE + s];
   return v;
 }
 __device__ __forceinline__ void lds_put(int32_t* lds, int e, const fe& v) {
+  const int s = lds_slot(e);
 #pragma unroll
-  for (int l = 0; l < NL; ++l) lds[l * TILE + e] = v.l[l];
+  for (int l = 0; l < NL; ++l) lds[l * TILE + s] = v.l[l];
 }
 __device__ __forceinline__ fe ld_fe_packed(const uint64_t* p) { return fe_unpack(ld_u256(p)); }
 
+// Where a tile sits in the transform and where its twiddles come from.
+struct ntt_geom {
+  int log_c, log_lo, log_tw;
+  size_t lowb;                  // the tile's block of adjacent columns
+  const uint64_t* tw;           // omega^k, k < 2^(log_tw - 1), Montgomery, packed
+};
+// Twiddle of the butterfly whose lower element has coupled index k, column c, in stage t of the pass
+// (global span h = 2^(t + log_lo)): omega_{2h}^(index mod h).
+__device__ __forceinline__ u256 ntt_twiddle(const ntt_geom& g, int t, int k, int c) {
+  const size_t j = ((size_t)(k & ((1 << t) - 1)) << g.log_lo) | (g.lowb << g.log_c) | (size_t)c;
+  return ld_u256(g.tw + 4 * (j << (g.log_tw - 1 - t - g.log_lo)));
+}
+
+// LOGR consecutive radix-2 stages (t_lo .. t_lo + LOGR - 1 of the pass) on 2^LOGR felts held in REGISTERS:
+// one LDS round trip and one barrier per LOGR stages instead of per stage (round 2: eleven of each per tile,
+// every operand through LDS as nine int32 planes), and carries only where the limb bounds ask for one.
+// Bounds, in units of 2^29 per limb ("B"): tile values enter with limbs 0..7 in [0, 2^29) (B = 1); a product
+// is B = 1; a sum adds the bounds of its operands, a difference of two non-negative values keeps the larger
+// one; a multiplicand may be B <= 3 (27 * 2^58 < 2^63), an int32 limb holds B <= 4 strictly (4 (2^29 - 1) + a
+// carry of 3 is 2^31 - 1), and fe_carry is safe up to there.  The VALUE is a separate matter:
+//   DIT: a' = a + w b, b' = a - w b grow by one B and at most p per stage: three stages end at B = 4, every
+//     output gets ONE fe_carry and no value reduction (11 stages of a pass add < 12 p; fe_canon at the store).
+//   DIF: a' = a + b doubles, b' = (a - b) w is fresh.  Of the eight felts only x0, x1 need a carry before the
+//     third stage; at the end the sums are carried and only x0 - the one felt that is a pure sum of all
+//     inputs, whose value doubles per stage - gets its multiple of p taken off (fe_weak_reduce at B <= 2: its
+//     limb-6 adjustment of up to 2^27 must not meet a limb near 2^31; at B = 4 it would, and four limbs of
+//     2^29 - 1 each are exactly what "-small" values of a sparse polynomial look like).
+// `unit_low`: the lowest stage is stage 0 of the whole transform, whose twiddle is 1 - no multiplication.
+template <int LOGR, bool DIT, int U>
+__device__ __forceinline__ void ntt_stage(fe (&x)[1 << LOGR], int (&B)[1 << LOGR], const u256 (&tw)[1 << LOGR],
+                                          bool unit_low) {
+  constexpr int R = 1 << LOGR;
+  const bool unit = unit_low && U == 0;  // stage t_lo + U pairs x[i] with x[i + 2^U]
+#pragma unroll
+  for (int mm = 0; mm < (1 << U); ++mm) {
+    fe w = FE_ZERO;
+    if (!unit) w = fe_unpack(tw[(1 << U) + mm]);
+#pragma unroll
+    for (int hi = 0; hi < (R >> (U + 1)); ++hi) {
+      const int i0 = (hi << (U + 1)) | mm, i1 = i0 + (1 << U);
+      if (DIT) {
+        const fe wb = unit ? x[i1] : fe_mul(x[i1], w);
+        const int bw = unit ? B[i1] : 1;
+        x[i1] = fe_sub(x[i0], wb);
+        x[i0] = fe_add(x[i0], wb);
+        B[i0] = B[i1] = B[i0] + bw;
+      } else {
+        if (B[i0] + B[i1] > 4) {  // resolved at compile time: only x0, x1 before the last stage of a radix-8 group
+          x[i0] = fe_carry(x[i0]);
+          x[i1] = fe_carry(x[i1]);
+          B[i0] = B[i1] = 1;
+        }
+        const fe d = fe_sub(x[i0], x[i1]);  // |d| <= max(B): both operands have non-negative limbs
+        x[i0] = fe_add(x[i0], x[i1]);
+        x[i1] = unit ? d : fe_mul(d, w);
+        const int bs = B[i0] + B[i1];
+        B[i1] = unit ? (B[i0] > B[i1] ? B[i0] : B[i1]) + 1 : 1;  // a stored difference has signed limbs: carry it
+        B[i0] = bs;
+      }
+    }
+  }
+}
+template <int LOGR, bool DIT>
+__device__ __forceinline__ void ntt_group(int32_t* lds, const ntt_geom& g, int grp, int t_lo, bool unit_low) {
+  constexpr int R = 1 << LOGR;
+  const int c = grp & ((1 << g.log_c) - 1), kk = grp >> g.log_c;
+  const int k0 = ((kk >> t_lo) << (t_lo + LOGR)) | (kk & ((1 << t_lo) - 1));
+  const int e0 = (k0 << g.log_c) | c, estep = 1 << (t_lo + g.log_c);
+  // All 2^LOGR - 1 twiddles of the group are requested BEFORE the tile values are read from LDS: with two
+  // waves per SIMD nothing else hides a table fetch, and hipcc otherwise places every load right in front of its
+  // first use (seven exposed round trips per radix-8 group).  Slot 2^U + mm: stage U, pair class mm.
+  u256 tw[R];
+#pragma unroll
+  for (int U = 0; U < LOGR; ++U) {
+#pragma unroll
+    for (int mm = 0; mm < (1 << U); ++mm) {
+      if (!(unit_low && U == 0)) tw[(1 << U) + mm] = ntt_twiddle(g, t_lo + U, k0 + (mm << t_lo), c);
+    }
+  }
+  fe x[R];
+  int B[R];
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    x[m] = lds_get(lds, e0 + m * estep);
+    B[m] = 1;
+  }
+  if constexpr (DIT) {
+    ntt_stage<LOGR, DIT, 0>(x, B, tw, unit_low);
+    if constexpr (LOGR > 1) ntt_stage<LOGR, DIT, 1>(x, B, tw, unit_low);
+    if constexpr (LOGR > 2) ntt_stage<LOGR, DIT, 2>(x, B, tw, unit_low);
+  } else {
+    if constexpr (LOGR > 2) ntt_stage<LOGR, DIT, 2>(x, B, tw, unit_low);
+    if constexpr (LOGR > 1) ntt_stage<LOGR, DIT, 1>(x, B, tw, unit_low);
+    ntt_stage<LOGR, DIT, 0>(x, B, tw, unit_low);
+    // x0 = the sum of all inputs: the only value that grows geometrically.  Adjust at B <= 2 only.
+    if (B[0] > 2) x[0] = fe_carry(x[0]);
+    x[0] = fe_weak_reduce(x[0]);
+    B[0] = 1;
+  }
+#pragma unroll
+  for (int m = 0; m < R; ++m) lds_put(lds, e0 + m * estep, B[m] > 1 ? fe_carry(x[m]) : x[m]);
+}
+
 // One pass = `nst` consecutive radix-2 stages on tiles of 2^log_e felts (2^log_t coupled points x
-// 2^(log_e-log_t) adjacent columns).  Stage with global span h = 2^(t + log_lo):
+// 2^(log_e-log_t) adjacent columns), executed as radix-8 / radix-4 / radix-2 groups (ntt_group).  Stage with
+// global span h = 2^(t + log_lo):
 //   DIF (forward half of a natural->bit-reversed transform): a' = a + b, b' = (a - b) w
 //   DIT (bit-reversed->natural):                             a' = a + w b, b' = a - w b
 // with w = omega_{2h}^(index mod h) = tw[(index mod h) << (log_tw - 1 - t - log_lo)].
+// use_scale: bit 0 - multiply the outputs by `scale`; bit 1 - not the last pass: store a 256-bit representative
+// in (0, 3p) instead of the canonical one.
 // pad_log_b > 0 (first pass of the big transform of an LDE): `in` is the coefficient array of the small
 // transform (2^pad_log_n felts per column, bit-reversed order); slot e of the tile stands for
 // coef[idx >> pad_log_b] * G[bitrev(idx >> pad_log_b)] when the low pad_log_b bits of idx are zero and
@@ -79,48 +193,67 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
     }
     s_begin = pad_log_b < nst ? pad_log_b : nst;
   } else {
-    for (int e = threadIdx.x; e < E; e += NTT_THREADS) {
-      const int k = e >> log_c, c = e & (C - 1);
-      const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
-      lds_put(lds, e, ld_fe_packed(in + 4 * idx));
+    if (E == TILE) {  // the usual tile: all eight loads of a thread in flight before the first unpack
+      constexpr int PER = TILE / NTT_THREADS;
+      u256 v[PER];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int e = threadIdx.x + q * NTT_THREADS;
+        const int k = e >> log_c, c = e & (C - 1);
+        v[q] = ld_u256(in + 4 * (base | ((size_t)k << log_lo) | (size_t)c));
+      }
+#pragma unroll
+      for (int q = 0; q < PER; ++q) lds_put(lds, threadIdx.x + q * NTT_THREADS, fe_unpack(v[q]));
+    } else {
+      for (int e = threadIdx.x; e < E; e += NTT_THREADS) {
+        const int k = e >> log_c, c = e & (C - 1);
+        const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
+        lds_put(lds, e, ld_fe_packed(in + 4 * idx));  // 256-bit input: limbs 0..7 normal, top limb < 2^24
+      }
     }
   }
   __syncthreads();
-  for (int s = s_begin; s < nst; ++s) {
-    const int t = dit ? (t_first + s) : (t_first - s);
-    const int tmask = (1 << t) - 1;
-    // Sums stay lazy for one stage: a value that skipped its reduction has limbs < 2 * 2^29, the next
-    // stage either multiplies it by a twiddle (18 * 2^58 per column, fine) or adds one more N-form
-    // product to it (3 * 2^29 per limb) and reduces.  The last stage always reduces (fe_canon below
-    // wants a value in (-p, 2p)).
-    // DIT only: in a DIF stage both operands of the next butterfly may be unreduced sums.
-    const bool red = !dit || (((s - s_begin) & 1) != 0) || (s + 1 == nst);
-    for (int p = threadIdx.x; p < E / 2; p += NTT_THREADS) {
-      const int c = p & (C - 1), kk = p >> log_c;
-      const int k0 = ((kk >> t) << (t + 1)) | (kk & tmask);
-      const int e0 = (k0 << log_c) | c, e1 = e0 + (1 << (t + log_c));
-      const size_t j = ((size_t)(k0 & tmask) << log_lo) | (lowb << log_c) | (size_t)c;
-      const fe w = ld_fe_packed(tw + 4 * (j << (log_tw - 1 - t - log_lo)));
-      const fe a = lds_get(lds, e0), b = lds_get(lds, e1);
+  const ntt_geom g = {log_c, log_lo, log_tw, lowb, tw};
+  // the stages of the pass, lowest first: DIT walks them upwards, DIF downwards
+  int left = nst - s_begin;
+  int t_next = dit ? t_first + s_begin : t_first;  // next stage to do
+  while (left > 0) {
+    const int r = left >= 3 ? 3 : left;  // stages in this group
+    const int t_lo = dit ? t_next : t_next - r + 1;
+    const bool unit_low = (t_lo + log_lo) == 0;
+    const int groups = E >> r;
+    for (int grp = threadIdx.x; grp < groups; grp += NTT_THREADS) {
       if (dit) {
-        const fe wb = fe_mul(b, w);
-        const fe u = fe_add(a, wb), v = fe_sub(a, wb);
-        lds_put(lds, e0, red ? fe_weak_reduce(u) : u);
-        lds_put(lds, e1, red ? fe_weak_reduce(v) : v);
+        if (r == 3) ntt_group<3, true>(lds, g, grp, t_lo, unit_low);
+        else if (r == 2) ntt_group<2, true>(lds, g, grp, t_lo, unit_low);
+        else ntt_group<1, true>(lds, g, grp, t_lo, unit_low);
       } else {
-        const fe u = fe_add(a, b);
-        lds_put(lds, e0, red ? fe_weak_reduce(u) : u);
-        lds_put(lds, e1, fe_mul(fe_sub(a, b), w));
+        if (r == 3) ntt_group<3, false>(lds, g, grp, t_lo, unit_low);
+        else if (r == 2) ntt_group<2, false>(lds, g, grp, t_lo, unit_low);
+        else ntt_group<1, false>(lds, g, grp, t_lo, unit_low);
       }
     }
     __syncthreads();
+    left -= r;
+    t_next = dit ? t_next + r : t_next - r;
   }
   for (int e = threadIdx.x; e < E; e += NTT_THREADS) {
     const int k = e >> log_c, c = e & (C - 1);
     const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
     fe v = lds_get(lds, e);
-    if (use_scale) v = fe_mul(v, scale);
-    st_u256(out + 4 * idx, fe_pack(fe_canon(v)));
+    if (use_scale & 1) v = fe_mul(v, scale);
+    if (use_scale & 2) {
+      // Between the passes of one transform the felt only has to FIT 256 bits: take floor(v / 2^251) - 1 multiples
+      // of p off (value in (0, 3p), one carry chain) instead of the three chains of the canonical form.  The next
+      // pass unpacks it to normal limbs and a top limb below 2^21 - all its bounds ask for.
+      const int32_t q = (v.l[8] >> 19) - 1;
+      v.l[0] -= q;
+      v.l[6] -= q * P6;
+      v.l[8] -= q * P8;
+      st_u256(out + 4 * idx, fe_pack(fe_carry(v)));
+    } else {
+      st_u256(out + 4 * idx, fe_pack(fe_canon(v)));
+    }
   }
 }
 
@@ -924,6 +1057,7 @@ static int coset_table(int log_n, int log_blowup, const uint64_t* shift_host, co
 // natural.  in/out may alias.  Values are plain integers throughout (see the file comment).  With
 // pad_log_b > 0 (dit only) `in` is the bit-reversed coefficient array of 2^(log_n - pad_log_b) felts per
 // column and the zero-padded, coset-scaled input of the transform exists only in LDS.
+static const bool g_ntt_lazy_store = getenv("STARKPERP_NTT_CANON_ALL") == nullptr;  // A/B switch
 static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse, int dit, int use_scale,
                       fe scale, hipStream_t st, unsigned ncols = 1, size_t in_col_stride = 0,
                       size_t out_col_stride = 0, const uint64_t* pad_G = nullptr, int pad_log_b = 0) {
@@ -973,7 +1107,7 @@ static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse,
     const unsigned blocks = (unsigned)(((size_t)1 << log_n) >> ps.log_e);
     const int pb = first ? pad_log_b : 0;
     hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks, ncols), dim3(NTT_THREADS), 0, st, src, out, ps.log_e, ps.log_t,
-                       ps.log_lo, ps.nst, ps.t_first, dit, tw, log_n, last ? use_scale : 0, scale, src_stride,
+                       ps.log_lo, ps.nst, ps.t_first, dit, tw, log_n, last ? (use_scale ? 1 : 0) : (g_ntt_lazy_store ? 2 : 0), scale, src_stride,
                        out_col_stride, pb ? pad_G : (const uint64_t*)nullptr, pb, pb ? log_n - pad_log_b : 0);
     src = out;
     src_stride = out_col_stride;

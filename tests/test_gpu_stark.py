@@ -90,6 +90,43 @@ def test_ntt_and_lde_at_the_maximum_size(stark):
     assert got == [f(stark.FIELD_GEN * pow(w, i, P) % P) for i in spots]
 
 
+def test_ntt_and_lde_of_sparse_polynomials_at_every_size(stark):
+    """Every pass plan of the register-blocked NTT (local only, one and two strided passes; radix-8 / 4 / 2 groups;
+    the unit-twiddle stage) at log_n = 2 .. 22: forward transform and coset LDE (x2, x4) of a sparse polynomial
+    against its definition, and the inverse transform back to the coefficients.  Sparse polynomials matter: their
+    evaluations contain "minus small" values whose limbs are all 2^29 - 1 - four of those in one lazy sum sit at
+    the edge of an int32 limb, which random data never does (a value reduction on such a sum once wrapped limb 6)."""
+    import torch
+    for log_n in range(2, 23):
+        n = 1 << log_n
+        coeffs = {0: 5, 1: 7, 57 % n: 11, n - 1: 13, n // 2 + 1: 17}
+
+        def sparse(size):
+            t = torch.zeros((size, 4), dtype=torch.int64, device="cuda")
+            for k, v in coeffs.items():
+                t[k, 0] += v
+            return t
+
+        merged = {}
+        for k, v in coeffs.items():
+            merged[k] = merged.get(k, 0) + v
+
+        def f(x):
+            return sum(v * pow(x, k, P) for k, v in merged.items()) % P
+
+        w = S.root_of_unity(log_n)
+        spots = sorted({0, 1, 2, 777 % n, n // 2, n - 1, 0x2345678 % n, n // 3})
+        ev = stark.ntt(sparse(n))
+        assert stark.tensor_to_felts(ev[spots]) == [f(pow(w, i, P)) for i in spots], log_n
+        assert torch.equal(stark.ntt(ev, inverse=True), sparse(n)), log_n
+        for bl in (1, 2):
+            m = n << bl
+            wm = S.root_of_unity(log_n + bl)
+            ext = stark.lde(ev.unsqueeze(0), blowup_log=bl)[0]
+            sp = sorted({0, 1, 2, 3, 777 % m, m // 2, m - 1, 0x2345678 % m, m // 3})
+            assert stark.tensor_to_felts(ext[sp]) == [f(stark.FIELD_GEN * pow(wm, i, P) % P) for i in sp], (log_n, bl)
+
+
 def test_lde_matches_oracle(stark):
     import torch
     rng = random.Random(3)
