@@ -728,8 +728,10 @@ SP_HD fe lehmer_finish(const fe& d, int32_t sf) {
   }
   return r;
 }
-// Bezout cofactor of x for gcd(modulus, x), one value per lane: on return (true) D sign = x^-1 (mod modulus)
-// with |D| < 2 modulus and sign = sf ? -1 : +1 (x = 0 gives D = 0).  false: the value needs the divsteps form.
+// Bezout cofactor of x for gcd(modulus, x), one value per lane.  x: any signed-limb integer with limbs 0..7 in
+// [0, 2^29) and |x| < 16 modulus (reduced or not: A E - B D = +-modulus holds from the start, so |D| < 2 modulus
+// whatever the size of x).  On return (true) D sign = x^-1 (mod modulus), sign = sf ? -1 : +1, and D = 0 when
+// x is a multiple of the modulus.  false: some value of the wave needs the divsteps form.
 SP_HD bool lehmer_bezout(const fe& modulus, const fe& x, fe& D, int32_t& sf) {
   fe A = modulus, B = x, E = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
   D = FE_ZERO;
@@ -752,7 +754,8 @@ SP_HD bool lehmer_bezout(const fe& modulus, const fe& x, fe& D, int32_t& sf) {
     const fe D2 = lehmer_row(D, E, ua, va), E2 = lehmer_row(D, E, ub, vb);
     A = A2; B = B2; D = D2; E = E2;
   }
-  sf = ad < 0.0 ? -1 : 0;  // A = +-1 (or the modulus, with D = 0, for x = 0)
+  sf = ad < 0.0 ? -1 : 0;  // A = +-1 - or +-modulus for a multiple of the modulus (reduced or not): answer 0
+  if (__builtin_fabs(ad) != 1.0) D = FE_ZERO;
 #if defined(__HIP_DEVICE_COMPILE__)
   return !__any(!ok);
 #else
@@ -781,11 +784,20 @@ SP_HD fe fe_inv_gcd_var(const fe& a) {
   const fe canon = fe_canon(fe_mul(a, FE_ONE_M));
   return fe_mul(fe_inv_plain_gcd_var(canon), FE_R3);
 }
+// Round 3: the double-steered form on the representative as it comes (no reduction multiplication, no canonical
+// form in front of the gcd), the divsteps form as its fallback.  12 us instead of 33 us on a lone wave of 64
+// distinct values (tools/ubench/inv_quad.hip).
+SP_HD fe fe_inv_lehmer(const fe& a) {
+  fe D;
+  int32_t sf;
+  if (!lehmer_bezout(FE_P, fe_carry(a), D, sf)) return fe_inv_gcd_var(a);
+  return fe_mul(lehmer_finish(D, sf), FE_R3);
+}
 
 // The inversion used everywhere (public data only: hash outputs, signature verification; the
 // mod-N inversion used by signing, fn_inv, stays fixed-length).
 #ifndef SP_INV_CONST_TIME
-SP_HD fe fe_inv(const fe& a) { return fe_inv_gcd_var(a); }
+SP_HD fe fe_inv(const fe& a) { return fe_inv_lehmer(a); }
 #else
 SP_HD fe fe_inv(const fe& a) { return fe_inv_gcd(a); }
 #endif

@@ -1005,14 +1005,16 @@ static int build_powers(DeviceBuffer& buf, size_t count, fe base_m, fe factor_m,
   std::vector<fe> pw(nbits);
   fe cur = base_m;
   for (int b = 0; b < nbits; ++b) { pw[b] = fe_mul(cur, FE_ONE_M); cur = fe_sqr(cur); }
-  fe* d_pw = nullptr;
-  SP_HIP(hipMalloc(&d_pw, nbits * sizeof(fe)));
-  SP_HIP(hipMemcpy(d_pw, pw.data(), nbits * sizeof(fe), hipMemcpyHostToDevice));
+  struct DevPowers {  // freed on every exit (the error paths leaked it)
+    fe* p = nullptr;
+    ~DevPowers() { if (p) (void)hipFree(p); }
+  } d_pw;
+  SP_HIP(hipMalloc(&d_pw.p, nbits * sizeof(fe)));
+  SP_HIP(hipMemcpy(d_pw.p, pw.data(), nbits * sizeof(fe), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(powers_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
-                     (uint64_t*)buf.ptr, count, d_pw, nbits, factor_m);
+                     (uint64_t*)buf.ptr, count, d_pw.p, nbits, factor_m);
   SP_HIP(hipGetLastError());
   SP_HIP(hipStreamSynchronize(st));
-  (void)hipFree(d_pw);
   return SP_OK;
 }
 

@@ -23,6 +23,11 @@ void t_fn_inv_fermat(const uint32_t* a, uint32_t* out) { from_mn(fn_inv_fermat(t
 void t_fe_inv_gcd(const uint32_t* a, uint32_t* out) { from_m(fe_inv_gcd(to_m(a)), out); }
 void t_fe_inv_gcd_var(const uint32_t* a, uint32_t* out) { from_m(fe_inv_gcd_var(to_m(a)), out); }
 void t_fe_inv_plain_gcd_var(const uint32_t* a, uint32_t* out) { store_plain(fe_inv_plain_gcd_var(load_plain(a)), out); }
+void t_fe_inv_lehmer_lazy(const uint32_t* a, int k, uint32_t* out) {  // Montgomery form + k p, uncarried
+  fe v = to_m(a);
+  for (int i = 0; i < (k < 0 ? -k : k); ++i) v = k < 0 ? fe_sub(v, FE_P) : fe_add(v, FE_P);
+  from_m(fe_inv_lehmer(v), out);
+}
 void t_fe_inv_plain_lehmer(const uint32_t* a, uint32_t* out) { store_plain(fe_inv_plain_lehmer(load_plain(a)), out); }
 // one batch of the double-steered Euclid on (|A|, |B|): rows out, returns 1 when the batch is representable
 int t_lehmer_batch(const uint32_t* a, const uint32_t* b, double* rows) {

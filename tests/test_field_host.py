@@ -289,6 +289,13 @@ def test_fe_inv_lehmer(shim):
         assert I(out) == pow(a, -1, P), hex(a)
     shim.t_fe_inv_plain_lehmer(W(0), out)
     assert I(out) == 0
+    for a in vals[:60] + vals[-200:]:                  # fe_inv: Montgomery form, unreduced representatives
+        for k in (0, 3, -2, 9):
+            shim.t_fe_inv_lehmer_lazy(W(a), k, out)
+            assert I(out) == pow(a, -1, P), (hex(a), k)
+    for k in (0, 1, 5, -3):
+        shim.t_fe_inv_lehmer_lazy(W(0), k, out)      # any representative of zero answers zero
+        assert I(out) == 0, k
     rows = (ctypes.c_double * 4)()
     for _ in range(500):
         a = rng.randrange(2**200, 2**252)
