@@ -548,7 +548,7 @@ def main():
             "bound": "valu_issue", "achieved": None, "peak": valu_peak(), "unit": "wave64 VALU instr/s", "frac": None}
         roof.update({
             "kernel": "ped_accumulate_kernel (one lane per hash: every level of more than 65 536 hashes; %.0f %% of "
-                      "the hashes of this run)" % (100.0 * k_units.value / max(hashes_per_step * args.steps / max(world, 1), 1)),
+                      "the hashes of this run)" % (100.0 * k_units.value / max(len(regions) * hashes_per_step * args.steps / max(world, 1), 1)),
             "peak_basis": VALU_PEAK_NOTE,
             "launches": int(k_launches.value), "hashes_per_launch": hashes_per_launch,
             "avg_launch_us": avg_launch_s * 1e6,
