@@ -167,7 +167,8 @@ int sp_tree_root(int tree, uint64_t* root);
  * (the level launches) runs without the library lock, so other trees and the stateless batches go on meanwhile. */
 /* BASELINE.json configs[2] in one call (services/perpetual/cairo/order/limit_order.cairo:24-52, order.cairo:23-31,
  * :122-124): message-hash chains of n orders (words: depth x n felts, word-major; z_out receives the hashes) ->
- * verification of (z mod 2^251, r, s, key) through the key tables (verdicts as sp_ecdsa_verify_batch; qy == NULL:
+ * verification of (z, r, s, key) through the key tables (verdicts as sp_ecdsa_verify_batch - a z of 2^251 or more is
+ * SP_VERIFY_ASSERT_MSG and nothing is committed, constants.cairo:57 SIGNED_MESSAGE_BOUND; qy == NULL:
  * x-only keys) -> order id = bits [id_shift, id_shift + 64) of z (187 for the 251-bit message: the top 64 bits) ->
  * update of the orders tree `tree` with leaves[i] at order id i.  Verification and tree hashing overlap on the
  * device; the new nodes are committed only when every signature verified, otherwise *tree_status =

@@ -386,6 +386,8 @@ struct SparseTree {
   hipStream_t stream = nullptr;
   DeviceBuffer buf;
   std::mutex mu;
+  bool destroyed = false;  // set by sp_tree_destroy under `mu`: a thread that was waiting for the mutex with the
+                           // old handle must not revive the freed tree
 };
 
 static std::map<int, std::shared_ptr<SparseTree>> g_trees;
@@ -420,6 +422,7 @@ struct TreeScope {
       t = it->second;
     }
     held = std::unique_lock<std::mutex>(t->mu);
+    if (t->destroyed) { set_error("unknown tree handle"); return SP_ERR_BAD_ARGUMENT; }
     previous_ctx = ctx_current();
     ctx_select(t->ctx_index);
     const int dev = ctx().device;
@@ -637,6 +640,7 @@ int sp_tree_destroy(int tree) {
       g_trees.erase(tree);
     }
     tree_free(*ts.t);  // waits for the tree's stream
+    ts.t->destroyed = true;
   }
   return SP_OK;
 }
@@ -693,8 +697,8 @@ int sp_tree_update(int tree, const uint64_t* keys, const uint64_t* leaves, size_
 // message hash, :122-124 writes the fulfilled amount at that id, verify_ecdsa_signature checks the signature).
 //   words      depth x n felts, word-major (word k of order i at words + 4 (k n + i)): the chain
 //              h = H(...H(H(w0, w1), w2)..., w_{depth-1}) is the message hash z_i (written to z_out)
-//   r, s, qx, qy   the signatures and public keys (qy == NULL: x-only keys), verified against z_i mod 2^251
-//              through the key tables; verdicts[i] as sp_ecdsa_verify_batch
+//   r, s, qx, qy   the signatures and public keys (qy == NULL: x-only keys), verified against z_i through the
+//              key tables; verdicts[i] as sp_ecdsa_verify_batch (z_i >= 2^251: SP_VERIFY_ASSERT_MSG, nothing committed)
 //   leaves     the new orders-tree leaf of order i; its key is bits [id_shift, id_shift + 64) of z_i
 // The verification runs on a host lane WHILE the tree update's levels are hashed on the tree's stream; the new
 // nodes are committed only if every signature verified (the batch is all-or-nothing in the Cairo program),
@@ -713,6 +717,20 @@ int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t
     for (size_t i = 0; i < n; ++i) verdicts[i] = 0;
     return sp_tree_root(tree, old_root) == SP_OK ? (std::memcpy(new_root, old_root, 32), SP_OK) : SP_ERR_BAD_ARGUMENT;
   }
+  // A message hash of 2^251 or more is not a signed message (constants.cairo:57 SIGNED_MESSAGE_BOUND,
+  // order.cairo:22; signature.py:227 asserts the same bound): its order id would not fit the 64-bit field, so
+  // the batch cannot be committed - the verdicts say which orders (SP_VERIFY_ASSERT_MSG) and the tree stays.
+  bool unsigned_message = false;
+  for (size_t i = 0; i < n; ++i) unsigned_message |= (z_out[4 * i + 3] >> 59) != 0;
+  if (unsigned_message) {
+    rc = sp_ecdsa_verify_batch_keyed(z_out, r, s, qx, qy, verdicts, n);
+    if (rc != SP_OK) return rc;
+    if (tree_status) *tree_status = SP_TREE_NOT_COMMITTED;
+    rc = sp_tree_root(tree, old_root);
+    if (rc != SP_OK) return rc;
+    std::memcpy(new_root, old_root, 32);
+    return SP_OK;
+  }
   // order ids, sorted, with the leaves in the same order
   std::vector<std::pair<uint64_t, size_t>> ids(n);
   for (size_t i = 0; i < n; ++i) {
@@ -723,18 +741,14 @@ int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t
     ids[i] = {v, i};
   }
   std::sort(ids.begin(), ids.end());
-  std::vector<uint64_t> keys(n), sorted_leaves(4 * n), z_sig(4 * n);
+  std::vector<uint64_t> keys(n), sorted_leaves(4 * n);
   for (size_t j = 0; j < n; ++j) {
     if (j > 0 && ids[j].first == ids[j - 1].first) { set_error("sp_order_batch: two orders share an order id"); return SP_ERR_BAD_ARGUMENT; }
     keys[j] = ids[j].first;
     std::memcpy(&sorted_leaves[4 * j], leaves + 4 * ids[j].second, 32);
   }
-  for (size_t i = 0; i < n; ++i) {  // the signed message is z mod 2^251 (SIGNED_MESSAGE_BOUND)
-    std::memcpy(&z_sig[4 * i], z_out + 4 * i, 32);
-    z_sig[4 * i + 3] &= ((uint64_t)1 << 59) - 1;
-  }
   int vrc = SP_OK;
-  std::thread verifier([&] { vrc = sp_ecdsa_verify_batch_keyed(z_sig.data(), r, s, qx, qy, verdicts, n); });
+  std::thread verifier([&] { vrc = sp_ecdsa_verify_batch_keyed(z_out, r, s, qx, qy, verdicts, n); });
   bool joined = false;
   const std::function<bool()> all_verified = [&]() {
     verifier.join();

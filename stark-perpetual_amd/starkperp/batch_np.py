@@ -67,7 +67,7 @@ def pedersen_hash_many(x, y) -> np.ndarray:
 def pedersen_chains(words) -> np.ndarray:
     """words uint64[depth, n, 4]: row i of the result = H(...H(H(w[0][i], w[1][i]), w[2][i])..., w[-1][i])."""
     w = np.ascontiguousarray(words, dtype=np.uint64)
-    assert w.ndim == 3 and w.shape[2] == 4 and w.shape[0] >= 2
+    assert w.ndim == 3 and w.shape[2] == 4 and w.shape[0] >= 1
     depth, n = w.shape[0], w.shape[1]
     out = np.empty((n, 4), dtype=np.uint64)
     if n == 0:
@@ -113,6 +113,8 @@ def verify_many(z, r, s, qx, qy=None) -> np.ndarray:
 def order_ids(message_hashes) -> np.ndarray:
     """order/order.cairo:23-59: the 64 most significant bits of the 251-bit message hash, uint64[n]."""
     h = _felts(message_hashes)
+    # 0 <= message_hash < SIGNED_MESSAGE_BOUND (order.cairo:22): a larger hash has no 64-bit order id
+    assert not np.any(h[:, 3] >> np.uint64(59)), "message hash >= 2**251"
     return (h[:, 2] >> np.uint64(59)) | (h[:, 3] << np.uint64(5))
 
 
@@ -141,13 +143,14 @@ TREE_NOT_COMMITTED = 0x80  # include/starkperp.h SP_TREE_NOT_COMMITTED
 
 def order_batch(words, r, s, qx, tree, leaves, qy=None, id_shift=187):
     """BASELINE.json configs[2] in ONE library call (sp_order_batch): message-hash chains of the n orders
-    (words uint64[depth, n, 4], e.g. limit_order_words) -> verification of (z mod 2^251, r, s, key) through the
-    key tables -> order ids (the top 64 bits of the 251-bit hash) -> update of `tree` (a state.LibrarySparseTree)
+    (words uint64[depth, n, 4], e.g. limit_order_words; depth 1 = the message hashes themselves) -> verification of
+    (z, r, s, key) through the key tables (z >= 2^251 is no signed message: verdict VERIFY_ASSERT_MSG = 5 and nothing
+    is committed, constants.cairo:57) -> order ids (the top 64 bits of the 251-bit hash) -> update of `tree` (a state.LibrarySparseTree)
     with leaves[i] at order id i.  The verification overlaps the tree's level hashing on the device; the tree
     is committed only when every signature verified.
     Returns (z uint64[n, 4], verdict codes uint8[n], old_root, new_root, committed)."""
     w = np.ascontiguousarray(words, dtype=np.uint64)
-    assert w.ndim == 3 and w.shape[2] == 4 and w.shape[0] >= 2
+    assert w.ndim == 3 and w.shape[2] == 4 and w.shape[0] >= 1
     depth, n = w.shape[0], w.shape[1]
     r, s, qx, leaves = _felts(r, n), _felts(s, n), _felts(qx, n), _felts(leaves, n)
     qy = None if qy is None else _felts(qy, n)

@@ -298,3 +298,36 @@ def test_order_batch_in_one_call_matches_the_separate_calls():
         t.join()
     assert got["a"] == got["b"] and tree.root == twin.root
     tree.close(), twin.close()
+
+
+def test_order_batch_refuses_a_message_hash_of_2p251_or_more():
+    """order.cairo:22 / constants.cairo:57: a message hash is a signed message only below 2^251 (the order id is its
+    top 64 bits); signature.py:227 asserts the same bound.  With depth 1 the words ARE the message hashes, so the
+    case can be stated: the order with z >= 2^251 gets SP_VERIFY_ASSERT_MSG, the others their verdicts, and the tree
+    stays as it was - the hash is NOT reduced modulo 2^251 and verified as another message."""
+    import numpy as np
+    import workloads as wl
+    from starkperp import batch, batch_np as bn, state
+    keys = wl.private_keys(8, seed=31)
+    pubs = batch.public_keys_many(keys)
+    rng = random.Random(32)
+    zs = [rng.randrange(2**251) for _ in range(8)]
+    zs[3] = rng.randrange(2**192)  # so that 2^251 + z is still a field element
+    sigs = batch.sign_many(zs, keys)
+    over = 2**251 + zs[3]  # < p; the same low 251 bits as the message order 3 was signed for
+    assert over < 2**251 + 17 * 2**192 + 1
+    words = bn.felts_from_ints(zs[:3] + [over] + zs[4:])[None]
+    r, s = bn.felts_from_ints([a for a, _ in sigs]), bn.felts_from_ints([b for _, b in sigs])
+    qx = bn.felts_from_ints([p[0] for p in pubs])
+    leaves = bn.felts_from_ints(list(range(1, 9)))
+    tree = state.LibrarySparseTree(64, 0)
+    before = tree.update({7: 9})[1]
+    z, verdicts, old, new, committed = bn.order_batch(words, r, s, qx, tree, leaves)
+    assert not committed and old == new == before == tree.root
+    assert verdicts.tolist() == [1, 1, 1, 5, 1, 1, 1, 1] and bn.ints_from_felts(z)[3] == over
+    # the same orders with the signed message itself: committed
+    words_ok = bn.felts_from_ints(zs)[None]
+    z, verdicts, old, new, committed = bn.order_batch(words_ok, r, s, qx, tree, leaves)
+    assert committed and verdicts.tolist() == [1] * 8 and old == before and new == tree.root != before
+    assert tree.get(zs[3] >> 187) == 4
+    tree.close()
