@@ -2,7 +2,7 @@
 """Per-level launch durations of one lockstep forest rebuild (dev aid).
 
   python tools/level_times.py run <trees> [window_bits]    # builds the forest 3 times (run under rocprofv3 --kernel-trace)
-  python tools/level_times.py parse <kernel_trace.csv> <launches_per_build>
+  python tools/level_times.py parse <kernel_trace.csv> <launches_per_build> [all]   # all: every kernel, not only ped_*
 """
 import csv
 import os
@@ -38,8 +38,8 @@ def run(trees, wbits):
     print("forest of %d trees: %.3f ms per build, %.3e hashes/s" % (trees, ms, trees * 65535 / ms * 1e3))
 
 
-def parse(path, tail):
-    rows = [r for r in csv.DictReader(open(path)) if "ped_" in r["Kernel_Name"]]
+def parse(path, tail, every_kernel=False):
+    rows = [r for r in csv.DictReader(open(path)) if every_kernel or "ped_" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[-tail:]
     t0 = int(rows[0]["Start_Timestamp"])
@@ -57,4 +57,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     else:
-        parse(sys.argv[2], int(sys.argv[3]))
+        parse(sys.argv[2], int(sys.argv[3]), len(sys.argv) > 4 and sys.argv[4] == "all")
