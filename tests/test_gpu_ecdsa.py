@@ -363,3 +363,36 @@ def test_device_rfc6979_matches_host_nonces(batch):
     big = [2**64, 2**64 + 1, 2**200 + 3]
     assert batch.sign_many(zs[:3], ds[:3], big) == [R.sign(z, d, s) for z, d, s in zip(zs[:3], ds[:3], big)]
     assert batch.sign_many([], []) == []
+
+
+def test_verify_extreme_limb_patterns_differential(batch):
+    """(z, r, s) drawn from the extreme-limb-pattern felts (tests/workloads.py extreme_felts) against real keys:
+    ladder, key tables and x-only keys give the verdict codes of the C oracle - mostly False / pre-assert codes,
+    but every scalar and field operand of the kernels is then an all-ones / p - small / 2^k pattern."""
+    import random
+    import workloads as wl
+    from oracle import cref
+    rng = random.Random(77)
+    ext = wl.extreme_felts()
+    ext_n = sorted(set(ext + [N - 1, N - 2, N, N + 1, (N - 1) // 2, 2**251 - 1, 2**251]))
+    keys = batch.public_keys_many([rng.randrange(1, N) for _ in range(16)])
+    n = 3000
+    zs = [rng.choice(ext) for _ in range(n)]
+    rs = [rng.choice(ext_n) for _ in range(n)]
+    ss = [rng.choice(ext_n) for _ in range(n)]
+    qs = [keys[rng.randrange(16)] for _ in range(n)]
+    # a third of the items: valid signatures over extreme messages (true verdicts with extreme z)
+    zok = [z for z in ext if z < 2**251]
+    for i in range(0, n, 3):
+        d = rng.randrange(1, N)
+        zs[i] = rng.choice(zok)
+        rs[i], ss[i] = batch.sign_many([zs[i]], [d])[0]
+        qs[i] = batch.public_keys_many([d])[0]
+    exp = cref.verify_codes(zs, rs, ss, qs)
+    assert exp.count(1) >= 900 and len(set(exp)) >= 4  # (z = 0 is signable but verifies False: signature.py:251-257)
+    assert batch.verify_codes(zs, rs, ss, qs, key_tables=False) == exp
+    assert batch.verify_codes(zs, rs, ss, qs, key_tables=True) == exp
+    xonly = [q[0] for q in qs]
+    assert batch.verify_codes(zs, rs, ss, xonly, key_tables=False) == batch.verify_codes(zs, rs, ss, xonly, key_tables=True)
+    got_x = batch.verify_codes(zs, rs, ss, xonly, key_tables=False)
+    assert [g for g, e in zip(got_x, exp) if e == 1] == [1] * exp.count(1)

@@ -129,3 +129,19 @@ def test_forest_roots_equal_individual_roots(batch):
     g = load("g6_merkle.json")
     assert batch.merkle_roots_many([wl.leaves(1 << 10, seed=110)]) == [h(g["roots_seed_100_plus_h"]["10"])]
     assert batch.merkle_roots_many([[5], [7]]) == [5, 7]
+
+
+def test_every_pair_of_extreme_limb_patterns_vs_c_oracle(batch):
+    """All ordered pairs of the extreme-limb-pattern felts (tests/workloads.py extreme_felts: all-ones limbs,
+    p - small, powers of two at the limb boundaries, ...) through the bulk path and, in small slices, through
+    every latency kernel, against the optimised C comparator (itself pinned by the reference goldens)."""
+    from oracle import cref
+    ext = wl.extreme_felts()
+    xs = [a for a in ext for _ in ext]
+    ys = [b for _ in ext for b in ext]
+    exp, st = cref.opt_pedersen_hash_many(xs, ys)
+    assert not any(st)
+    assert batch.pedersen_hash_many(xs, ys) == exp
+    for size in (1, 3, 17, 64, 200, 1000, 3000):  # quad / split / fused kernels by level size
+        for off in range(0, min(len(xs), 6 * size), size):
+            assert batch.pedersen_hash_many(xs[off:off + size], ys[off:off + size]) == exp[off:off + size], (size, off)

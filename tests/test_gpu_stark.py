@@ -170,6 +170,45 @@ def test_trace_air_fri_match_oracle(stark):
         assert stark.tensor_to_felts(layer) == exp_layer
 
 
+def test_prover_kernels_on_extreme_limb_patterns(stark):
+    """NTT / LDE / composition / fold on inputs made of extreme limb patterns (all-ones limbs, p - small, powers of
+    two at the limb boundaries) equal the oracle: the kernels reduce lazily, and the cases that overflow a lazy
+    reduction first are exactly the ones seeded random data never produces."""
+    import torch
+    rng = random.Random(44)
+    import workloads as wl
+    ext = wl.extreme_felts()
+    pick = lambda k: [rng.choice(ext) if rng.random() < 0.85 else rng.randrange(P) for _ in range(k)]
+    for log_n in (3, 6, 11, 12, 13):
+        c = pick(1 << log_n)
+        t = stark.felts_to_tensor(c)
+        assert stark.tensor_to_felts(stark.ntt(t)) == S.ntt(c, S.root_of_unity(log_n)), log_n
+        assert stark.tensor_to_felts(stark.ntt(t, inverse=True)) == S.intt(c, S.root_of_unity(log_n)), log_n
+    for log_n in (4, 9, 11):
+        cols = [pick(1 << log_n) for _ in range(2)]
+        got = stark.lde(torch.stack([stark.felts_to_tensor(c) for c in cols]))
+        for c, g in zip(cols, got):
+            assert stark.tensor_to_felts(g) == S.lde(c), log_n
+    # a composition is a function of the columns on the coset, whatever they hold: every AIR of the library
+    n = 1024
+    for air, spec in S.AIRS.items():
+        cols = [pick(4 * n) for _ in range(spec["n_cols"])]
+        per = stark.periodic_lde(n, air=air)
+        exp_per = S.periodic_lde(n, air=air)
+        dev_cols = torch.stack([stark.felts_to_tensor(c) for c in cols])
+        for trial in range(2):
+            alphas = pick(spec["n_constraints"])
+            comp = stark.air_eval(dev_cols, per, n, alphas, air=air)
+            assert stark.tensor_to_felts(comp) == S.composition_on_coset(cols, exp_per, n, alphas, air=air), (air, trial)
+    layer = pick(4 * n)
+    t, shift = stark.felts_to_tensor(layer), S.GEN
+    while len(layer) > 64:
+        beta = rng.choice(ext)
+        t, layer = stark.fri_fold(t, beta, shift), S.fri_fold(layer, beta, shift)
+        shift = shift * shift % P
+        assert stark.tensor_to_felts(t) == layer, len(layer)
+
+
 def test_commit_rows_matches_oracle(stark):
     import torch
     rng = random.Random(6)

@@ -142,6 +142,11 @@ def test_shared_state_on_gpu_matches_oracle_twin():
     accesses = [(1000 + 77 * i, empty, tuple([p[0], p[1], tuple(p[2])])) for i, p in enumerate(poss)]
     orders = [(2**63 + i, 0, 5 * i + 1) for i in range(5)]
     assert gpu.apply_state_updates(accesses, orders) == ref.apply_state_updates(accesses, orders)
+    # ... and not only its twin: the roots recomputed FROM SCRATCH by the oracle's own sparse-tree walk
+    # (oracle/ref_py.py merkle_multi_update_sparse, no SharedState / squash code involved)
+    leaves = {k: R.position_hash(p[0], p[1], list(p[2])) for k, _, p in accesses}
+    assert gpu.positions_root == R.merkle_multi_update_sparse(64, leaves, R.position_hash(0, 0, []))
+    assert gpu.orders_root == R.merkle_multi_update_sparse(64, {k: v for k, _, v in orders})
 
 
 def test_library_tree_matches_the_python_tree_over_many_batches():

@@ -164,3 +164,18 @@ def crafted_verify_cases(d, q, rng, extra_u2=()):
                     cases.append((z, r, s))
                     break
     return cases
+
+
+def extreme_felts(prime=None):
+    """Field elements whose 29-bit limb strings are what random data never looks like: every limb at its maximum,
+    alternating empty / full limbs, the neighbours of 0, p, 2^251 and of the limb boundaries - the patterns on
+    which a lazy (carry-only) reduction overflows first (the B = 4 bug of the NTT)."""
+    P = prime or (2**251 + 17 * 2**192 + 1)
+    full = (1 << 232) - 1                                  # limbs 0..7 all 2^29 - 1
+    vals = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 1 << 251, (1 << 251) - 1, (1 << 251) + 1,
+            full, full + (((1 << 19) - 1) << 232), full + (1 << 250), 17 << 192, (17 << 192) - 1, (17 << 192) + 1]
+    alt = sum(((1 << 29) - 1) << (29 * k) for k in range(0, 8, 2))
+    vals += [alt, alt << 29, alt + (((1 << 19) - 1) << 232), (alt << 29) + (1 << 250)]
+    for k in (28, 29, 30, 57, 58, 59, 87, 116, 174, 191, 192, 193, 203, 231, 232, 233, 250):
+        vals += [(1 << k) - 1, 1 << k, P - (1 << k), P - (1 << k) - 1]
+    return sorted(set(v % P for v in vals))
