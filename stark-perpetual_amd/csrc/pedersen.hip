@@ -345,8 +345,9 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
       zz = FE_ONE_M;
       st = SP_HASH_UNHASHABLE;
     }
-    const fe zinv = fe_inv_shared_quad<(LOG_L >= 2 ? 0 : 2 - LOG_L)>(zz, (int)(threadIdx.x & 3));
-    xa_plain = fe_pack(fe_from_mont(fe_mul(acc.X, zinv)));
+    // the inverse without its Montgomery factor: X R x ZZ^-1 is already the plain x (no fe_from_mont pass)
+    const fe zinv = fe_inv_shared_quad<(LOG_L >= 2 ? 0 : 2 - LOG_L), true>(zz, (int)(threadIdx.x & 3));
+    xa_plain = fe_pack(fe_canon(fe_mul(acc.X, zinv)));
   }
   if (!active || sub != 0) return;
   if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
@@ -472,7 +473,7 @@ ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, 
     zz = FE_ONE_M;
     st = SP_HASH_UNHASHABLE;
   }
-  const u256 xa_plain = fe_pack(fe_from_mont(fe_mul(s.a, fe_inv_quad(zz, k))));
+  const u256 xa_plain = fe_pack(fe_canon(fe_mul(s.a, fe_inv_quad<true>(zz, k))));  // plain-form inverse: no fe_from_mont
   if (!active || g != 0) return;
   if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
   st_u256(out + 4 * e * ostride, xa_plain);
@@ -533,7 +534,9 @@ ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int
   }
   // ONE divsteps run per DPP quad: the four threads' totals are multiplied together, inverted once with the
   // quad-split inversion and separated again (quad.hpp) - 8 k instead of 13 k instructions per lane
-  fe inv = fe_inv_shared_quad<2>(run, (int)(threadIdx.x & 3));
+  // ... and without the Montgomery factor: inv stays "plain" through inv * z, so zinv = inv * pre is the plain
+  // 1 / ZZ and X R x zinv the plain x - one reduction pass (fe_from_mont) less per hash
+  fe inv = fe_inv_shared_quad<2, true>(run, (int)(threadIdx.x & 3));
 #pragma unroll 1
   for (size_t j = cnt; j-- > 0;) {
     const fe z = zn, pre = pn, xv = xn;
@@ -545,8 +548,8 @@ ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int
     }
     const fe zinv = fe_mul(inv, pre);
     inv = fe_mul(inv, z);
-    const fe xa = fe_mul(xv, zinv);  // Montgomery form of X/ZZ
-    st_u256(out + 4 * cur * ostride, fe_pack(fe_from_mont(xa)));
+    const fe xa = fe_mul(xv, zinv);  // X / ZZ itself (xv carries the only Montgomery factor, the product removes it)
+    st_u256(out + 4 * cur * ostride, fe_pack(fe_canon(xa)));
   }
 }
 

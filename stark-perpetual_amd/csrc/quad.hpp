@@ -230,8 +230,13 @@ __device__ __forceinline__ fe fe_inv_plain_quad(const fe& x, int k) {
 
 // Montgomery-form inverse; a (N-form, |value| < 16p) must be identical on the four lanes of every quad.
 // The plain inverse of the representative a R is a^-1 R^-1; times R^3 (Montgomery product) gives a^-1 R.
+// PLAIN = true: times R^2 instead, i.e. the inverse WITHOUT the Montgomery factor (N-form limbs of a^-1): a
+// caller that only multiplies it into Montgomery-form values and then leaves the Montgomery domain
+// (x = X / ZZ of a hash) gets the plain result from that product directly - fe_mul(X R, ZZ^-1) = X / ZZ - and
+// saves the reduction pass of fe_from_mont per output.
+template <bool PLAIN = false>
 __device__ __forceinline__ fe fe_inv_quad(const fe& a, int k) {
-  return fe_mul(fe_inv_plain_quad(a, k), FE_R3);
+  return fe_mul(fe_inv_plain_quad(a, k), PLAIN ? FE_R2 : FE_R3);
 }
 
 
@@ -245,19 +250,21 @@ __device__ __forceinline__ fe fe_inv_quad(const fe& a, int k) {
 //                  2: four different values
 // a: Montgomery N-form, non-zero (callers replace a zero - an exceptional addition - by one beforehand:
 // a single zero would spoil the three other inverses of its quad).  All four lanes must be active.
-template <int LOG_DISTINCT>
+// PLAIN as in fe_inv_quad: the shared inverse comes back without the Montgomery factor, and so does every lane's
+// own inverse (plain x Montgomery-form cofactor = plain).
+template <int LOG_DISTINCT, bool PLAIN = false>
 __device__ __forceinline__ fe fe_inv_shared_quad(const fe& a, int k) {
   if constexpr (LOG_DISTINCT == 0) {
-    return fe_inv_quad(a, k);
+    return fe_inv_quad<PLAIN>(a, k);
   } else if constexpr (LOG_DISTINCT == 1) {
     const fe other = fe_dpp<quad_perm(2, 3, 0, 1)>(a);
-    const fe pinv = fe_inv_quad(fe_mul(a, other), k);
+    const fe pinv = fe_inv_quad<PLAIN>(fe_mul(a, other), k);
     return fe_mul(pinv, other);
   } else {
     const fe nb = fe_dpp<quad_perm(1, 0, 3, 2)>(a);       // the pair partner's value
     const fe pair = fe_mul(a, nb);                          // a0 a1 | a0 a1 | a2 a3 | a2 a3
     const fe opp = fe_dpp<quad_perm(2, 3, 0, 1)>(pair);    // the other pair's product
-    const fe pinv = fe_inv_quad(fe_mul(pair, opp), k);
+    const fe pinv = fe_inv_quad<PLAIN>(fe_mul(pair, opp), k);
     return fe_mul(pinv, fe_mul(nb, opp));
   }
 }
