@@ -134,6 +134,6 @@ def test_host_lanes_overlap_scalar_calls():
         eight = time.perf_counter() - t0
         print("one thread: %.2f ms per call; eight threads: %.2f ms per call (aggregate)" % (
             one / 40 * 1e3, eight / 320 * 1e3))
-        assert eight < 4 * one, (one, eight)  # serialised calls would take 8 x
+        assert eight < 6 * one, (one, eight)  # serialised calls would take 8 x (measured: 1 - 2 x; the margin is for a busy host)
     finally:
         batch.set_verify_policy(batch.VERIFY_POLICY_AUTO)
