@@ -308,3 +308,48 @@ def test_fe_inv_lehmer(shim):
         assert abs(nb) < a >> 22 and abs(na) < a      # B is the last remainder: below (2^-27 + 2^-23) A on the true integers
     assert shim.t_lehmer_batch(W(P), W(1), rows) == 0          # partial quotient 2^251: not representable
     assert shim.t_lehmer_batch(W(12345), W(0), rows) == 1 and list(rows) == [1.0, 0.0, 0.0, 1.0]
+
+
+def test_extreme_limb_patterns_keep_every_bound(shim):
+    """Every pair of the extreme-limb-pattern felts (tests/workloads.py extreme_felts: all-ones limbs, p - small,
+    2^k at the limb boundaries) through the bound-checked build of the multiplier, the lazy expression and the XYZZ
+    chain: a limb or column that leaves its budget aborts the process, a wrong value fails the comparison.  The
+    chord rule does not use the curve equation, so "points" with extreme coordinates exercise the addition formulas
+    as they stand."""
+    import sys
+    sys.path.insert(0, HERE)
+    import workloads as wl
+    ext = wl.extreme_felts()
+    out = (ctypes.c_uint32 * 8)()
+    for a in ext:
+        shim.t_fe_sqr(W(a), out)
+        assert I(out) == a * a % P
+        for b in ext:
+            shim.t_fe_mul(W(a), W(b), out)
+            assert I(out) == a * b % P, (hex(a), hex(b))
+    rng = random.Random(19)
+    for _ in range(4000):
+        a, b, c, d, e, f = (rng.choice(ext) for _ in range(6))
+        shim.t_fe_expr(W(a), W(b), W(c), W(d), W(e), W(f), out)
+        assert I(out) == ((a - b) * (c + d) - e * f) % P
+    x, y = (ctypes.c_uint32 * 8)(), (ctypes.c_uint32 * 8)()
+
+    def chord(p, q):
+        lam = (q[1] - p[1]) * pow(q[0] - p[0], -1, P) % P
+        x3 = (lam * lam - p[0] - q[0]) % P
+        return x3, (lam * (p[0] - x3) - p[1]) % P
+    done = 0
+    while done < 300:
+        n = rng.choice((2, 3, 5, 9))
+        pts = [(rng.choice(ext), rng.choice(ext)) for _ in range(n)]
+        exp, ok = pts[0], True
+        for q in pts[1:]:
+            if (q[0] - exp[0]) % P == 0:
+                ok = False
+                break
+            exp = chord(exp, q)
+        if not ok:
+            continue
+        shim.t_xyzz_chain(WN([p[0] for p in pts]), WN([p[1] for p in pts]), n, x, y)
+        assert (I(x), I(y)) == exp
+        done += 1
