@@ -340,13 +340,20 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
     // shares ONE quad-split divsteps run: its lanes hold one sum (L >= 4), two (L = 2) or four different
     // ones (L = 1), multiplied together first and separated afterwards (quad.hpp fe_inv_shared_quad).
     fe zz = acc.ZZ;
-    const bool unhashable = fe_is_zero(zz);  // exceptional addition happened (signature.py:313 territory)
-    if (unhashable) {
-      zz = FE_ONE_M;
-      st = SP_HASH_UNHASHABLE;
+    // ZZ = 0: an exceptional addition happened (signature.py:313 territory).  Lanes that SHARE an inversion with
+    // other sums (L < 4) must find that out first - a zero would spoil the product of the quad; where the quad
+    // holds one sum the test costs nothing: the inversion answers 0 for a multiple of p, and only for one.
+    if constexpr (LOG_L < 2) {
+      if (fe_is_zero(zz)) {
+        zz = FE_ONE_M;
+        st = SP_HASH_UNHASHABLE;
+      }
     }
     // the inverse without its Montgomery factor: X R x ZZ^-1 is already the plain x (no fe_from_mont pass)
     const fe zinv = fe_inv_shared_quad<(LOG_L >= 2 ? 0 : 2 - LOG_L), true>(zz, (int)(threadIdx.x & 3));
+    if constexpr (LOG_L >= 2) {
+      if (limbs_is_zero(zinv)) st = SP_HASH_UNHASHABLE;
+    }
     xa_plain = fe_pack(fe_canon(fe_mul(acc.X, zinv)));
   }
   if (!active || sub != 0) return;
@@ -468,12 +475,11 @@ ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, 
   if constexpr (LOG_Q == 3) { SP_BUTTERFLY(4, false) SP_BUTTERFLY(8, false) SP_BUTTERFLY(16, true) }
 #undef SP_BUTTERFLY
   uint8_t st = SP_HASH_OK;
-  fe zz = s.b;
-  if (fe_is_zero(zz)) {  // exceptional addition happened (signature.py:313 territory)
-    zz = FE_ONE_M;
-    st = SP_HASH_UNHASHABLE;
-  }
-  const u256 xa_plain = fe_pack(fe_canon(fe_mul(s.a, fe_inv_quad<true>(zz, k))));  // plain-form inverse: no fe_from_mont
+  // ZZ = 0 - an exceptional addition (signature.py:313 territory) - shows as a zero inverse: the inversion answers
+  // 0 for a multiple of p and only for one, so no test of ZZ sits on the chain in front of it
+  const fe zinv = fe_inv_quad<true>(s.b, k);  // plain-form inverse: no fe_from_mont
+  if (limbs_is_zero(zinv)) st = SP_HASH_UNHASHABLE;
+  const u256 xa_plain = fe_pack(fe_canon(fe_mul(s.a, zinv)));
   if (!active || g != 0) return;
   if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
   st_u256(out + 4 * e * ostride, xa_plain);
