@@ -312,8 +312,11 @@ VALU_PEAK_NOTE = ("peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 integer VAL
                   "measured on this chip (profiles/r01_valu_rate_ubench.txt: 4.2-5.3 cycles for v_mad_u64_u32, "
                   "v_add_co, v_mul_lo at 4 waves per SIMD; nothing integer below 4).  MI355X_MICROARCH.md quotes "
                   "2 cycles for a wave64 v_fma_f32 on the SIMD-32; priced against that figure every VALU "
-                  "fraction here halves (frac_at_2_cycle_peak).  The chip sustains about 1.9 of the nominal "
-                  "2.4 GHz under this kernel (GRBM_GUI_ACTIVE)")
+                  "fraction here halves (frac_at_2_cycle_peak; v_fma_f32 itself measures 3.1 cycles at 4 waves per SIMD "
+                  "there, every integer instruction 4.3 or more).  Under this kernel the package runs at its power "
+                  "limit (1.34-1.35 kW) and holds 2.08-2.10 GHz of the nominal 2.4 (rocm-smi, "
+                  "profiles/r03_power_clock_bulk.txt): at the clock it holds, back-to-back bulk batches reach 0.91 "
+                  "of the issue rate")
 
 
 def valu_issue(hashes_per_sec, window_bits, workload, include_finish=True):
