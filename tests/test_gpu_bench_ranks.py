@@ -41,3 +41,28 @@ def test_two_ranks_share_one_gpu(workload, extra):
     else:  # ONE 2^15- / 2^20-row proof over the two ranks: its roots are the single-GPU roots of the same trace
         assert d["config"]["rows_total"] == 2 << int(extra[5]) and d["sharded_roots_match_single_gpu"] is True
         assert d["config"]["exchange"]["per_fold"].startswith("none")
+
+
+@pytest.mark.parametrize("workload,extra", [("merkle", ["--steps", "3", "--warmup", "1"]),
+                                            ("airfri", ["--steps", "1", "--warmup", "0", "--log-rows", "15"])])
+def test_eight_ranks_share_one_gpu(workload, extra):
+    """BASELINE configs[4] names EIGHT devices: the same launch with world = 8 (eight processes on device 0, gloo
+    for the exchanges) - per-rank subtrees + all_gather + three top levels for the Merkle workload, and ONE
+    2^18-row trace as 16 coset units over eight ranks (two per rank, block-cyclic row shards, shard-local folds)
+    whose roots must equal the single-GPU roots of the same trace."""
+    env = dict(os.environ, STARKPERP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", STARKPERP_WINDOW_BITS="16")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "8", "--workload", workload, "--window-bits", "0", "--no-extras", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    if workload == "merkle":
+        assert d["config"]["hashes_per_step"] == 8 * 65535 + 7
+        assert d["combine_matches_recomputed"] is True
+    else:
+        assert d["config"]["rows_total"] == 8 << int(extra[5]) and d["sharded_roots_match_single_gpu"] is True
+        assert d["config"]["exchange"]["per_fold"].startswith("none")
