@@ -44,12 +44,15 @@ def test_two_ranks_share_one_gpu(workload, extra):
 
 
 @pytest.mark.parametrize("workload,extra", [("merkle", ["--steps", "3", "--warmup", "1"]),
-                                            ("airfri", ["--steps", "1", "--warmup", "0", "--log-rows", "15"])])
+                                            ("airfri", ["--steps", "1", "--warmup", "0", "--log-rows", "15"]),
+                                            # BASELINE configs[4] at its stated size: 2^24 rows in all, 8 ranks
+                                            ("airfri", ["--steps", "1", "--warmup", "0", "--log-rows", "21"])])
 def test_eight_ranks_share_one_gpu(workload, extra):
     """BASELINE configs[4] names EIGHT devices: the same launch with world = 8 (eight processes on device 0, gloo
     for the exchanges) - per-rank subtrees + all_gather + three top levels for the Merkle workload, and ONE
-    2^18-row trace as 16 coset units over eight ranks (two per rank, block-cyclic row shards, shard-local folds)
-    whose roots must equal the single-GPU roots of the same trace."""
+    2^18-row (and one 2^24-row: configs[4] at its stated size, 8 GiB through the all-to-all) trace as 16 coset units
+    over eight ranks (two per rank, block-cyclic row shards, shard-local folds) whose roots must equal the single-GPU
+    roots of the same trace."""
     env = dict(os.environ, STARKPERP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", STARKPERP_WINDOW_BITS="16")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
