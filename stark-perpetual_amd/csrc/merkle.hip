@@ -31,6 +31,9 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
                      size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
                      const Scratch& s, const int2* src);
 int get_scratch_public(size_t n, Scratch& s, hipStream_t st);
+int enqueue_partial_points(const uint64_t* felts, int count, aff_packed* out, hipStream_t st, bool* usable);
+int enqueue_pedersen_sparse(const uint64_t* x, const uint64_t* y, uint64_t* out, unsigned* flag, size_t n,
+                            hipStream_t st, const Scratch& s, const int2* src, const aff_packed* cpts);
 
 static DeviceBuffer g_sparse_buf;
 // empty-subtree roots are a pure function of the empty leaf: cached on the host per leaf value
@@ -385,6 +388,11 @@ struct SparseTree {
   // updates of OTHER trees proceed meanwhile (round 2: null stream, library lock across everything).
   hipStream_t stream = nullptr;
   DeviceBuffer buf;
+  // The constant points of the levels (pedersen.hip SPARSE quad kernel): for level l the sum of the table entries
+  // that the level's empty-subtree root selects as a left / right operand, [2 l] and [2 l + 1]; computed on the
+  // tree's stream by its first update, kept for its lifetime (the window plan cannot change under a live tree).
+  DeviceBuffer cpts;
+  int cpts_state = 0;  // 0: not computed, 1: ready, -1: the plan has no constant window on one side
   std::mutex mu;
   bool destroyed = false;  // set by sp_tree_destroy under `mu`: a thread that was waiting for the mutex with the
                            // old handle must not revive the freed tree
@@ -401,6 +409,8 @@ static void tree_free(SparseTree& t) {
   if (t.table) (void)hipFree(t.table);
   if (t.d_entries) (void)hipFree(t.d_entries);
   t.buf.release();
+  t.cpts.release();
+  t.cpts_state = 0;
   t.stream = nullptr;
   t.table = nullptr;
   t.d_entries = nullptr;
@@ -564,9 +574,17 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
     hipLaunchKernelGGL(tree_lookup_kernel, dim3((unsigned)((srcs + 255) / 256)), dim3(256), 0, st, lv, d_idx, t.table,
                        t.slots - 1, d_felts, d_src, (unsigned)srcs);
     SP_HIP(hipGetLastError());
+    if (t.cpts_state == 0) {  // once per tree: the constant points of its 64 levels (d_emp is on the stream already)
+      SP_HIP(t.cpts.reserve(2 * (size_t)height * sizeof(aff_packed)));
+      bool usable = false;
+      rc = enqueue_partial_points(d_emp, (int)height, (aff_packed*)t.cpts.ptr, st, &usable);
+      if (rc != SP_OK) return rc;
+      t.cpts_state = usable ? 1 : -1;
+    }
+    const aff_packed* cpts = t.cpts_state == 1 ? (const aff_packed*)t.cpts.ptr : nullptr;
     for (unsigned l = 0; l < height; ++l) {
-      rc = enqueue_pedersen(d_felts, 1, d_emp + 4 * l, 1, d_felts + 4 * (size_t)lv.val_base[l + 1], 1, nullptr, s.flag,
-                            cnt[l + 1], st, s, d_src + lv.src_off[l]);
+      rc = enqueue_pedersen_sparse(d_felts, d_emp + 4 * l, d_felts + 4 * (size_t)lv.val_base[l + 1], s.flag, cnt[l + 1],
+                                   st, s, d_src + lv.src_off[l], cpts ? cpts + 2 * l : nullptr);
       if (rc != SP_OK) return rc;
     }
   }

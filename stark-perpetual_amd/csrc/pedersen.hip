@@ -414,12 +414,22 @@ ped_accumulate_mixed_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
 // windows.  Every lane then inverts ZZ (all copies are identical; a wave with few active lanes runs the
 // same code 4x slower, tools/ubench/inv_lanes.hip) and lane 0 writes the affine x.  One launch per
 // level, no scratch.  Requires nwin >= 2 * QUADS (every quad owns at least one pair).
-template <int LOG_Q>
+//
+// SPARSE (levels of a sparse multi-update, merkle.hip): a node with ONE touched child has the level's
+// empty-subtree root as its other operand - a constant.  The windows that lie wholly inside that operand's half of
+// x || y (the first `cx` windows for a constant left operand, the last `cy` for a constant right one) always select
+// the same entries, whose sum is tabulated once per level and side (`cpts`: [0] left, [1] right;
+// ped_partial_kernel).  Such a node sums 1 + nwin - cx (or - cy) points instead of nwin - 11 instead of 19 with
+// 26-bit windows: a tree sum of depth 4 instead of 5, 14 instead of 18 rounds.  The window list is per lane group
+// ("virtual" window v: 0 = the constant point, v >= 1 = real window cx + v - 1, resp. v - 1), the loop bound is the
+// largest of the wave.  Requires 1 + nwin - max(cx, cy) >= 2 * QUADS.
+template <int LOG_Q, bool SPARSE = false>
 __global__ void __launch_bounds__(256)
 ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride, size_t ystride,
-                size_t n, const aff_packed* __restrict__ ped, int w0, int log2e, int nwin,
+                size_t n, const aff_packed* __restrict__ ped, int w0, int log2e, int nwin_plan,
                 uint8_t* __restrict__ status, unsigned* __restrict__ flag, const int2* __restrict__ src,
-                uint64_t* __restrict__ out, size_t ostride, int dup) {
+                uint64_t* __restrict__ out, size_t ostride, int dup, const aff_packed* __restrict__ cpts, int cx,
+                int cy) {
   constexpr int QUADS = 1 << LOG_Q, LANES = 4 * QUADS;
   const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   // dup: 2^dup lane groups compute the same hash, so that a wave holds ONE value while the level is small
@@ -430,13 +440,30 @@ ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, 
   const size_t e = active ? e_raw : n - 1;  // clamp: whole groups stay convergent for the lane exchanges
   const uint64_t *fx, *fy;
   operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
-  auto entry = [&](int w) {
+  int mode = 0, nwin = nwin_plan, first_real = 0;  // mode 1 / 2: the left / right operand is the level's constant
+  if constexpr (SPARSE) {
+    const int2 sc = src[e];
+    mode = sc.x < 0 ? 1 : (sc.y < 0 ? 2 : 0);
+    nwin = mode == 0 ? nwin_plan : 1 + nwin_plan - (mode == 1 ? cx : cy);
+    first_real = mode == 1 ? cx - 1 : (mode == 2 ? -1 : 0);  // real window of virtual window v >= 1: first_real + v
+  }
+  auto entry = [&](int v) {
+    if constexpr (SPARSE) {
+      if (mode != 0 && v == 0) return unpack_raw(ld_raw(cpts + (mode - 1)));
+    }
+    const int w = first_real + v;
     const window_ref r =
         window_entry(ped, w, window_from_memory(fx, fy, window_start(w, w0, log2e), window_width(w, w0, log2e)), w0, log2e);
     return signed_aff(ld_raw(r.entry), r.negative);
   };
   const int cnt = nwin / QUADS + (q < nwin % QUADS ? 1 : 0);  // windows of this quad: q, q + QUADS, q + 2 QUADS, ...
-  const int max_cnt = (nwin + QUADS - 1) / QUADS;
+  int max_cnt = (nwin + QUADS - 1) / QUADS;
+  if constexpr (SPARSE) {  // the loop below must run the same number of times on every lane of the wave
+    max_cnt = 0;
+    if (__any(mode == 0)) max_cnt = (nwin_plan + QUADS - 1) / QUADS;
+    if (__any(mode == 1)) max_cnt = max(max_cnt, (1 + nwin_plan - cx + QUADS - 1) / QUADS);
+    if (__any(mode == 2)) max_cnt = max(max_cnt, (1 + nwin_plan - cy + QUADS - 1) / QUADS);
+  }
   // lanes 0,1: pair A = windows (q, q + QUADS); lanes 2,3: pair B = (q + 2 QUADS, q + 3 QUADS) where they exist
   const bool upper = (k & 2) != 0;
   const bool odd = (k & 1) != 0;
@@ -589,6 +616,43 @@ ped_point_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y,
   status[e] = SP_HASH_OK;
 }
 
+// The constant points of the SPARSE quad kernel: for felt e of `felts` (the empty-subtree root of level e) the sum
+// of the table entries its first `cx` windows select when it is the LEFT operand (out[2 e]) and of the entries its
+// last `cy` windows select when it is the RIGHT operand (out[2 e + 1]) - affine, Montgomery form, packed like a
+// table entry.  One thread per point, its own inversion: 2 x 64 points per empty leaf, computed once per tree.
+__global__ void __launch_bounds__(64)
+ped_partial_kernel(const uint64_t* __restrict__ felts, int count, const aff_packed* __restrict__ ped, int w0, int log2e,
+                   int nwin, int cx, int cy, aff_packed* __restrict__ out) {
+  int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (t >= 2 * count) t = 2 * count - 1;  // redundant copy of the last item (few active lanes are slow)
+  const int side = t & 1;
+  const uint64_t* f = felts + 4 * (size_t)(t >> 1);
+  const int g0 = side == 0 ? 0 : nwin - cy, g1 = side == 0 ? cx : nwin;
+  auto entry = [&](int w) {
+    const window_ref r =
+        window_entry(ped, w, window_from_memory(f, f, window_start(w, w0, log2e), window_width(w, w0, log2e)), w0, log2e);
+    return signed_aff(ld_raw(r.entry), r.negative);
+  };
+  aff_packed res;
+  if (g1 - g0 == 1) {
+    const aff a = entry(g0);
+    res.x = fe_pack(fe_canon(a.x));
+    res.y = fe_pack(fe_canon(a.y));
+  } else {
+    xyzz acc = xyzz_mmadd(entry(g0), entry(g0 + 1));
+    for (int g = g0 + 2; g < g1; ++g) acc = xyzz_madd(acc, entry(g));
+    const fe izzz = fe_inv(acc.ZZZ);                       // Montgomery-form inverse
+    const fe izz = fe_sqr(fe_mul(acc.ZZ, izzz));           // ZZ^2 / ZZZ^2 = 1 / ZZ
+    res.x = fe_pack(fe_canon(fe_mul(acc.X, izz)));
+    res.y = fe_pack(fe_canon(fe_mul(acc.Y, izzz)));
+  }
+  uint4* q = reinterpret_cast<uint4*>(out + t);
+  q[0] = make_uint4(res.x.w[0], res.x.w[1], res.x.w[2], res.x.w[3]);
+  q[1] = make_uint4(res.x.w[4], res.x.w[5], res.x.w[6], res.x.w[7]);
+  q[2] = make_uint4(res.y.w[0], res.y.w[1], res.y.w[2], res.y.w[3]);
+  q[3] = make_uint4(res.y.w[4], res.y.w[5], res.y.w[6], res.y.w[7]);
+}
+
 // ---- optional per-launch timing of the dominant kernel (bench.py roofline leg) -----------------
 struct KernelProfile {
   bool enabled = false;
@@ -602,6 +666,7 @@ static bool g_fuse_enabled = getenv("STARKPERP_NO_FUSE") == nullptr;
 static bool g_quad_enabled = getenv("STARKPERP_NO_QUAD") == nullptr;
 static bool g_quad2_enabled = getenv("STARKPERP_NO_QUAD2") == nullptr;
 static bool g_level_split = getenv("STARKPERP_NO_LEVEL_SPLIT") == nullptr;
+static bool g_sparse_enabled = getenv("STARKPERP_NO_SPARSE_LEVELS") == nullptr;  // constant points of sparse levels
 static size_t g_quad_max = getenv("STARKPERP_QUAD_MAX") ? (size_t)atoll(getenv("STARKPERP_QUAD_MAX")) : 2048;
 // ---- host-side drivers -------------------------------------------------------------------------
 struct Scratch {
@@ -650,10 +715,46 @@ void release_pedersen_state() {
   g_prof.enabled = false;
 }
 
+// Windows of the plan that lie wholly inside the x half (the first cx) / the y half (the last cy) of x || y.
+void constant_window_counts(const PedPlan& p, int& cx, int& cy) {
+  cx = cy = 0;
+  for (int g = 0; g < p.nwin; ++g) {
+    if (p.start[g] + p.bits[g] <= 252) ++cx;
+    if (p.start[g] >= 252) ++cy;
+  }
+}
+// The constant points of a sparse tree's levels (ped_partial_kernel): out[2 l], out[2 l + 1] for felts[l].
+// Returns SP_OK with *usable = false when the plan leaves no constant window on one of the sides.
+int enqueue_partial_points(const uint64_t* felts, int count, aff_packed* out, hipStream_t st, bool* usable) {
+  Context& c = ctx();
+  int cx, cy;
+  constant_window_counts(c.plan, cx, cy);
+  *usable = cx >= 1 && cy >= 1 && count > 0;
+  if (!*usable) return SP_OK;
+  hipLaunchKernelGGL(ped_partial_kernel, dim3((unsigned)((2 * count + 63) / 64)), dim3(64), 0, st, felts, count, c.ped,
+                     (int)c.plan.bits[0], c.plan.log2e, c.plan.nwin, cx, cy, out);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+static int enqueue_pedersen_impl(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
+                                 size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
+                                 const Scratch& s, const int2* src, const aff_packed* cpts);
 // Enqueue n hashes; x/y/out strides in felts.  `flag` (device, may be null) ORs item status.
 int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
                      size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
                      const Scratch& s, const int2* src) {
+  return enqueue_pedersen_impl(x, xs, y, ys, out, os, status, flag, n, st, s, src, nullptr);
+}
+// A level of a sparse multi-update (gathered mode, src != null): `cpts` = the level's two constant points
+// (enqueue_partial_points) or null.  Levels that fit the quad kernels take the SPARSE variant.
+int enqueue_pedersen_sparse(const uint64_t* x, const uint64_t* y, uint64_t* out, unsigned* flag, size_t n,
+                            hipStream_t st, const Scratch& s, const int2* src, const aff_packed* cpts) {
+  return enqueue_pedersen_impl(x, 1, y, 1, out, 1, nullptr, flag, n, st, s, src, cpts);
+}
+static int enqueue_pedersen_impl(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
+                                 size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
+                                 const Scratch& s, const int2* src, const aff_packed* cpts) {
   if (n == 0) return SP_OK;
   Context& c = ctx();
   // sp_profile_begin/_end time the DOMINANT kernel only (ped_accumulate_kernel: the pure one-lane-per-hash
@@ -682,16 +783,29 @@ int enqueue_pedersen(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys,
     else if (n <= 2 * g_quad_max && nwin >= 8) log_q = 2;
     else if (n <= 4 * g_quad_max && nwin >= 4 && g_quad2_enabled) log_q = 1;
   }
+  // sparse level: nodes with one constant operand sum 1 + nwin - cx (cy) points
+  int cx = 0, cy = 0;
+  bool sparse = false;
+  // (levels the eight-quad kernel takes - up to 2048 nodes, the top of an update where most nodes have two touched
+  // children - stay with it: 21.5 us against 22.5 for the four-quad sparse form, gpurun timeline of quick_tree_update)
+  if (g_sparse_enabled && cpts != nullptr && src != nullptr && (log_q == 1 || log_q == 2)) {
+    constant_window_counts(c.plan, cx, cy);
+    const int shortest = 1 + nwin - (cx > cy ? cx : cy);
+    sparse = cx >= 1 && cy >= 1 && shortest >= (2 << log_q);
+  }
   if (log_q != 0) {
     int dup = 0;
     while ((4 << (log_q + dup)) < 64 && ((n * 4) << (log_q + dup + 1)) <= 65536) ++dup;  // up to one hash per wave
     const unsigned blocks = (unsigned)((((n * 4) << (log_q + dup)) + 255) / 256);
-#define SP_LAUNCH_QUAD(LOGQ)                                                                                   \
-  hipLaunchKernelGGL((ped_quad_kernel<LOGQ>), dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n, c.ped, w0, log2e, \
-                     nwin, status, flag, src, out, os, dup)
-    if (log_q == 3) SP_LAUNCH_QUAD(3);
-    else if (log_q == 2) SP_LAUNCH_QUAD(2);
-    else SP_LAUNCH_QUAD(1);
+#define SP_LAUNCH_QUAD(LOGQ, SPARSEV)                                                                           \
+  hipLaunchKernelGGL((ped_quad_kernel<LOGQ, SPARSEV>), dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n, c.ped, w0, \
+                     log2e, nwin, status, flag, src, out, os, dup, cpts, cx, cy)
+    if (sparse) {
+      if (log_q == 2) SP_LAUNCH_QUAD(2, true);
+      else SP_LAUNCH_QUAD(1, true);
+    } else if (log_q == 3) SP_LAUNCH_QUAD(3, false);
+    else if (log_q == 2) SP_LAUNCH_QUAD(2, false);
+    else SP_LAUNCH_QUAD(1, false);
 #undef SP_LAUNCH_QUAD
     fused = true;
   } else if (log_l == 0 && !(g_split_enabled && g_fuse_enabled && n <= 65536)) {
