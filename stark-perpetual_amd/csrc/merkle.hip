@@ -119,13 +119,16 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
   const size_t nn = n ? n : 1;
   const size_t fb = nn * 32;
   const size_t emp_bytes = ((size_t)height + 1) * 32;
-  const size_t src_bytes = (src.size() + 1) * sizeof(int2);
-  SP_HIP(g_sparse_buf.reserve(emp_bytes + 2 * fb + src_bytes + 1024));
+  const size_t src_bytes = ((src.size() + 1) * sizeof(int2) + 63) & ~(size_t)63;
+  const size_t cpt_bytes = 2 * ((size_t)height + 1) * sizeof(aff_packed);
+  SP_HIP(g_sparse_buf.reserve(emp_bytes + 2 * fb + src_bytes + cpt_bytes + 1024));
   char* b = (char*)g_sparse_buf.ptr;
   uint64_t* d_emp = (uint64_t*)b;
   uint64_t* d_a = (uint64_t*)(b + emp_bytes);
   uint64_t* d_b = (uint64_t*)(b + emp_bytes + fb);
   int2* d_src = (int2*)(b + emp_bytes + 2 * fb);
+  // the constant points of the levels (SPARSE quad kernel, pedersen.hip), 64-byte aligned behind the child lists
+  aff_packed* d_cpts = (aff_packed*)(((uintptr_t)(b + emp_bytes + 2 * fb + src_bytes) + 63) & ~(uintptr_t)63);
   Scratch s;
   int rc = get_scratch_public(nn, s, 0);
   if (rc != SP_OK) return rc;
@@ -143,11 +146,17 @@ extern "C" int sp_merkle_sparse_root(const uint64_t* keys, const uint64_t* leave
     SP_HIP(hipMemcpy(d_a, leaves, n * 32, hipMemcpyHostToDevice));
     if (!src.empty()) SP_HIP(hipMemcpy(d_src, src.data(), src.size() * sizeof(int2), hipMemcpyHostToDevice));
     uint64_t *cur = d_a, *nxt = d_b;
+    bool have_cpts = false;
+    if (height > 0) {
+      rc = enqueue_partial_points(d_emp, (int)height, d_cpts, 0, &have_cpts);
+      if (rc != SP_OK) return rc;
+    }
     for (size_t l = 0; l < level_cnt.size(); ++l) {
       const size_t m = level_cnt[l];
       // gathered mode: operand pointers come from src (children in `cur`, or this level's
       // empty-subtree root) inside the accumulate kernel - no separate gather pass
-      rc = enqueue_pedersen(cur, 1, d_emp + 4 * l, 1, nxt, 1, nullptr, s.flag, m, 0, s, d_src + level_off[l]);
+      rc = enqueue_pedersen_sparse(cur, d_emp + 4 * l, nxt, s.flag, m, 0, s, d_src + level_off[l],
+                                   have_cpts ? d_cpts + 2 * l : nullptr);
       if (rc != SP_OK) return rc;
       std::swap(cur, nxt);
     }
