@@ -1006,22 +1006,26 @@ int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, ui
   return SP_OK;
 }
 
-// Host-pointer variant of sp_pedersen_chains_dev: one call for `width` chains of `depth` words.
+// Host-pointer variant of sp_pedersen_chains_dev: one call for `width` chains of `depth` words.  Runs on a host
+// lane (context.hpp): its own stream and staging buffer, the library lock only inside the _dev call that enqueues,
+// no device-wide synchronisation - work in flight on other streams (a tree's insertion kernel, other threads'
+// batches) is not waited for.
 int sp_pedersen_chains(const uint64_t* elems, size_t width, size_t depth, uint64_t* out, uint8_t* status) {
+  LaneScope ls(0);  // the primary context: where sp_order_batch keeps the key tables it verifies against next
   SP_REQUIRE_READY();
   if (depth < 1) { set_error("chain depth must be >= 1"); return SP_ERR_BAD_ARGUMENT; }
   if (width == 0) return SP_OK;
-  Context& c = ctx();
-  ctx_lock lk(c.mu);  // held across the nested _dev call: the staging buffer is shared
-  SP_HIP(c.io.reserve((width * depth + width) * 32 + 64));
-  uint64_t* d_el = (uint64_t*)c.io.ptr;
+  if (ls.open() != SP_OK) return SP_ERR_HIP;
+  HostLane& L = *ls.lane;
+  SP_HIP(L.io.reserve((width * depth + width) * 32 + 64));
+  uint64_t* d_el = (uint64_t*)L.io.ptr;
   uint64_t* d_out = d_el + 4 * width * depth;
-  SP_HIP(hipMemcpy(d_el, elems, width * depth * 32, hipMemcpyHostToDevice));
-  uint8_t st8 = 0;
-  int rc = sp_pedersen_chains_dev(d_el, width, depth, d_out, &st8, 0);
+  SP_HIP(hipMemcpyAsync(d_el, elems, width * depth * 32, hipMemcpyHostToDevice, L.stream));
+  uint8_t st8 = 0;  // written by the stream (the chains' status flag), read after the synchronisation below
+  int rc = sp_pedersen_chains_dev(d_el, width, depth, d_out, &st8, L.stream);
   if (rc != SP_OK) return rc;
-  SP_HIP(hipDeviceSynchronize());
-  SP_HIP(hipMemcpy(out, d_out, width * 32, hipMemcpyDeviceToHost));
+  SP_HIP(hipMemcpyAsync(out, d_out, width * 32, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipStreamSynchronize(L.stream));
   if (status) *status = st8;
   return SP_OK;
 }
