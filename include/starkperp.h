@@ -22,12 +22,15 @@
  *   - Threading: every entry point may be called from any host thread.  One recursive lock
  *     serialises the host-side bookkeeping; scratch, window tables of the verifier and NTT work
  *     columns are per stream, so _dev calls on different streams overlap on the device.  The
- *     host-pointer batches that carry no shared state - sp_pedersen_batch, sp_ecdsa_verify_batch
- *     (per-signature ladder), sp_ecdsa_sign_batch, sp_ecdsa_sign_rfc6979_batch, sp_public_key_batch -
+ *     host-pointer batches that carry no shared state - sp_pedersen_batch, sp_pedersen_chains,
+ *     sp_ecdsa_verify_batch (per-signature ladder), sp_ecdsa_sign_batch, sp_ecdsa_sign_rfc6979_batch,
+ *     sp_public_key_batch -
  *     run on one of 16 host lanes (own stream, own staging buffer) and hold the lock only while a
  *     kernel is enqueued: calls from different threads overlap on the device - on the devices, after
- *     sp_init_devices - (a seventeenth concurrent caller waits for a lane).  The other host-pointer calls (chains, trees, key registration and
- *     keyed verification) hold the lock for their whole staged round trip.
+ *     sp_init_devices - (a seventeenth concurrent caller waits for a lane).  Keyed verification runs on a lane too and holds the
+ *     lock to register keys and to enqueue; a persistent tree has its own stream and mutex (below).  The remaining
+ *     host-pointer calls (the scalar chain calls, sp_merkle_root / _sparse_root, key registration) hold the lock for
+ *     their whole staged round trip.
  *     Each entry point binds the device given to sp_init for its duration and restores the calling
  *     thread's current HIP device on return.
  */
