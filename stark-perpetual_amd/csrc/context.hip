@@ -397,7 +397,23 @@ static int init_locked(Context& c, int device, int window_bits) {
   }
 
   const size_t gen_entries = (size_t)c.nwin << c.wbits;
-  SP_HIP(hipMalloc(&c.ped, p.entries * sizeof(aff_packed)));
+  // Experiment switch: STARKPERP_CONTIGUOUS_TABLES=1 asks for physically contiguous tables
+  // (hipDeviceMallocContiguous) - larger page-table fragments for the random 64-byte gathers - and falls back to
+  // the ordinary allocation when the driver cannot give that much contiguous memory.
+  c.ped = nullptr;
+  if (const char* contig = getenv("STARKPERP_CONTIGUOUS_TABLES")) {
+    if (contig[0] == '1') {
+      void* ptr = nullptr;
+      if (hipExtMallocWithFlags(&ptr, p.entries * sizeof(aff_packed), hipDeviceMallocContiguous) == hipSuccess) {
+        c.ped = (aff_packed*)ptr;
+      } else {
+        (void)hipGetLastError();
+        fprintf(stderr, "libstarkperp: no contiguous allocation of %zu bytes, using hipMalloc\n",
+                (size_t)(p.entries * sizeof(aff_packed)));
+      }
+    }
+  }
+  if (!c.ped) SP_HIP(hipMalloc(&c.ped, p.entries * sizeof(aff_packed)));
   SP_HIP(hipMalloc(&c.gen, gen_entries * sizeof(aff_packed)));
   SP_HIP(hipMemset(c.gen, 0, gen_entries * sizeof(aff_packed)));
   SP_HIP(hipMalloc(&c.d_plan, sizeof(PedPlan)));
