@@ -666,6 +666,7 @@ static bool g_fuse_enabled = getenv("STARKPERP_NO_FUSE") == nullptr;
 static bool g_quad_enabled = getenv("STARKPERP_NO_QUAD") == nullptr;
 static bool g_quad2_enabled = getenv("STARKPERP_NO_QUAD2") == nullptr;
 static bool g_level_split = getenv("STARKPERP_NO_LEVEL_SPLIT") == nullptr;
+static bool g_quad_no_dup = getenv("STARKPERP_QUAD_NO_DUP") != nullptr;
 static bool g_sparse_enabled = getenv("STARKPERP_NO_SPARSE_LEVELS") == nullptr;  // constant points of sparse levels
 static size_t g_quad_max = getenv("STARKPERP_QUAD_MAX") ? (size_t)atoll(getenv("STARKPERP_QUAD_MAX")) : 2048;
 // ---- host-side drivers -------------------------------------------------------------------------
@@ -796,6 +797,7 @@ static int enqueue_pedersen_impl(const uint64_t* x, size_t xs, const uint64_t* y
   if (log_q != 0) {
     int dup = 0;
     while ((4 << (log_q + dup)) < 64 && ((n * 4) << (log_q + dup + 1)) <= 65536) ++dup;  // up to one hash per wave
+    if (g_quad_no_dup) dup = 0;  // A/B switch
     const unsigned blocks = (unsigned)((((n * 4) << (log_q + dup)) + 255) / 256);
 #define SP_LAUNCH_QUAD(LOGQ, SPARSEV)                                                                           \
   hipLaunchKernelGGL((ped_quad_kernel<LOGQ, SPARSEV>), dim3(blocks), dim3(256), 0, st, x, y, xs, ys, n, c.ped, w0, \
