@@ -244,9 +244,19 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
  * caller. */
 int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
                                 uint64_t* s, uint8_t* status, size_t n);
+/* The two signing calls on DEVICE pointers (signature.py:137-173 per item, as above): one launch on `stream`,
+ * nothing staged and nothing waited for - the batch signer of a device-resident pipeline (message hashes left
+ * in HBM by sp_pedersen_chains_dev are signed where they lie).  status is required; r / s of an item whose
+ * status is not SP_SIGN_OK are left as they were.  seeds may be NULL (no seed for any item). */
+int sp_ecdsa_sign_batch_dev(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r, uint64_t* s,
+                            uint8_t* status, size_t n, void* stream);
+int sp_ecdsa_sign_rfc6979_batch_dev(const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
+                                    uint64_t* s, uint8_t* status, size_t n, void* stream);
 /* private_key_to_ec_point_on_stark_curve signature.py:104-106: (qx, qy) = d * EC_GEN.
  * status: 0 ok, 2 when d is not in (0, EC_ORDER). */
 int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* status, size_t n);
+/* The same on device pointers (qy, status may be NULL; outputs of a rejected item are left as they were). */
+int sp_public_key_batch_dev(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* status, size_t n, void* stream);
 
 /* ---- prover-side transforms over GF(p) (build-defined: the reference has no prover) -------------- */
 /* Field and generator: pedersen_params.json:20-21 (FIELD_PRIME, FIELD_GEN = 3).  All pointers are

@@ -1310,6 +1310,52 @@ int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint
   return SP_OK;
 }
 
+// Device-pointer forms of the two signing calls (the batch signer of a device-resident pipeline: message
+// hashes that sp_pedersen_chains_dev left in HBM are signed where they lie).  One launch on the caller's
+// stream, nothing staged, nothing waited for; r / s of an item whose status is not SP_SIGN_OK are left as
+// they were.  No shared state: the lock covers the launch bookkeeping only.
+int sp_ecdsa_sign_batch_dev(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r, uint64_t* s,
+                            uint8_t* status, size_t n, void* stream) {
+  CtxByPointer sp_ctx_sel__(z);  // the context of the device these pointers live on
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  if (!z || !d || !k || !r || !s || !status) { set_error("sp_ecdsa_sign_batch_dev: null pointer"); return SP_ERR_BAD_ARGUMENT; }
+  Context& c = ctx();
+  ctx_lock lk(c.mu);
+  hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z, d, k, r, s, status,
+                     n, c.gen, c.wbits, c.nwin);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+int sp_ecdsa_sign_rfc6979_batch_dev(const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
+                                    uint64_t* s, uint8_t* status, size_t n, void* stream) {
+  CtxByPointer sp_ctx_sel__(z);  // the context of the device these pointers live on
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  if (!z || !d || !r || !s || !status) { set_error("sp_ecdsa_sign_rfc6979_batch_dev: null pointer"); return SP_ERR_BAD_ARGUMENT; }
+  Context& c = ctx();
+  ctx_lock lk(c.mu);
+  hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z, d, seeds, r,
+                     s, status, n, c.gen, c.wbits, c.nwin);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
+// (qx, qy) = d * EC_GEN on device pointers; qy and status may be null.  Outputs of a rejected item are left as they were.
+int sp_public_key_batch_dev(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* status, size_t n, void* stream) {
+  CtxByPointer sp_ctx_sel__(d);  // the context of the device these pointers live on
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  if (!d || !qx) { set_error("sp_public_key_batch_dev: null pointer"); return SP_ERR_BAD_ARGUMENT; }
+  Context& c = ctx();
+  ctx_lock lk(c.mu);
+  hipLaunchKernelGGL(public_key_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, d, qx, qy, status, n,
+                     c.gen, c.wbits, c.nwin);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
 int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* status, size_t n) {
   LaneScope ls;
   SP_REQUIRE_READY();

@@ -18,7 +18,17 @@ struct sha256_state {
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, (uint32_t)n); }
 
-__device__ __noinline__ void sha256_compress(sha256_state& s, const uint32_t* block /* 16 big-endian words */) {
+struct sha256_block {
+  uint32_t w[16];  // big-endian words
+};
+
+// One compression; always inlined, and inlined exactly ONCE per kernel: rfc6979_nonce below runs its 16
+// compressions as the steps of one wave-uniform loop around a single copy of these 1.8 k instructions.
+// (The first version - a non-inlined compress behind a byte-stream SHA-256 whose message bytes and midstates lived
+// in scratch memory: 8.4 k instructions, 1391 scratch accesses and 66 call sites - cost 0.69 ms of a 0.92 ms
+// signature launch at 2^16 items; this form has no calls and no scratch: 0.62 of 0.85 ms.  What remains is the
+// rejection loop, see rfc6979_nonce.)
+__device__ __forceinline__ sha256_state sha256_compress(sha256_state s, sha256_block blk) {
   constexpr uint32_t K[64] = {
       0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
       0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
@@ -28,9 +38,7 @@ __device__ __noinline__ void sha256_compress(sha256_state& s, const uint32_t* bl
       0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
       0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
       0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-  uint32_t w[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) w[i] = block[i];
+  uint32_t* w = blk.w;
   uint32_t a = s.h[0], b = s.h[1], c = s.h[2], d = s.h[3], e = s.h[4], f = s.h[5], g = s.h[6], h = s.h[7];
 #pragma unroll
   for (int i = 0; i < 64; ++i) {
@@ -49,156 +57,116 @@ __device__ __noinline__ void sha256_compress(sha256_state& s, const uint32_t* bl
     h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
   }
   s.h[0] += a; s.h[1] += b; s.h[2] += c; s.h[3] += d; s.h[4] += e; s.h[5] += f; s.h[6] += g; s.h[7] += h;
+  return s;
 }
 
 __device__ __forceinline__ sha256_state sha256_init() {
   return sha256_state{{0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}};
 }
 
-// Streaming SHA-256 over big-endian bytes, byte granularity (messages here are < 200 bytes).
-struct sha256_stream {
-  sha256_state st;
-  uint32_t block[16];
-  uint32_t len;  // bytes absorbed
-};
-__device__ __forceinline__ void sha256_begin(sha256_stream& s, const sha256_state& start, uint32_t already) {
-  s.st = start;
-  s.len = already;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s.block[i] = 0;
-}
-__device__ __forceinline__ void sha256_put(sha256_stream& s, uint32_t byte) {
-  const uint32_t pos = s.len & 63u;
-  // dynamic word index kept cheap: select chain over 16 words
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    if ((int)(pos >> 2) == i) s.block[i] |= byte << (24 - 8 * (pos & 3u));
-  }
-  ++s.len;
-  if ((s.len & 63u) == 0) {
-    sha256_compress(s.st, s.block);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s.block[i] = 0;
-  }
-}
-__device__ __forceinline__ void sha256_put_words(sha256_stream& s, const uint32_t* be_words, int n_words) {
-  for (int i = 0; i < n_words; ++i) {
-    sha256_put(s, be_words[i] >> 24);
-    sha256_put(s, (be_words[i] >> 16) & 0xff);
-    sha256_put(s, (be_words[i] >> 8) & 0xff);
-    sha256_put(s, be_words[i] & 0xff);
-  }
-}
-__device__ __forceinline__ void sha256_end(sha256_stream& s, uint32_t* digest /* 8 big-endian words */) {
-  const uint32_t total_bits = s.len * 8u;
-  sha256_put(s, 0x80);
-  while ((s.len & 63u) != 56u) sha256_put(s, 0);
-  sha256_put(s, 0); sha256_put(s, 0); sha256_put(s, 0); sha256_put(s, 0);
-  sha256_put(s, total_bits >> 24); sha256_put(s, (total_bits >> 16) & 0xff);
-  sha256_put(s, (total_bits >> 8) & 0xff); sha256_put(s, total_bits & 0xff);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) digest[i] = s.st.h[i];
-}
-
-// HMAC-SHA256 with a 32-byte key: midstates after the ipad / opad blocks.
-struct hmac_key {
-  sha256_state inner, outer;
-};
-__device__ __forceinline__ hmac_key hmac_prepare(const uint32_t* key /* 8 BE words */) {
-  uint32_t blk[16];
-  hmac_key k;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) blk[i] = (i < 8 ? key[i] : 0u) ^ 0x36363636u;
-  k.inner = sha256_init();
-  sha256_compress(k.inner, blk);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) blk[i] = (i < 8 ? key[i] : 0u) ^ 0x5c5c5c5cu;
-  k.outer = sha256_init();
-  sha256_compress(k.outer, blk);
-  return k;
-}
-// One-block tail: `words` (8 big-endian words) plus, optionally, one more byte, hashed on top of a
-// midstate that has absorbed 64 bytes already.
-__device__ __forceinline__ void sha256_tail_block(const sha256_state& mid, const uint32_t* words, int extra_byte,
-                                                  uint32_t* digest) {
-  uint32_t blk[16];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) blk[i] = words[i];
-  blk[8] = extra_byte < 0 ? 0x80000000u : (((uint32_t)extra_byte << 24) | 0x00800000u);
-#pragma unroll
-  for (int i = 9; i < 15; ++i) blk[i] = 0;
-  blk[15] = extra_byte < 0 ? (64u + 32u) * 8u : (64u + 33u) * 8u;
-  sha256_state st = mid;
-  sha256_compress(st, blk);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) digest[i] = st.h[i];
-}
-
-// out = HMAC(key, V || [sep || d || h1 || entropy])   (sep < 0: V only)
-__device__ __forceinline__ void hmac_v(const hmac_key& key, const uint32_t* v, int sep, const uint32_t* d_be,
-                                       const uint32_t* h1_be, uint64_t seed, bool with_material, uint32_t* out) {
-  uint32_t inner[8];
-  if (sep >= 0 && with_material) {  // the two long messages: byte stream
-    sha256_stream s;
-    sha256_begin(s, key.inner, 64);
-    sha256_put_words(s, v, 8);
-    sha256_put(s, (uint32_t)sep);
-    sha256_put_words(s, d_be, 8);
-    sha256_put_words(s, h1_be, 8);
-    int nbytes = 0;
-    for (uint64_t t = seed; t != 0; t >>= 8) ++nbytes;
-    for (int i = nbytes - 1; i >= 0; --i) sha256_put(s, (uint32_t)((seed >> (8 * i)) & 0xff));
-    sha256_end(s, inner);
-  } else {  // V, or V || sep: a single block with a fixed layout
-    sha256_tail_block(key.inner, v, sep, inner);
-  }
-  sha256_tail_block(key.outer, inner, -1, out);
-}
-
-__device__ __forceinline__ void u256_to_be_words(const u256& a, uint32_t* be) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) be[i] = a.w[7 - i];
-}
-
 // k = generate_k(N, d, sha256, message(z), extra_entropy(seed)); returns the first valid candidate.
-__device__ __noinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint64_t seed) {
-  uint32_t d_be[8], h1_be[8], v[8], kk[8], t[8];
-  u256_to_be_words(d, d_be);
-  u256_to_be_words(z, h1_be);
+//
+// HMAC-SHA256 with 32-byte keys throughout: a key is the pair of midstates after its ipad / opad blocks
+// (kin, kout); HMAC(key, m) = compress*(kout, compress*(kin, m)).  The messages have fixed layouts:
+//   V                          one block behind the ipad block: V, 0x80, zeros, bit length (64 + 32) * 8
+//   V || sep                   the same with sep in front of the 0x80 and length (64 + 33) * 8
+//   V || sep || d || h1 || e   97 + nb bytes (e = the nb = 0..8 minimal big-endian bytes of the seed): always TWO
+//                              blocks; the stream sep || d || h1 || e || 0x80 is the word sequence X = d, h1, E
+//                              (entropy left-aligned, the 0x80 marker behind it) shifted right by one byte
+// so every block is assembled from whole words, and the 16 compressions of a nonce (+ 8 per rejected candidate)
+// are the steps of ONE loop.  A candidate int(V) >> 4 has 252 bits and N ~ 2^251: HALF of the candidates are
+// rejected, so a wave of 64 items runs 1 + ~7 rounds of the retry (the longest of 64 geometric runs): ~72
+// compressions where an item needs 24 on average - measured, quick_sign.py: the nonce is 0.46 ms of a 0.59 ms
+// signature launch whatever the batch size up to one wave per SIMD.  The wait is inherent to lockstep lanes
+// (the retry chain K = HMAC(K, V 00), V = HMAC(K, V), V = HMAC(K, V) is serial per item and must be followed
+// exactly to reproduce the reference's k); callers that hold their own nonces use sp_ecdsa_sign_batch_dev.
+//    0  1  2 | 3  4 | 5  6 | 7  8  9 | 10 11 | 12 13 | 14 15 | (16 17 | 18 19 | 20 21 -> 14)
+//    K = HMAC(0, V 00 d h1 e)   V = HMAC(K, V)   K = HMAC(K, V 01 d h1 e)   V = HMAC(K, V)   V = HMAC(K, V) -> k
+// The all-zero key of step 0 / 2 is a constant: compress(IV, 0x36 x 64), compress(IV, 0x5c x 64).
+__device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint64_t seed) {
+  uint32_t X[19];  // d, h1 big-endian, entropy + marker
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { v[i] = 0x01010101u; kk[i] = 0; }
-  hmac_key key = hmac_prepare(kk);
-  hmac_v(key, v, 0x00, d_be, h1_be, seed, true, kk);
-  key = hmac_prepare(kk);
-  hmac_v(key, v, -1, d_be, h1_be, seed, false, t);
+  for (int i = 0; i < 8; ++i) { X[i] = d.w[7 - i]; X[8 + i] = z.w[7 - i]; }
+  uint32_t nb = 0;
+  for (uint64_t t = seed; t != 0; t >>= 8) ++nb;
+  {
+    const uint64_t left = nb ? seed << (8u * (8u - nb)) : 0ull;  // entropy bytes left-aligned in 64 bits
+    X[16] = (uint32_t)(left >> 32); X[17] = (uint32_t)left; X[18] = 0u;
+    const uint32_t mark = 0x80u << (24u - 8u * (nb & 3u));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = t[i];
-  hmac_v(key, v, 0x01, d_be, h1_be, seed, true, kk);
-  key = hmac_prepare(kk);
-  hmac_v(key, v, -1, d_be, h1_be, seed, false, t);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = t[i];
-  for (int guard = 0; guard < 64; ++guard) {
-    hmac_v(key, v, -1, d_be, h1_be, seed, false, t);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = t[i];
-    u256 cand;  // int(V) >> 4
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t lo = v[7 - i], hi = i < 7 ? v[6 - i] : 0u;
-      cand.w[i] = (lo >> 4) | (hi << 28);
-    }
-    if (!u256_is_zero(cand) && u256_lt(cand, U256_N)) return cand;
-    hmac_v(key, v, 0x00, d_be, h1_be, seed, false, kk);
-    key = hmac_prepare(kk);
-    hmac_v(key, v, -1, d_be, h1_be, seed, false, t);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = t[i];
+    for (int i = 0; i < 3; ++i)
+      if ((int)(nb >> 2) == i) X[16 + i] |= mark;
   }
-  u256 zero;
+  uint32_t T[20];  // the byte-shifted stream; the separator byte is OR-ed into T[0] per use
+  T[0] = X[0] >> 8;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) zero.w[i] = 0;
-  return zero;  // unreachable in practice; the caller reports SP_SIGN_RETRY
+  for (int i = 1; i < 19; ++i) T[i] = (X[i - 1] << 24) | (X[i] >> 8);
+  T[19] = X[18] << 24;
+  const uint32_t long_bits = (64u + 97u + nb) * 8u;
+
+  sha256_state kin = {{0xf454dead, 0x9725214f, 0x90daf2a0, 0xdf1228ea, 0x64e5750f, 0xa3924181, 0x824a932b, 0xf8e04e32}};
+  sha256_state kout = {{0xd385480f, 0x7abb6477, 0x37c9c538, 0x5dd82467, 0x8e043a72, 0x753434b0, 0xdeb82818, 0x361d45a6}};
+  sha256_state v, kk = sha256_init(), acc = sha256_init();  // V, the new key K, the running digest
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v.h[i] = 0x01010101u;
+  u256 cand;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) cand.w[i] = 0;
+  int step = 0, rejected = 0;
+  for (;;) {
+    // ---- the block and the state it is compressed onto ----
+    sha256_block blk;
+    sha256_state st;
+    const bool long_a = step == 0 || step == 7, long_b = step == 1 || step == 8;
+    const bool pad_in = step == 3 || step == 10 || step == 18, pad_out = step == 4 || step == 11 || step == 19;
+    const bool outer = step == 2 || step == 6 || step == 9 || step == 13 || step == 15 || step == 17 || step == 21;
+    if (long_a) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { blk.w[i] = v.h[i]; blk.w[8 + i] = T[i]; }
+      blk.w[8] |= step == 7 ? 0x01000000u : 0u;
+      st = kin;
+    } else if (long_b) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) blk.w[i] = T[8 + i];
+      blk.w[12] = blk.w[13] = blk.w[14] = 0;
+      blk.w[15] = long_bits;
+      st = acc;
+    } else if (pad_in || pad_out) {
+      const uint32_t pad = pad_in ? 0x36363636u : 0x5c5c5c5cu;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) blk.w[i] = (i < 8 ? kk.h[i] : 0u) ^ pad;
+      st = sha256_init();
+    } else {  // a 32-byte message behind a 64-byte pad block: V (or V || 00 at step 16), or an inner digest
+#pragma unroll
+      for (int i = 0; i < 8; ++i) blk.w[i] = outer ? acc.h[i] : v.h[i];
+      blk.w[8] = step == 16 ? 0x00800000u : 0x80000000u;
+#pragma unroll
+      for (int i = 9; i < 15; ++i) blk.w[i] = 0;
+      blk.w[15] = step == 16 ? (64u + 33u) * 8u : (64u + 32u) * 8u;
+      st = outer ? kout : kin;
+    }
+    acc = sha256_compress(st, blk);
+    // ---- where the result goes ----
+    if (step == 2 || step == 9 || step == 17) kk = acc;                      // K = HMAC(K, ...)
+    else if (pad_in) kin = acc;
+    else if (pad_out) kout = acc;
+    else if (step == 6 || step == 13 || step == 15 || step == 21) v = acc;   // V = HMAC(K, V)
+    if (step == 15) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {  // int(V) >> 4
+        const uint32_t lo = v.h[7 - i], hi = i < 7 ? v.h[6 - i] : 0u;
+        cand.w[i] = (lo >> 4) | (hi << 28);
+      }
+      if (!u256_is_zero(cand) && u256_lt(cand, U256_N)) break;
+      if (++rejected == 64) {  // unreachable in practice; the caller reports SP_SIGN_RETRY for k = 0
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cand.w[i] = 0;
+        break;
+      }
+    }
+    step = step == 21 ? 14 : step + 1;
+  }
+  return cand;
 }
 
 }  // namespace sp

@@ -115,6 +115,9 @@ _SIGNATURES = {
     "sp_ecdsa_sign_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
     "sp_ecdsa_sign_rfc6979_batch": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t]),
     "sp_public_key_batch": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t]),
+    "sp_ecdsa_sign_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "sp_ecdsa_sign_rfc6979_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "sp_public_key_batch_dev": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]),
 }
 
 

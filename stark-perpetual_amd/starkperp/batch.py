@@ -339,6 +339,53 @@ def sign_attempt_many(msg_hashes, priv_keys, ks):
     return unpack_felts(r, n), unpack_felts(s, n), list(bytes(st)[:n])
 
 
+def sign_dev(z, d, seeds=None, k=None, stream=None):
+    """Signing on tensors that already live in HBM (sp_ecdsa_sign_rfc6979_batch_dev; with caller nonces `k`
+    sp_ecdsa_sign_batch_dev: one attempt, signature.py:146-173): z, d (and k) int64[n, 4] felts on the GPU, seeds
+    int64[n] or None -> (r, s, status) tensors on the same device, status uint8[n] of SIGN_OK / SIGN_RETRY /
+    SIGN_BAD_INPUT (include/starkperp.h).  One launch on the current stream, nothing is copied or waited for; r / s
+    of an item that is not SIGN_OK stay zero."""
+    import torch
+    n = z.shape[0]
+    assert z.is_cuda and z.dtype == torch.int64 and z.shape == (n, 4) and z.is_contiguous(), "z: int64[n, 4] on the GPU"
+    for t in (d, k):
+        assert t is None or (t.device == z.device and t.dtype == torch.int64 and t.shape == (n, 4) and t.is_contiguous())
+    assert seeds is None or k is None, "a caller nonce leaves no room for a seed"
+    if seeds is not None:
+        assert seeds.device == z.device and seeds.dtype == torch.int64 and seeds.shape == (n,) and seeds.is_contiguous()
+    r, s = torch.zeros_like(z), torch.zeros_like(z)
+    st = torch.zeros(n, dtype=torch.uint8, device=z.device)
+    if n == 0:
+        return r, s, st
+    lib = _lib.ensure_init()
+    h = torch.cuda.current_stream(z.device).cuda_stream if stream is None else stream
+    if k is None:
+        _lib.check(lib.sp_ecdsa_sign_rfc6979_batch_dev(z.data_ptr(), d.data_ptr(),
+                                                       None if seeds is None else seeds.data_ptr(), r.data_ptr(),
+                                                       s.data_ptr(), st.data_ptr(), n, h), "sp_ecdsa_sign_rfc6979_batch_dev")
+    else:
+        _lib.check(lib.sp_ecdsa_sign_batch_dev(z.data_ptr(), d.data_ptr(), k.data_ptr(), r.data_ptr(), s.data_ptr(),
+                                               st.data_ptr(), n, h), "sp_ecdsa_sign_batch_dev")
+    return r, s, st
+
+
+def public_keys_dev(d, want_y=True, stream=None):
+    """d int64[n, 4] on the GPU -> (qx, qy or None, status) on the same device (sp_public_key_batch_dev,
+    signature.py:104-106); status 0 ok, SIGN_BAD_INPUT for d outside (0, EC_ORDER) - that row stays zero."""
+    import torch
+    n = d.shape[0]
+    assert d.is_cuda and d.dtype == torch.int64 and d.shape == (n, 4) and d.is_contiguous(), "d: int64[n, 4] on the GPU"
+    qx = torch.zeros_like(d)
+    qy = torch.zeros_like(d) if want_y else None
+    st = torch.zeros(n, dtype=torch.uint8, device=d.device)
+    if n:
+        lib = _lib.ensure_init()
+        h = torch.cuda.current_stream(d.device).cuda_stream if stream is None else stream
+        _lib.check(lib.sp_public_key_batch_dev(d.data_ptr(), qx.data_ptr(), None if qy is None else qy.data_ptr(),
+                                               st.data_ptr(), n, h), "sp_public_key_batch_dev")
+    return qx, qy, st
+
+
 def sign_many(msg_hashes, priv_keys, seeds=None):
     """[sign(z, d, seed) ...] (signature.py:137-173) in one launch: RFC 6979 nonce, k*G, the mod-N
     finish and the reference's retry rule all run on the GPU (sp_ecdsa_sign_rfc6979_batch).  Items

@@ -8,8 +8,8 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .batch import (EC_ORDER, FIELD_PRIME, HASH_OUT_OF_RANGE, HASH_UNHASHABLE, VERIFY_TRUE, _raise_hash_status,
-                    raise_for_verify_code)
+from .batch import (EC_ORDER, FIELD_PRIME, HASH_OUT_OF_RANGE, HASH_UNHASHABLE, SIGN_BAD_INPUT, SIGN_OK, SIGN_RETRY,
+                    VERIFY_TRUE, _raise_hash_status, raise_for_verify_code)
 
 _P_LIMBS = np.array([(FIELD_PRIME >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
 
@@ -108,6 +108,43 @@ def verify_many(z, r, s, qx, qy=None) -> np.ndarray:
         zi, ri, si = (ints_from_felts(a[i : i + 1])[0] for a in (_felts(z), _felts(r), _felts(s)))
         raise_for_verify_code(int(codes[i]), zi, ri, si)
     return codes == VERIFY_TRUE
+
+
+def sign_many(z, d, seeds=None):
+    """sign(z, d, seed) per row (signature.py:137-173: RFC 6979 nonce, attempt and retry rule on the device,
+    sp_ecdsa_sign_rfc6979_batch) without a Python int per field element: z, d uint64[n, 4], seeds uint64[n] or
+    None (0 = no seed) -> (r, s) uint64[n, 4].  Raises the reference's AssertionError for a message >= 2^251
+    and for a key outside [1, EC_ORDER) (starkperp.batch.sign_many); an item the device hands back after eight
+    rejected nonces (a 2^-55 event each) is finished by the list API's host nonce generator."""
+    z = _felts(z)
+    n = z.shape[0]
+    d = _felts(d, n)
+    r, s = np.zeros((n, 4), dtype=np.uint64), np.zeros((n, 4), dtype=np.uint64)
+    if n == 0:
+        return r, s
+    st = np.zeros(n, dtype=np.uint8)
+    sd = None
+    if seeds is not None:
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert sd.shape == (n,), "seeds are uint64[n]"
+    lib = _lib.ensure_init()
+    _lib.check(lib.sp_ecdsa_sign_rfc6979_batch(_ptr(z), _ptr(d), None if sd is None else _ptr(sd), _ptr(r), _ptr(s),
+                                               _ptr(st), n), "sp_ecdsa_sign_rfc6979_batch")
+    bad = np.flatnonzero(st == SIGN_BAD_INPUT)
+    if bad.size:
+        i = int(bad[0])
+        zi, di = ints_from_felts(z[i : i + 1])[0], ints_from_felts(d[i : i + 1])[0]
+        assert 0 <= zi < 2**251, "Message not signable."
+        raise AssertionError("private key must be in [1, EC_ORDER), got %s" % hex(di))
+    left = np.flatnonzero(st == SIGN_RETRY)
+    if left.size:
+        from .batch import _sign_many_host_nonces
+        zs, ds = ints_from_felts(z[left]), ints_from_felts(d[left])
+        sl = [None if sd is None or int(sd[i]) == 0 else int(sd[i]) for i in left]
+        sigs = _sign_many_host_nonces(zs, ds, sl)
+        r[left] = felts_from_ints([a for a, _ in sigs])
+        s[left] = felts_from_ints([b for _, b in sigs])
+    return r, s
 
 
 def order_ids(message_hashes) -> np.ndarray:

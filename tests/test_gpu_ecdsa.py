@@ -61,6 +61,62 @@ def test_sign_all(batch, sig):
         sig.sign(2**251, 5)
 
 
+def test_sign_on_device_pointers_and_numpy(batch):
+    """The same 256 reference signatures (signature.py:137-173, seeds included) through the device-pointer
+    entry point (sp_ecdsa_sign_rfc6979_batch_dev: tensors in HBM, one launch on the caller's stream) and through
+    the NumPy entry point; the caller-nonce form against the list API; rejected items leave r / s untouched."""
+    import numpy as np
+    import torch
+    from starkperp import batch_np as bn, stark as st
+    cases = load("g3_sign.json")["cases"]
+    zs = [h(c[0]) for c in cases]
+    ds = [h(c[1]) for c in cases]
+    seeds = [0 if c[2] is None else h(c[2]) for c in cases]
+    want = [(h(c[3]), h(c[4])) for c in cases]
+    dz, dd = st.felts_to_tensor(zs), st.felts_to_tensor(ds)
+    dseed = torch.from_numpy(np.asarray(seeds, dtype=np.uint64).view(np.int64)).cuda()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # a caller's own stream
+        r, s, status = batch.sign_dev(dz, dd, dseed)
+    side.synchronize()
+    assert status.cpu().tolist() == [batch.SIGN_OK] * len(cases)
+    assert list(zip(st.tensor_to_felts(r), st.tensor_to_felts(s))) == want
+    unseeded = [i for i, c in enumerate(cases) if c[2] is None]
+    r0, s0, st0 = batch.sign_dev(dz[unseeded].contiguous(), dd[unseeded].contiguous())  # seeds = NULL
+    torch.cuda.synchronize()
+    assert list(zip(st.tensor_to_felts(r0), st.tensor_to_felts(s0))) == [want[i] for i in unseeded]
+    rn, sn = bn.sign_many(bn.felts_from_ints(zs), bn.felts_from_ints(ds), np.asarray(seeds, dtype=np.uint64))
+    assert list(zip(bn.ints_from_felts(rn), bn.ints_from_felts(sn))) == want
+    # one attempt with the caller's nonce: the host RFC 6979 nonces of the oracle give the same signatures
+    ks = [R.generate_k_rfc6979(z, d, None if sd == 0 else sd) for z, d, sd in zip(zs, ds, seeds)]
+    rk, sk, stk = batch.sign_dev(dz, dd, k=st.felts_to_tensor(ks))
+    torch.cuda.synchronize()
+    assert stk.cpu().tolist() == [batch.SIGN_OK] * len(cases)
+    assert list(zip(st.tensor_to_felts(rk), st.tensor_to_felts(sk))) == want
+    # out-of-range items: status SIGN_BAD_INPUT, their r / s rows stay zero, the neighbours are signed
+    bad_z = st.felts_to_tensor([2**251, zs[1], zs[2], zs[3]])
+    bad_d = st.felts_to_tensor([ds[0], 0, N, ds[3]])
+    rb, sb, stb = batch.sign_dev(bad_z, bad_d, dseed[:4].contiguous())
+    torch.cuda.synchronize()
+    assert stb.cpu().tolist() == [batch.SIGN_BAD_INPUT] * 3 + [batch.SIGN_OK]
+    assert st.tensor_to_felts(rb)[:3] == [0, 0, 0] and st.tensor_to_felts(sb)[:3] == [0, 0, 0]
+    assert (st.tensor_to_felts(rb)[3], st.tensor_to_felts(sb)[3]) == want[3]
+    with pytest.raises(AssertionError, match="Message not signable."):
+        bn.sign_many(bn.felts_from_ints([2**251]), bn.felts_from_ints([5]))
+    with pytest.raises(AssertionError, match="private key"):
+        bn.sign_many(bn.felts_from_ints([5]), bn.felts_from_ints([N]))
+    # public keys on device pointers
+    keys = load("g2_keys.json")["keys"]
+    qx, qy, stq = batch.public_keys_dev(st.felts_to_tensor([h(d) for d, _, _ in keys] + [0, N]))
+    torch.cuda.synchronize()
+    assert stq.cpu().tolist() == [0] * len(keys) + [batch.SIGN_BAD_INPUT] * 2
+    assert list(zip(st.tensor_to_felts(qx), st.tensor_to_felts(qy)))[: len(keys)] == [(h(x), h(y)) for _, x, y in keys]
+    qx2, qy2, _ = batch.public_keys_dev(st.felts_to_tensor([h(d) for d, _, _ in keys]), want_y=False)
+    torch.cuda.synchronize()
+    assert qy2 is None and st.tensor_to_felts(qx2) == [h(x) for _, x, _ in keys]
+
+
 def _key(c):
     return tuple(h(v) for v in c["key"]) if isinstance(c["key"], list) else h(c["key"])
 
