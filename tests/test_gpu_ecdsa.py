@@ -106,6 +106,18 @@ def test_sign_on_device_pointers_and_numpy(batch):
         bn.sign_many(bn.felts_from_ints([2**251]), bn.felts_from_ints([5]))
     with pytest.raises(AssertionError, match="private key"):
         bn.sign_many(bn.felts_from_ints([5]), bn.felts_from_ints([N]))
+    # empty batches are no-ops; a missing status / output pointer is refused before anything is launched
+    from starkperp import _lib
+    lib = _lib.ensure_init()
+    e = torch.zeros((0, 4), dtype=torch.int64, device="cuda")
+    assert [t.shape[0] for t in batch.sign_dev(e, e)] == [0, 0, 0]
+    assert lib.sp_ecdsa_sign_rfc6979_batch_dev(None, None, None, None, None, None, 0, None) == 0
+    assert lib.sp_ecdsa_sign_rfc6979_batch_dev(dz.data_ptr(), dd.data_ptr(), None, r.data_ptr(), s.data_ptr(), None,
+                                               4, None) != 0
+    assert b"null pointer" in lib.sp_last_error()
+    assert lib.sp_ecdsa_sign_batch_dev(dz.data_ptr(), dd.data_ptr(), None, r.data_ptr(), s.data_ptr(),
+                                       status.data_ptr(), 4, None) != 0
+    assert lib.sp_public_key_batch_dev(dd.data_ptr(), None, None, None, 4, None) != 0
     # public keys on device pointers
     keys = load("g2_keys.json")["keys"]
     qx, qy, stq = batch.public_keys_dev(st.felts_to_tensor([h(d) for d, _, _ in keys] + [0, N]))
