@@ -22,7 +22,10 @@ Rank 0 prints ONE JSON line.  `value` = Pedersen hashes/s over the whole job.
                 they were collected on.
   airfri        the second half of BASELINE.json's metric: 2^20-row AIR+FRI commit jobs per second
                 (configs[3]), per-phase times with each phase's dominant kernel and HBM fraction, its own
-                roofline and a CPU baseline (oracle/stark_ref.py, build-defined, parity unpinned).
+                roofline and a CPU baseline (oracle/stark_ref.py, build-defined, parity unpinned).  With
+                N > 1 ranks: independent 2^20-row jobs on every GPU started together (no data-path
+                collective), commits_per_sec = N x the slowest rank's rate; ONE trace sharded over the
+                ranks is `--workload airfri`.
   cpu_baseline  the oracle (pure-Python restatement of the reference algorithm) on the host cores, a
                 bounded sample of the same tree; cpu_baseline_c the same algorithm in C on the whole tree;
                 cpu_baseline_opt an optimised CPU comparator (windowed tables + batched affine additions).
@@ -391,7 +394,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-airfri", action="store_true",
-                    help="merkle workload: skip the `airfri` object (the 2^20-row AIR+FRI half of the metric)")
+                    help="merkle workload: skip the `airfri` object (the 2^20-row AIR+FRI half of the metric; at N > 1 "
+                         "independent jobs on every GPU)")
     args = ap.parse_args()
 
     import torch
@@ -538,6 +542,26 @@ def main():
     hashes_per_step = world * (n_leaves - 1) + (world - 1)
     value = hashes_per_step * args.steps / elapsed
 
+    # The AIR + FRI half of the metric at N > 1: independent 2^20-row jobs on every GPU (BASELINE north_star:
+    # "independent order batches ... shard across the 8 GPUs"), no data-path collective; the ranks start their
+    # timed jobs together and the job rate of the node is n_gpus x the slowest rank's rate.
+    airfri_multi = None
+    if world > 1 and not args.no_airfri:
+        loc = airfri_object(torch, lib, _lib, dev, False, brief=True, fence=fence)
+        t = torch.tensor([loc["commits_per_sec"], 1.0 / loc["seconds_per_job_one_stream"]], dtype=torch.float64, device=dev)
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        loc["commits_per_sec_slowest_gpu"] = float(t[0])
+        loc["commits_per_sec"] = world * float(t[0])
+        loc["seconds_per_job_one_stream"] = 1.0 / float(t[1])
+        loc["n_gpus"] = world
+        loc["scaling"] = "weak"
+        loc["sharding"] = ("independent 2^20-row jobs on every GPU, no data-path collective: commits_per_sec = n_gpus x "
+                           "the slowest rank's rate (seconds_per_job_one_stream = the slowest rank's); ONE trace over "
+                           "all ranks is `--workload airfri`")
+        airfri_multi = loc
+
     if rank == 0:
         wbits = int(lib.sp_window_bits())
         n_l = max(int(k_launches.value), 1)
@@ -607,8 +631,9 @@ def main():
         }
         if world > 1:
             result["combine_matches_recomputed"] = combine_check(slots[0], world, _lib)
-        if world == 1 and not args.no_airfri:
-            result["airfri"] = airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline)
+        if not args.no_airfri:
+            result["airfri"] = (airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline) if world == 1
+                                else airfri_multi)
         if world == 1 and not args.no_extras:
             result["extra"] = extras(torch, lib, _lib, dev, stream)
         if world == 1 and not args.no_cpu_baseline:
@@ -850,11 +875,13 @@ def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, tr
     dist.destroy_process_group()
 
 
-def airfri_object(torch, lib, _lib, dev, with_cpu):
+def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None):
     """BASELINE.json configs[3], the second half of the metric: one 2^20-row Pedersen-step trace ->
     4-column LDE to 2^22 -> commit -> composition -> commit -> 16 folds with 15 layer commits (25.2 M
     Pedersen hashes).  Inputs (the witness) resident in HBM.  commits_per_sec times independent jobs
-    alternating over three streams, exactly what `--workload airfri` times per GPU."""
+    alternating over three streams, exactly what `--workload airfri` times per GPU.
+    brief (the N > 1 form of the default line): every rank runs its own jobs - `fence` (barrier + synchronize)
+    lines the ranks up in front of the timed jobs - and the object stops after the rates and the hash roofline."""
     import random
     from starkperp import stark
     m = 2048
@@ -910,11 +937,28 @@ def airfri_object(torch, lib, _lib, dev, with_cpu):
         torch.cuda.synchronize()
 
     pipelined(3)
+    if fence is not None:
+        fence()
     t0 = time.perf_counter()
     pipelined(9)
     out["commits_per_sec"] = 9 / (time.perf_counter() - t0)
     out["commits_per_sec_note"] = "9 independent jobs alternating over 3 streams (tree tops of one job beside the row " \
                                   "hashing of the next); one job at a time: %.1f commits/s" % (1.0 / t_seq)
+    n_l = max(int(k_launches.value), 1)
+    rate = (k_units.value / n_l) / ((k_ms.value / 1e3) / n_l) if k_ms.value > 0 else 0.0
+    roof = valu_issue(rate, int(lib.sp_window_bits()),
+                      "inside the ped_accumulate_kernel launches of three sequential jobs (HIP events)",
+                      include_finish=False) or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None}
+    roof.update({"kernel": "ped_accumulate_kernel (row chains and the tree levels above 65 536 hashes: %.0f %% of the "
+                           "job's hashes)" % (100.0 * k_units.value / (3.0 * hashes)),
+                 "launches": int(k_launches.value), "avg_launch_us": (k_ms.value / n_l) * 1e3,
+                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
+                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
+                 "hbm": {"achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}})
+    if brief:
+        out["roofline"] = roof
+        return out
     out["witness_generation_seconds"] = timed(lambda: stark.pedersen_trace(xs, ys), 2)
     t_lde = stark.lde(trace)
     comp = stark.air_eval(t_lde, per, n_rows, alphas)
@@ -948,18 +992,6 @@ def airfri_object(torch, lib, _lib, dev, with_cpu):
                          "hbm_frac_of_8_tb_per_s": algo[k] / phase_s[k] / 1e9 / HBM_PEAK_GBS,
                          "traffic_per_launch_of_dominant_kernel": pmc_traffic(
                              "sp::" + dominant[k][0], "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json"))} for k in phase_s}
-    n_l = max(int(k_launches.value), 1)
-    rate = (k_units.value / n_l) / ((k_ms.value / 1e3) / n_l) if k_ms.value > 0 else 0.0
-    roof = valu_issue(rate, int(lib.sp_window_bits()),
-                      "inside the ped_accumulate_kernel launches of three sequential jobs (HIP events)",
-                      include_finish=False) or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None}
-    roof.update({"kernel": "ped_accumulate_kernel (row chains and the tree levels above 65 536 hashes: %.0f %% of the "
-                           "job's hashes)" % (100.0 * k_units.value / (3.0 * hashes)),
-                 "launches": int(k_launches.value), "avg_launch_us": (k_ms.value / n_l) * 1e3,
-                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
-                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
-                 "hbm": {"achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}})
     out["roofline"] = roof
     stark.prove(xs, ys, n_queries=8, seed=0)
     torch.cuda.synchronize()

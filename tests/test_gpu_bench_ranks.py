@@ -38,6 +38,12 @@ def test_two_ranks_share_one_gpu(workload, extra):
     if workload == "merkle":
         assert d["config"]["hashes_per_step"] == 2 * 65535 + 1
         assert d["combine_matches_recomputed"] is True
+        # the AIR + FRI half of the metric at N > 1: independent 2^20-row jobs on every rank, n_gpus x the slowest rate
+        a = d["airfri"]
+        assert a["n_gpus"] == 2 and a["scaling"] == "weak" and a["pedersen_hashes_per_job"] == 6 * (1 << 22) - 128
+        assert a["commits_per_sec"] == pytest.approx(2 * a["commits_per_sec_slowest_gpu"]) and a["commits_per_sec"] > 0
+        assert d["summary"]["airfri_commits_per_sec"] == a["commits_per_sec"]
+        assert list(d)[-1] == "summary"
     else:  # ONE 2^15- / 2^20-row proof over the two ranks: its roots are the single-GPU roots of the same trace
         assert d["config"]["rows_total"] == 2 << int(extra[5]) and d["sharded_roots_match_single_gpu"] is True
         assert d["config"]["exchange"]["per_fold"].startswith("none")
@@ -56,7 +62,8 @@ def test_eight_ranks_share_one_gpu(workload, extra):
     env = dict(os.environ, STARKPERP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", STARKPERP_WINDOW_BITS="16")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "8", "--workload", workload, "--window-bits", "0", "--no-extras", "--no-cpu-baseline"] + extra
+           "--gpus", "8", "--workload", workload, "--window-bits", "0", "--no-extras", "--no-cpu-baseline",
+           "--no-airfri"] + extra  # (the per-rank AIR + FRI jobs of the default line are covered by the two-rank test)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
