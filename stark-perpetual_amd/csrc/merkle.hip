@@ -34,6 +34,13 @@ int get_scratch_public(size_t n, Scratch& s, hipStream_t st);
 int enqueue_partial_points(const uint64_t* felts, int count, aff_packed* out, hipStream_t st, bool* usable);
 int enqueue_pedersen_sparse(const uint64_t* x, const uint64_t* y, uint64_t* out, unsigned* flag, size_t n,
                             hipStream_t st, const Scratch& s, const int2* src, const aff_packed* cpts);
+struct PathLevels {  // pedersen.hip ped_path_kernel
+  int first, n_levels;
+  int val_base[66];
+  unsigned src_off[66];
+};
+int enqueue_pedersen_path(uint64_t* felts, const uint64_t* emp, unsigned* flag, size_t n, hipStream_t st,
+                          const int2* src_all, const PathLevels& pl, const aff_packed* cpts_tree, bool* done);
 
 static DeviceBuffer g_sparse_buf;
 // empty-subtree roots are a pure function of the empty leaf: cached on the host per leaf value
@@ -591,10 +598,26 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
       t.cpts_state = usable ? 1 : -1;
     }
     const aff_packed* cpts = t.cpts_state == 1 ? (const aff_packed*)t.cpts.ptr : nullptr;
-    for (unsigned l = 0; l < height; ++l) {
+    for (unsigned l = 0; l < height;) {
+      // a run of levels whose paths do not merge (as many parents as children: every node has ONE touched child)
+      // goes out as one launch where the size class allows it (ped_path_kernel)
+      unsigned l2 = l;
+      while (l2 < height && cnt[l2 + 1] == cnt[l]) ++l2;
+      if (l2 - l >= 2) {
+        PathLevels pl;
+        std::memset(&pl, 0, sizeof(pl));
+        pl.first = (int)l;
+        pl.n_levels = (int)(l2 - l);
+        for (unsigned j = 0; j <= height; ++j) { pl.val_base[j] = lv.val_base[j]; pl.src_off[j] = lv.src_off[j]; }
+        bool done = false;
+        rc = enqueue_pedersen_path(d_felts, d_emp, s.flag, cnt[l], st, d_src, pl, cpts, &done);
+        if (rc != SP_OK) return rc;
+        if (done) { l = l2; continue; }
+      }
       rc = enqueue_pedersen_sparse(d_felts, d_emp + 4 * l, d_felts + 4 * (size_t)lv.val_base[l + 1], s.flag, cnt[l + 1],
                                    st, s, d_src + lv.src_off[l], cpts ? cpts + 2 * l : nullptr);
       if (rc != SP_OK) return rc;
+      ++l;
     }
   }
   // ---- the device runs; nobody waits on the library lock for it ----

@@ -423,27 +423,18 @@ ped_accumulate_mixed_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
 // 26-bit windows: a tree sum of depth 4 instead of 5, 14 instead of 18 rounds.  The window list is per lane group
 // ("virtual" window v: 0 = the constant point, v >= 1 = real window cx + v - 1, resp. v - 1), the loop bound is the
 // largest of the wave.  Requires 1 + nwin - max(cx, cy) >= 2 * QUADS.
-template <int LOG_Q, bool SPARSE = false>
-__global__ void __launch_bounds__(256)
-ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride, size_t ystride,
-                size_t n, const aff_packed* __restrict__ ped, int w0, int log2e, int nwin_plan,
-                uint8_t* __restrict__ status, unsigned* __restrict__ flag, const int2* __restrict__ src,
-                uint64_t* __restrict__ out, size_t ostride, int dup, const aff_packed* __restrict__ cpts, int cx,
-                int cy) {
-  constexpr int QUADS = 1 << LOG_Q, LANES = 4 * QUADS;
-  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // dup: 2^dup lane groups compute the same hash, so that a wave holds ONE value while the level is small
-  // enough anyway (the variable-time inversion runs as long as the slowest value of the wave)
-  const size_t e_raw = gt / ((size_t)LANES << dup);
-  const int g = (int)(gt % LANES), q = g >> 2, k = g & 3;
-  const bool active = e_raw < n;
-  const size_t e = active ? e_raw : n - 1;  // clamp: whole groups stay convergent for the lane exchanges
-  const uint64_t *fx, *fy;
-  operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
-  int mode = 0, nwin = nwin_plan, first_real = 0;  // mode 1 / 2: the left / right operand is the level's constant
+// The hash of one lane group (see ped_quad_kernel): fx / fy = the two operands (global memory, or LDS through a
+// generic pointer), mode = 0, or 1 / 2 when the left / right operand is the level's constant whose point is cpts[0] /
+// cpts[1]; g = lane within the group.  Returns the plain affine x on EVERY lane of the group; *unhashable is set
+// when the sum met an exceptional addition (signature.py:313).
+template <int LOG_Q, bool SPARSE>
+__device__ __forceinline__ u256 quad_hash(const uint64_t* fx, const uint64_t* fy, int mode, const aff_packed* __restrict__ cpts,
+                                          int cx, int cy, const aff_packed* __restrict__ ped, int w0, int log2e,
+                                          int nwin_plan, int g, bool* unhashable) {
+  constexpr int QUADS = 1 << LOG_Q;
+  const int q = g >> 2, k = g & 3;
+  int nwin = nwin_plan, first_real = 0;
   if constexpr (SPARSE) {
-    const int2 sc = src[e];
-    mode = sc.x < 0 ? 1 : (sc.y < 0 ? 2 : 0);
     nwin = mode == 0 ? nwin_plan : 1 + nwin_plan - (mode == 1 ? cx : cy);
     first_real = mode == 1 ? cx - 1 : (mode == 2 ? -1 : 0);  // real window of virtual window v >= 1: first_real + v
   }
@@ -501,17 +492,102 @@ ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, 
   if constexpr (LOG_Q == 2) { SP_BUTTERFLY(4, false) SP_BUTTERFLY(8, true) }
   if constexpr (LOG_Q == 3) { SP_BUTTERFLY(4, false) SP_BUTTERFLY(8, false) SP_BUTTERFLY(16, true) }
 #undef SP_BUTTERFLY
-  uint8_t st = SP_HASH_OK;
   // ZZ = 0 - an exceptional addition (signature.py:313 territory) - shows as a zero inverse: the inversion answers
   // 0 for a multiple of p and only for one, so no test of ZZ sits on the chain in front of it
   const fe zinv = fe_inv_quad<true>(s.b, k);  // plain-form inverse: no fe_from_mont
-  if (limbs_is_zero(zinv)) st = SP_HASH_UNHASHABLE;
-  const u256 xa_plain = fe_pack(fe_canon(fe_mul(s.a, zinv)));
+  *unhashable = limbs_is_zero(zinv);
+  return fe_pack(fe_canon(fe_mul(s.a, zinv)));
+}
+
+template <int LOG_Q, bool SPARSE = false>
+__global__ void __launch_bounds__(256)
+ped_quad_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride, size_t ystride,
+                size_t n, const aff_packed* __restrict__ ped, int w0, int log2e, int nwin_plan,
+                uint8_t* __restrict__ status, unsigned* __restrict__ flag, const int2* __restrict__ src,
+                uint64_t* __restrict__ out, size_t ostride, int dup, const aff_packed* __restrict__ cpts, int cx,
+                int cy) {
+  constexpr int QUADS = 1 << LOG_Q, LANES = 4 * QUADS;
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // dup: 2^dup lane groups compute the same hash, so that a wave holds ONE value while the level is small
+  // enough anyway (the variable-time inversion runs as long as the slowest value of the wave)
+  const size_t e_raw = gt / ((size_t)LANES << dup);
+  const int g = (int)(gt % LANES);
+  const bool active = e_raw < n;
+  const size_t e = active ? e_raw : n - 1;  // clamp: whole groups stay convergent for the lane exchanges
+  const uint64_t *fx, *fy;
+  operand_pointers(x, y, xstride, ystride, src, e, fx, fy);
+  int mode = 0;  // mode 1 / 2: the left / right operand is the level's constant
+  if constexpr (SPARSE) {
+    const int2 sc = src[e];
+    mode = sc.x < 0 ? 1 : (sc.y < 0 ? 2 : 0);
+  }
+  bool unhashable;
+  const u256 xa_plain = quad_hash<LOG_Q, SPARSE>(fx, fy, mode, cpts, cx, cy, ped, w0, log2e, nwin_plan, g, &unhashable);
+  uint8_t st = unhashable ? SP_HASH_UNHASHABLE : SP_HASH_OK;
   if (!active || g != 0) return;
   if (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P)) st = SP_HASH_OUT_OF_RANGE;
   st_u256(out + 4 * e * ostride, xa_plain);
   if (status) status[e] = st;
   if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
+}
+
+// Levels of a sparse multi-update whose paths do not merge (every node has exactly one touched child: the 40-odd
+// lowest levels of a height-64 update over random keys) as ONE launch: a lane group follows its path from level to
+// level, the node value it has just computed - present on every lane of the group - goes to the group's LDS slot
+// and is the next level's touched operand; the other operand (a sibling the lookup kernel copied from the tree's
+// table, or the level's empty-subtree root) and the child lists are independent of the chain.  Every node value is
+// also written to `felts` for the insertion into the table.  Saves the launch boundary and the store -> load round
+// trip through HBM between two levels.  pl.val_base / pl.src_off are merkle.hip's TreeLevels fields; level
+// `pl.first` is the children's level of the first hash.
+struct PathLevels {
+  int first, n_levels;
+  int val_base[66];
+  unsigned src_off[66];
+};
+template <int LOG_Q, bool SPARSE>
+__global__ void __launch_bounds__(256)
+ped_path_kernel(uint64_t* __restrict__ felts, const uint64_t* __restrict__ emp, size_t n,
+                const aff_packed* __restrict__ ped, int w0, int log2e, int nwin_plan, unsigned* __restrict__ flag,
+                const int2* __restrict__ src_all, PathLevels pl, int dup, const aff_packed* __restrict__ cpts_tree,
+                int cx, int cy) {
+  constexpr int QUADS = 1 << LOG_Q, LANES = 4 * QUADS;
+  __shared__ uint64_t slot[256 / LANES][4];
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e_raw = gt / ((size_t)LANES << dup);
+  const int g = (int)(gt % LANES), grp = (int)(threadIdx.x / LANES);
+  const bool active = e_raw < n;
+  const size_t e = active ? e_raw : n - 1;
+  for (int i = 0; i < pl.n_levels; ++i) {
+    const int l = pl.first + i;  // the children's level; the node computed here is node e of level l + 1
+    const int2 sc = src_all[pl.src_off[l] + e];
+    const uint64_t* y = emp + 4 * l;
+    const uint64_t* fx = sc.x >= 0 ? felts + 4 * (size_t)sc.x : y;
+    const uint64_t* fy = sc.y >= 0 ? felts + 4 * (size_t)sc.y : y;
+    if (i > 0) {  // the touched child is the node this group computed one level below: node e of level l
+      if (sc.x == pl.val_base[l] + (int)e) fx = slot[grp];
+      else fy = slot[grp];
+    }
+    int mode = 0;
+    if constexpr (SPARSE) mode = sc.x < 0 ? 1 : (sc.y < 0 ? 2 : 0);
+    bool unhashable;
+    const u256 xa = quad_hash<LOG_Q, SPARSE>(fx, fy, mode, cpts_tree ? cpts_tree + 2 * l : nullptr, cx, cy, ped, w0, log2e,
+                                             nwin_plan, g, &unhashable);
+    uint8_t st = unhashable ? SP_HASH_UNHASHABLE : SP_HASH_OK;
+    // only the first level can see a caller's value (the new leaves); above it the operands are hash outputs,
+    // table values and empty-subtree roots
+    if (i == 0 && g == 0 && (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P))) st = SP_HASH_OUT_OF_RANGE;
+    __syncthreads();  // every lane of the block has taken its windows of this level
+    if (g == 0) {
+      uint32_t* sl = reinterpret_cast<uint32_t*>(slot[grp]);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sl[w] = xa.w[w];
+      if (active) {
+        st_u256(felts + 4 * ((size_t)pl.val_base[l + 1] + e), xa);
+        if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // Kernel B: thread t owns elements t, t+T, t+2T, ...; one inversion per thread (Montgomery's trick).
@@ -753,6 +829,47 @@ int enqueue_pedersen_sparse(const uint64_t* x, const uint64_t* y, uint64_t* out,
                             hipStream_t st, const Scratch& s, const int2* src, const aff_packed* cpts) {
   return enqueue_pedersen_impl(x, 1, y, 1, out, 1, nullptr, flag, n, st, s, src, cpts);
 }
+static bool g_path_fusion = getenv("STARKPERP_NO_PATH_FUSION") == nullptr;  // A/B switch
+// pl.n_levels consecutive levels of a sparse multi-update with n nodes each and no merging paths, as one launch
+// (ped_path_kernel).  *done = false when the levels are not of a size class the quad kernels serve (or the switch is
+// off): the caller then enqueues them one by one.  cpts_tree: the tree's constant points ([2 l], [2 l + 1]) or null.
+int enqueue_pedersen_path(uint64_t* felts, const uint64_t* emp, unsigned* flag, size_t n, hipStream_t st,
+                          const int2* src_all, const PathLevels& pl, const aff_packed* cpts_tree, bool* done) {
+  *done = false;
+  Context& c = ctx();
+  const int w0 = c.plan.bits[0], log2e = c.plan.log2e, nwin = c.plan.nwin;
+  if (!g_path_fusion || !g_quad_enabled || nwin > 64 || n == 0 || pl.n_levels < 2) return SP_OK;
+  int log_q = 0;  // the size classes of enqueue_pedersen_impl
+  if (n <= g_quad_max && nwin >= 16) log_q = 3;
+  else if (n <= 2 * g_quad_max && nwin >= 8) log_q = 2;
+  else if (n <= 4 * g_quad_max && nwin >= 4 && g_quad2_enabled) log_q = 1;
+  if (log_q == 0) return SP_OK;
+  int cx = 0, cy = 0;
+  bool sparse = false;
+  if (g_sparse_enabled && cpts_tree != nullptr && (log_q == 1 || log_q == 2)) {
+    constant_window_counts(c.plan, cx, cy);
+    const int shortest = 1 + nwin - (cx > cy ? cx : cy);
+    sparse = cx >= 1 && cy >= 1 && shortest >= (2 << log_q);
+  }
+  int dup = 0;
+  while ((4 << (log_q + dup)) < 64 && ((n * 4) << (log_q + dup + 1)) <= 65536) ++dup;  // up to one hash per wave
+  if (g_quad_no_dup) dup = 0;
+  const unsigned blocks = (unsigned)((((n * 4) << (log_q + dup)) + 255) / 256);
+#define SP_LAUNCH_PATH(LOGQ, SPARSEV)                                                                             \
+  hipLaunchKernelGGL((ped_path_kernel<LOGQ, SPARSEV>), dim3(blocks), dim3(256), 0, st, felts, emp, n, c.ped, w0, log2e, \
+                     nwin, flag, src_all, pl, dup, sparse ? cpts_tree : nullptr, cx, cy)
+  if (sparse) {
+    if (log_q == 2) SP_LAUNCH_PATH(2, true);
+    else SP_LAUNCH_PATH(1, true);
+  } else if (log_q == 3) SP_LAUNCH_PATH(3, false);
+  else if (log_q == 2) SP_LAUNCH_PATH(2, false);
+  else SP_LAUNCH_PATH(1, false);
+#undef SP_LAUNCH_PATH
+  SP_HIP(hipGetLastError());
+  *done = true;
+  return SP_OK;
+}
+
 static int enqueue_pedersen_impl(const uint64_t* x, size_t xs, const uint64_t* y, size_t ys, uint64_t* out,
                                  size_t os, uint8_t* status, unsigned* flag, size_t n, hipStream_t st,
                                  const Scratch& s, const int2* src, const aff_packed* cpts) {
