@@ -590,6 +590,54 @@ ped_path_kernel(uint64_t* __restrict__ felts, const uint64_t* __restrict__ emp, 
   }
 }
 
+// The small levels of a DENSE forest (at most 2048 hashes per level: the eight-quad size class) as one launch per
+// FOUR levels: a block of 8 lane groups (256 threads = one wave per SIMD of its CU: two blocks' waves on one SIMD
+// would halve the speed of both chains) takes 2^L consecutive nodes of level j (L <= 4 levels remain inside every
+// tree) and hashes them down to one node of level j + L - 8, 4, 2, 1 hashes - handing every node value on through
+// LDS (two slot arrays, written and read alternately: one barrier per level) and writing it to its place in the
+// level-major buffer.  At a level of c < 8 hashes the 8 / c groups that share a hash all compute it (the `dup` idiom of
+// ped_quad_kernel: a wave holds ONE value for the variable-time inversion); the first of them writes.  Same chain per
+// level as ped_quad_kernel<3>, without the launch boundary and the HBM round trip between levels.
+__global__ void __launch_bounds__(256)
+ped_top_kernel(uint64_t* __restrict__ cur, size_t n_in, int n_levels, const aff_packed* __restrict__ ped, int w0, int log2e,
+               int nwin_plan, unsigned* __restrict__ flag) {
+  constexpr int LANES = 32, GROUPS = 256 / LANES;  // 8
+  __shared__ uint64_t slot[2][GROUPS][4];
+  const int g = (int)(threadIdx.x % LANES), grp = (int)(threadIdx.x / LANES);
+  const size_t b = blockIdx.x;
+  const int chunk = 1 << n_levels;  // input nodes of this block (<= 16)
+  uint64_t* out = cur + 4 * n_in;   // level j + 1
+  size_t n_out = n_in >> 1;
+  int share = 4 - n_levels;  // log2 of the groups per hash at the first level
+  for (int t = 0; t < n_levels; ++t, ++share) {
+    const int cnt = chunk >> (t + 1);  // hashes of this block at this level = GROUPS >> share
+    const int i = grp >> share;
+    const bool writer = g == 0 && (grp & ((1 << share) - 1)) == 0;
+    const uint64_t *fx, *fy;
+    if (t == 0) {
+      fx = cur + 4 * ((size_t)chunk * b + 2 * (size_t)i);
+      fy = fx + 4;
+    } else {
+      fx = slot[(t - 1) & 1][2 * i];
+      fy = slot[(t - 1) & 1][2 * i + 1];
+    }
+    bool unhashable;
+    const u256 xa = quad_hash<3, false>(fx, fy, 0, nullptr, 0, 0, ped, w0, log2e, nwin_plan, g, &unhashable);
+    uint8_t st = unhashable ? SP_HASH_UNHASHABLE : SP_HASH_OK;
+    if (t == 0 && writer && (!u256_lt(ld_u256(fx), U256_P) || !u256_lt(ld_u256(fy), U256_P))) st = SP_HASH_OUT_OF_RANGE;
+    if (writer) {
+      uint32_t* sl = reinterpret_cast<uint32_t*>(slot[t & 1][i]);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sl[w] = xa.w[w];
+      st_u256(out + 4 * ((size_t)cnt * b + (size_t)i), xa);
+      if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
+    }
+    __syncthreads();
+    out += 4 * n_out;
+    n_out >>= 1;
+  }
+}
+
 // Kernel B: thread t owns elements t, t+T, t+2T, ...; one inversion per thread (Montgomery's trick).
 // Launched with at most one wave per SIMD when it can be (finish_threads), so nothing hides a load:
 // both passes are software-pipelined by hand (the operands of element j +- 1 are requested before
@@ -830,6 +878,23 @@ int enqueue_pedersen_sparse(const uint64_t* x, const uint64_t* y, uint64_t* out,
   return enqueue_pedersen_impl(x, 1, y, 1, out, 1, nullptr, flag, n, st, s, src, cpts);
 }
 static bool g_path_fusion = getenv("STARKPERP_NO_PATH_FUSION") == nullptr;  // A/B switch
+static bool g_top_fusion = getenv("STARKPERP_NO_TOP_FUSION") == nullptr;    // A/B switch
+// Up to four consecutive small levels of a dense forest as one launch (ped_top_kernel): `cur` = the level-major
+// buffer at a level of n_in nodes, `remaining` = levels left inside every tree.  Returns the number of levels
+// enqueued (0: not this size class, the caller enqueues one level the usual way).
+int enqueue_pedersen_top(uint64_t* cur, size_t n_in, unsigned remaining, unsigned* flag, hipStream_t st, int* levels_done) {
+  *levels_done = 0;
+  Context& c = ctx();
+  const int nwin = c.plan.nwin;
+  if (!g_top_fusion || !g_quad_enabled || nwin > 64 || nwin < 16 || remaining < 2 || n_in / 2 > g_quad_max || n_in < 4) return SP_OK;
+  const int L = remaining < 4 ? (int)remaining : 4;
+  const unsigned blocks = (unsigned)(n_in >> L);  // every tree holds a whole number of 2^L-node chunks at this level
+  hipLaunchKernelGGL(ped_top_kernel, dim3(blocks), dim3(256), 0, st, cur, n_in, L, c.ped, (int)c.plan.bits[0], c.plan.log2e,
+                     nwin, flag);
+  SP_HIP(hipGetLastError());
+  *levels_done = L;
+  return SP_OK;
+}
 // pl.n_levels consecutive levels of a sparse multi-update with n nodes each and no merging paths, as one launch
 // (ped_path_kernel).  *done = false when the levels are not of a size class the quad kernels serve (or the switch is
 // off): the caller then enqueues them one by one.  cpts_tree: the tree's constant points ([2 l], [2 l + 1]) or null.
@@ -1223,11 +1288,21 @@ int sp_merkle_forest_dev(uint64_t* levels, size_t n_trees, unsigned height, uint
   SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
   uint64_t* cur = levels;
   size_t n = n0;
-  for (unsigned k = 0; k < height; ++k, n >>= 1) {
+  for (unsigned k = 0; k < height;) {
+    int fused = 0;  // the small levels go out four at a time (ped_top_kernel)
+    rc = enqueue_pedersen_top(cur, n, height - k, s.flag, st, &fused);
+    if (rc != SP_OK) return rc;
+    if (fused > 0) {
+      for (int j = 0; j < fused; ++j, n >>= 1) cur += 4 * n;
+      k += (unsigned)fused;
+      continue;
+    }
     uint64_t* nxt = cur + 4 * n;
     rc = enqueue_pedersen(cur, 2, cur + 4, 2, nxt, 1, nullptr, s.flag, n / 2, st, s, nullptr);
     if (rc != SP_OK) return rc;
     cur = nxt;
+    ++k;
+    n >>= 1;
   }
   if (status) SP_HIP(hipMemcpyAsync(status, s.flag, 1, hipMemcpyDeviceToHost, st));
   return SP_OK;
