@@ -590,6 +590,50 @@ ped_path_kernel(uint64_t* __restrict__ felts, const uint64_t* __restrict__ emp, 
   }
 }
 
+// Hash chains as ONE launch: lane group e folds its chain h <- H(h, w_j) (or H(w_j, h): h_right) over `steps`
+// words, the running hash - present on every lane of the group - handed on through the group's LDS slot; the
+// words are read from HBM ahead of the chain.  first + 4 e = the chain's start value, words + 4 e its first word,
+// word_stride = felts between consecutive words of one chain (the word-major layout of sp_pedersen_chains_dev:
+// `width`; a single chain folded from its last element down: -1).  A 4096-order batch's message hashes are three
+// such steps, a program-hash chain (sp_pedersen_chain_right) thousands: the launch boundary and the HBM round trip
+// of every step go.
+template <int LOG_Q>
+__global__ void __launch_bounds__(256)
+ped_chain_kernel(const uint64_t* __restrict__ first, const uint64_t* __restrict__ words, long long word_stride, size_t n,
+                 int steps, bool h_right, const aff_packed* __restrict__ ped, int w0, int log2e, int nwin_plan,
+                 unsigned* __restrict__ flag, uint64_t* __restrict__ out, int dup) {
+  constexpr int QUADS = 1 << LOG_Q, LANES = 4 * QUADS;
+  __shared__ uint64_t slot[256 / LANES][4];
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e_raw = gt / ((size_t)LANES << dup);
+  const int g = (int)(gt % LANES), grp = (int)(threadIdx.x / LANES);
+  const bool active = e_raw < n;
+  const size_t e = active ? e_raw : n - 1;
+  const uint64_t* h = first + 4 * e;
+  const uint64_t* w = words + 4 * e;
+  for (int j = 0; j < steps; ++j, w += 4 * word_stride) {
+    const uint64_t* fx = h_right ? w : h;
+    const uint64_t* fy = h_right ? h : w;
+    bool unhashable;
+    const u256 xa = quad_hash<LOG_Q, false>(fx, fy, 0, nullptr, 0, 0, ped, w0, log2e, nwin_plan, g, &unhashable);
+    uint8_t st = unhashable ? SP_HASH_UNHASHABLE : SP_HASH_OK;
+    // every word is a caller's value; the running hash is one only at the first step
+    if (g == 0 && (!u256_lt(ld_u256(w), U256_P) || (j == 0 && !u256_lt(ld_u256(h), U256_P)))) st = SP_HASH_OUT_OF_RANGE;
+    __syncthreads();
+    if (g == 0) {
+      uint32_t* sl = reinterpret_cast<uint32_t*>(slot[grp]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sl[k] = xa.w[k];
+      if (active) {
+        if (j == steps - 1) st_u256(out + 4 * e, xa);
+        if (st != SP_HASH_OK && flag) atomicOr(flag, (unsigned)st);
+      }
+    }
+    __syncthreads();
+    h = slot[grp];
+  }
+}
+
 // The small levels of a DENSE forest (at most 2048 hashes per level: the eight-quad size class) as one launch per
 // FOUR levels: a block of 8 lane groups (256 threads = one wave per SIMD of its CU: two blocks' waves on one SIMD
 // would halve the speed of both chains) takes 2^L consecutive nodes of level j (L <= 4 levels remain inside every
@@ -879,6 +923,35 @@ int enqueue_pedersen_sparse(const uint64_t* x, const uint64_t* y, uint64_t* out,
 }
 static bool g_path_fusion = getenv("STARKPERP_NO_PATH_FUSION") == nullptr;  // A/B switch
 static bool g_top_fusion = getenv("STARKPERP_NO_TOP_FUSION") == nullptr;    // A/B switch
+static bool g_chain_fusion = getenv("STARKPERP_NO_CHAIN_FUSION") == nullptr;  // A/B switch
+// n chains of `steps` hashes each as one launch (ped_chain_kernel); *done = false when n is not of a size class the
+// quad kernels serve or there is a single step: the caller enqueues the steps one by one.
+int enqueue_pedersen_chain(const uint64_t* first, const uint64_t* words, long long word_stride, size_t n, size_t steps,
+                           bool h_right, uint64_t* out, unsigned* flag, hipStream_t st, bool* done) {
+  *done = false;
+  Context& c = ctx();
+  const int w0 = c.plan.bits[0], log2e = c.plan.log2e, nwin = c.plan.nwin;
+  if (!g_chain_fusion || !g_quad_enabled || nwin > 64 || n == 0 || steps < 2 || steps > 0x7fffffffull) return SP_OK;
+  int log_q = 0;  // the size classes of enqueue_pedersen_impl
+  if (n <= g_quad_max && nwin >= 16) log_q = 3;
+  else if (n <= 2 * g_quad_max && nwin >= 8) log_q = 2;
+  else if (n <= 4 * g_quad_max && nwin >= 4 && g_quad2_enabled) log_q = 1;
+  if (log_q == 0) return SP_OK;
+  int dup = 0;
+  while ((4 << (log_q + dup)) < 64 && ((n * 4) << (log_q + dup + 1)) <= 65536) ++dup;  // up to one hash per wave
+  if (g_quad_no_dup) dup = 0;
+  const unsigned blocks = (unsigned)((((n * 4) << (log_q + dup)) + 255) / 256);
+#define SP_LAUNCH_CHAIN(LOGQ)                                                                                      \
+  hipLaunchKernelGGL((ped_chain_kernel<LOGQ>), dim3(blocks), dim3(256), 0, st, first, words, word_stride, n, (int)steps, \
+                     h_right, c.ped, w0, log2e, nwin, flag, out, dup)
+  if (log_q == 3) SP_LAUNCH_CHAIN(3);
+  else if (log_q == 2) SP_LAUNCH_CHAIN(2);
+  else SP_LAUNCH_CHAIN(1);
+#undef SP_LAUNCH_CHAIN
+  SP_HIP(hipGetLastError());
+  *done = true;
+  return SP_OK;
+}
 // Up to four consecutive small levels of a dense forest as one launch (ped_top_kernel): `cur` = the level-major
 // buffer at a level of n_in nodes, `remaining` = levels left inside every tree.  Returns the number of levels
 // enqueued (0: not this size class, the caller enqueues one level the usual way).
@@ -1180,8 +1253,13 @@ int sp_pedersen_chains_dev(const uint64_t* elems, size_t width, size_t depth, ui
   }
   // h lives in `out` and is updated in place: thread e reads x[e] and writes out[e] only after
   // kernel A of the same launch pair consumed it (A and B are separate kernels on one stream).
+  bool fused = false;  // small batches of chains: every step inside one launch (ped_chain_kernel)
+  if (depth >= 3) {
+    rc = enqueue_pedersen_chain(elems, elems + 4 * width, (long long)width, width, depth - 1, false, out, s.flag, st, &fused);
+    if (rc != SP_OK) return rc;
+  }
   const uint64_t* h = elems;
-  for (size_t j = 1; j < depth; ++j) {
+  for (size_t j = 1; j < depth && !fused; ++j) {
     rc = enqueue_pedersen(h, 1, elems + 4 * j * width, 1, out, 1, nullptr, s.flag, width, st, s, nullptr);
     if (rc != SP_OK) return rc;
     h = out;
@@ -1251,7 +1329,13 @@ int sp_pedersen_chain_right(const uint64_t* elems, size_t n_elems, uint64_t* out
   SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), 0));
   const uint64_t* h = d_el + 4 * (n_elems - 1);
   uint64_t* nxt = d_a;
-  for (size_t i = n_elems - 1; i-- > 0;) {
+  bool fused = false;  // the whole fold inside one launch: h = H(e_i, h) for i = n - 2 .. 0 (ped_chain_kernel)
+  if (n_elems >= 3) {
+    rc = enqueue_pedersen_chain(h, d_el + 4 * (n_elems - 2), -1, 1, n_elems - 1, true, d_a, s.flag, 0, &fused);
+    if (rc != SP_OK) return rc;
+    if (fused) h = d_a;
+  }
+  for (size_t i = n_elems - 1; !fused && i-- > 0;) {
     rc = enqueue_pedersen(d_el + 4 * i, 1, h, 1, nxt, 1, nullptr, s.flag, 1, 0, s, nullptr);
     if (rc != SP_OK) return rc;
     h = nxt;

@@ -72,6 +72,41 @@ def test_chain(batch):
         assert batch.pedersen_chain(el) == exp
 
 
+def test_chains_in_one_launch_vs_c_oracle(batch):
+    """Batches of equal-depth chains in every size class of the fused chain kernel (<= 2048 / 4096 / 8192 chains: eight,
+    four, two quads per hash) and just beyond it (one launch per step), depths 2 .. 9, against the C oracle step by
+    step; a single long chain folded from the left and from the right (the program-hash shape); an out-of-range
+    word in the middle of a chain is reported, not reduced."""
+    from oracle import cref
+    from starkperp import _lib, hash_chains as hc
+    rng = random.Random(123)
+    for width, depth in ((1, 9), (7, 3), (300, 5), (2048, 4), (2049, 3), (4096, 4), (5000, 3), (8192, 3), (8193, 3),
+                         (64, 2)):
+        chains = [[rng.randrange(P) for _ in range(depth)] for _ in range(width)]
+        exp = [c[0] for c in chains]
+        for j in range(1, depth):
+            exp, st = cref.pedersen_hash_many(exp, [c[j] for c in chains])
+            assert not any(st)
+        assert batch.pedersen_chains_many(chains) == exp, (width, depth)
+    words = [rng.randrange(P) for _ in range(200)]
+    left = words[0]
+    for w in words[1:]:
+        left = cref.pedersen_hash_many([left], [w])[0][0]
+    assert batch.pedersen_chain(words) == left
+    right = words[-1]
+    for w in reversed(words[:-1]):
+        right = cref.pedersen_hash_many([w], [right])[0][0]
+    assert hc.compute_hash_chain(words) == right
+    # status flag of the fused launch: word 2 of chain 5 is p itself
+    lib = _lib.ensure_init()
+    width, depth = 16, 4
+    flat = [rng.randrange(P) for _ in range(width * depth)]
+    flat[2 * width + 5] = P
+    out, st = _lib.new_felts(width), _lib.new_bytes(1)
+    _lib.check(lib.sp_pedersen_chains(_lib.pack_felts(flat), width, depth, out, st), "sp_pedersen_chains")
+    assert st[0] & 1  # SP_HASH_OUT_OF_RANGE
+
+
 def test_merkle_small(batch):
     g = load("g6_merkle.json")
     for hgt in range(0, 11):
