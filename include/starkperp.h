@@ -87,7 +87,8 @@ int sp_init(int device, int window_bits);
  *     they are handed (lanes go round-robin over the contexts, so concurrent host threads spread over the
  *     devices), and one call of sp_pedersen_batch / sp_ecdsa_verify_batch with 16384 items or more is cut into
  *     one contiguous slice per context, the slices running side by side on host threads of the library; sp_pedersen_batch_dev, sp_pedersen_chains_dev, sp_merkle_build_dev, sp_merkle_forest_dev,
- *     sp_commit_rows_dev and sp_ecdsa_verify_batch_dev run on the device their pointers live on (the stream
+ *     sp_commit_rows_dev, sp_ecdsa_verify_batch_dev, sp_ecdsa_sign_batch_dev, sp_ecdsa_sign_rfc6979_batch_dev and
+ *     sp_public_key_batch_dev run on the device their pointers live on (the stream
  *     must belong to that device);
  *   - everything with state - persistent trees, key tables, the prover entry points (twiddle tables, witness
  *     scratch) and the remaining host-pointer calls - stays on the primary device.
