@@ -437,6 +437,7 @@ def grind_key(key_seed, key_value_limit):
 LIMIT_ORDER_WITH_FEES = 3
 TRANSFER = 4
 CONDITIONAL_TRANSFER = 5
+WITHDRAWAL = 6
 WITHDRAWAL_TO_ADDRESS = 7
 
 
@@ -517,6 +518,36 @@ def get_withdrawal_to_address_msg(
     w = _pack([(WITHDRAWAL_TO_ADDRESS, 0), (position_id, 64), (nonce, 32), (amount, 64),
                (expiration_timestamp, 32), (0, 49)])
     return h(h(asset_id_collateral, int(eth_address, 16)), w)
+
+
+def get_withdrawal_msg(
+    asset_id_collateral, position_id, nonce, expiration_timestamp, amount, hash_function=pedersen_hash,
+):
+    """Old-API withdrawal, transaction type 6: services/perpetual/cairo/transactions/withdrawal.cairo:57-60
+    (owner_key == public_key branch) with the packing of :66-74; JS twin
+    services/perpetual/public/js/perpetual_messages.js:49-82 (bounds :63-72)."""
+    assert 0 <= asset_id_collateral < 2**250 and 0 <= nonce < 2**32 and 0 <= position_id < 2**64
+    assert 0 <= expiration_timestamp < 2**32 and 0 <= amount < 2**64
+    w = _pack([(WITHDRAWAL, 0), (position_id, 64), (nonce, 32), (amount, 64),
+               (expiration_timestamp, 32), (0, 49)])
+    return hash_function(asset_id_collateral, w)
+
+
+def withdrawal_hash(
+    asset_id_collateral, position_id, owner_key, public_key, nonce, expiration_timestamp, amount,
+    hash_function=pedersen_hash,
+):
+    """withdrawal.cairo:47-78: both branches of the message the program verifies."""
+    h = hash_function
+    if owner_key == public_key:
+        first, kind = asset_id_collateral, WITHDRAWAL
+    else:
+        first, kind = h(asset_id_collateral, owner_key), WITHDRAWAL_TO_ADDRESS
+    w = kind
+    for value, upper in ((position_id, 2**64), (nonce, 2**32), (amount, 2**64),
+                         (expiration_timestamp, 2**32)):
+        w = w * upper + value
+    return h(first, w * 2**49)
 
 
 def get_price_msg(oracle_name, asset_pair, timestamp, price, hash_function=pedersen_hash):

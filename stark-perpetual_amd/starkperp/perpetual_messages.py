@@ -12,6 +12,7 @@ from .signature import pedersen_hash
 LIMIT_ORDER_WITH_FEES = 3
 TRANSFER = 4
 CONDITIONAL_TRANSFER = 5
+WITHDRAWAL = 6
 WITHDRAWAL_TO_ADDRESS = 7
 
 
@@ -50,8 +51,8 @@ def _transfer_words(kind, sender_position_id, receiver_position_id, src_fee_posi
     return word0, word1
 
 
-def _withdrawal_word(position_id, nonce, amount, expiration_timestamp):
-    word = WITHDRAWAL_TO_ADDRESS
+def _withdrawal_word(position_id, nonce, amount, expiration_timestamp, kind=WITHDRAWAL_TO_ADDRESS):
+    word = kind
     word = word * 2**64 + position_id
     word = word * 2**32 + nonce
     word = word * 2**64 + amount
@@ -181,6 +182,41 @@ def get_withdrawal_to_address_msg(asset_id_collateral, position_id, eth_address,
         hash_function=hash_function)
 
 
+def get_withdrawal_msg_without_bounds(asset_id_collateral, position_id, nonce, expiration_timestamp, amount,
+                                      hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """The old-API withdrawal (transaction type 6: the owner key IS the signing key and is not part of
+    the message): services/perpetual/cairo/transactions/withdrawal.cairo:57-60,66-74, JS twin
+    services/perpetual/public/js/perpetual_messages.js:49-82.  h(asset_id_collateral,
+    6 | position_id (64) | nonce (32) | amount (64) | expiration_timestamp (32) | 0 (49))."""
+    return hash_function(asset_id_collateral,
+                         _withdrawal_word(position_id, nonce, amount, expiration_timestamp, WITHDRAWAL))
+
+
+def get_withdrawal_msg(asset_id_collateral, position_id, nonce, expiration_timestamp, amount,
+                       hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """Argument order of the JS builder (perpetual_messages.js:49-56); bounds :63-72 (the Cairo
+    assumptions withdrawal.cairo:42-46)."""
+    assert 0 <= asset_id_collateral < 2**250
+    assert 0 <= nonce < 2**32
+    assert 0 <= position_id < 2**64
+    assert 0 <= expiration_timestamp < 2**32
+    assert 0 <= amount < 2**64
+    return get_withdrawal_msg_without_bounds(
+        asset_id_collateral, position_id, nonce, expiration_timestamp, amount, hash_function=hash_function)
+
+
+def withdrawal_hash(asset_id_collateral, position_id, owner_key, public_key, nonce, expiration_timestamp,
+                    amount, hash_function: Callable[..., int] = pedersen_hash) -> int:
+    """The message the Cairo program checks a withdrawal's signature against (withdrawal.cairo:47-78):
+    type 6 without the owner key when owner_key == public_key (the old API), otherwise type 7 over
+    h(asset_id_collateral, owner_key) - the owner key in the place of the eth address."""
+    if owner_key == public_key:
+        return get_withdrawal_msg_without_bounds(
+            asset_id_collateral, position_id, nonce, expiration_timestamp, amount, hash_function=hash_function)
+    return _fold(hash_function, [asset_id_collateral, owner_key,
+                                 _withdrawal_word(position_id, nonce, amount, expiration_timestamp)])
+
+
 def get_price_msg(oracle_name: int, asset_pair: int, timestamp: int, price: int,
                   hash_function=pedersen_hash):
     """perpetual_messages.py:311-326."""
@@ -236,6 +272,36 @@ def withdrawal_to_address_msgs_many(withdrawals: Sequence[Sequence]):
         address = int(eth_address, 16) if isinstance(eth_address, str) else int(eth_address)
         words.append([asset_id_collateral, address, _withdrawal_word(position_id, nonce, amount, expiration)])
     return batch.pedersen_chains_many(words)
+
+
+def withdrawal_msgs_many(withdrawals: Sequence[Sequence[int]]):
+    """Many old-API withdrawals (5-tuples in get_withdrawal_msg argument order): one hash each."""
+    xs = [w[0] for w in withdrawals]
+    ys = [_withdrawal_word(position_id, nonce, amount, expiration, WITHDRAWAL)
+          for _, position_id, nonce, expiration, amount in withdrawals]
+    return batch.pedersen_hash_many(xs, ys)
+
+
+def withdrawal_hashes_many(withdrawals: Sequence[Sequence[int]]):
+    """withdrawal_hash for a mixed batch (7-tuples: asset_id_collateral, position_id, owner_key,
+    public_key, nonce, expiration_timestamp, amount): the type-6 messages as one batch of single hashes,
+    the type-7 ones as depth-3 chains; results in input order."""
+    old = [i for i, w in enumerate(withdrawals) if w[2] == w[3]]
+    new = [i for i, w in enumerate(withdrawals) if w[2] != w[3]]
+    out = [None] * len(withdrawals)
+    if old:
+        got = withdrawal_msgs_many([(withdrawals[i][0], withdrawals[i][1], withdrawals[i][4],
+                                     withdrawals[i][5], withdrawals[i][6]) for i in old])
+        for i, v in zip(old, got):
+            out[i] = v
+    if new:
+        got = batch.pedersen_chains_many([
+            [withdrawals[i][0], withdrawals[i][2],
+             _withdrawal_word(withdrawals[i][1], withdrawals[i][4], withdrawals[i][6], withdrawals[i][5])]
+            for i in new])
+        for i, v in zip(new, got):
+            out[i] = v
+    return out
 
 
 def verify_price_signatures_many(prices: Sequence[Sequence[int]], signatures: Sequence[Sequence[int]],

@@ -237,6 +237,12 @@ def test_messages(sig):
             asset_id_collateral=d["assetIdCollateral"], eth_address=d["ethAddress"],
             position_id=d["positionId"], nonce=d["nonce"],
             expiration_timestamp=d["expirationTimestamp"], amount=d["amount"])) == exp
+    for exp, d in m["withdrawal"].items():  # type 6 (withdrawal.cairo:57-60), KAT 0x6fbdeabb...c7f62
+        assert hex(pm.get_withdrawal_msg(
+            asset_id_collateral=d["assetIdCollateral"], position_id=d["positionId"], nonce=d["nonce"],
+            expiration_timestamp=d["expirationTimestamp"], amount=d["amount"])) == exp
+        assert hex(spm.withdrawal_msgs_many([(d["assetIdCollateral"], d["positionId"], d["nonce"],
+                                              d["expirationTimestamp"], d["amount"])])[0]) == exp
     g = load("g5_messages.json")
     orders = wl.limit_orders(256, seed=g["seed"])
     got = spm.limit_order_msgs_many([wl.order_args(o) for o in orders])
@@ -253,6 +259,11 @@ def test_messages(sig):
     assert spm.withdrawal_to_address_msgs_many(wd) == [R.get_withdrawal_to_address_msg(*a) for a in wd]
     assert spm.withdrawal_to_address_msgs_many([(5, 6, 0xabc, 7, 8, 9)]) == [
         R.get_withdrawal_to_address_msg(5, 6, "0xabc", 7, 8, 9)]
+    w6 = [(5 + i, 6 + i, 7, 8, 9 + i) for i in range(5)]
+    assert spm.withdrawal_msgs_many(w6) == [R.get_withdrawal_msg(*a) for a in w6]
+    mixed = [(5 + i, 6, 100 + (i % 2), 100, 7, 8, 9 + i) for i in range(6)]  # owner == signer on even i
+    assert spm.withdrawal_hashes_many(mixed) == [R.withdrawal_hash(*a) for a in mixed]
+    assert [pm.withdrawal_hash(*a) for a in mixed[:2]] == [R.withdrawal_hash(*a) for a in mixed[:2]]
     # oracle price quorum: one hash + one verification per signed price (oracle_price.cairo:96-108)
     keys = [R.private_to_stark_key(1000 + i) for i in range(3)]
     zs = [R.get_price_msg(*a) for a in pr]

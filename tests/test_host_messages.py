@@ -55,6 +55,23 @@ def test_scalar_builders_with_the_oracle_hash_match_the_reference_kats():
         assert hex(pm.get_withdrawal_to_address_msg(
             d["assetIdCollateral"], d["positionId"], d["ethAddress"], d["nonce"],
             d["expirationTimestamp"], d["amount"], hash_function=H)) == exp
+    for exp, d in m["withdrawal"].items():  # type 6, withdrawal.cairo:57-60
+        assert hex(pm.get_withdrawal_msg(
+            d["assetIdCollateral"], d["positionId"], d["nonce"], d["expirationTimestamp"], d["amount"],
+            hash_function=H)) == exp
+        assert hex(pm.withdrawal_hash(d["assetIdCollateral"], d["positionId"], 5, 5, d["nonce"],
+                                      d["expirationTimestamp"], d["amount"], hash_function=H)) == exp
+    # both branches of the Cairo selector against the oracle's restatement, and the bounds
+    for owner, signer in ((9, 9), (9, 10)):
+        assert pm.withdrawal_hash(3, 4, owner, signer, 5, 6, 7, hash_function=H) == \
+            R.withdrawal_hash(3, 4, owner, signer, 5, 6, 7)
+    for bad in ((2**250, 1, 1, 1, 1), (1, 2**64, 1, 1, 1), (1, 1, 2**32, 1, 1), (1, 1, 1, 2**32, 1),
+                (1, 1, 1, 1, 2**64), (1, 1, -1, 1, 1)):
+        try:
+            pm.get_withdrawal_msg(*bad, hash_function=H)
+        except AssertionError:
+            continue
+        raise AssertionError("accepted an out-of-range withdrawal field")
 
 
 def test_pi_as_string_leading_digits():

@@ -101,6 +101,16 @@ def test_reference_message_kats():
             d["assetIdCollateral"], d["positionId"], d["ethAddress"], d["nonce"],
             d["expirationTimestamp"], d["amount"])
         assert hex(got) == exp
+        # the Cairo program's type-7 branch puts the owner key where the eth address is (withdrawal.cairo:61-64)
+        assert hex(R.withdrawal_hash(d["assetIdCollateral"], d["positionId"], int(d["ethAddress"], 16),
+                                     12345, d["nonce"], d["expirationTimestamp"], d["amount"])) == exp
+    assert m["withdrawal"], "the reference's type-6 withdrawal vector is part of the fixture"
+    for exp, d in m["withdrawal"].items():  # perpetual_messages_precomputed.json:16-24
+        got = R.get_withdrawal_msg(d["assetIdCollateral"], d["positionId"], d["nonce"],
+                                   d["expirationTimestamp"], d["amount"])
+        assert hex(got) == exp
+        assert hex(R.withdrawal_hash(d["assetIdCollateral"], d["positionId"], 777, 777, d["nonce"],
+                                     d["expirationTimestamp"], d["amount"])) == exp
 
 
 def test_g1_pedersen_sample_and_edges():
