@@ -801,6 +801,9 @@ struct KeyCache {
   std::unordered_map<KeyId, uint32_t, KeyIdHash> slot_of;
   std::unordered_map<KeyId, uint32_t, KeyIdHash> invalid;  // key -> sentinel slot
   std::vector<uint32_t> free_slots;                        // slots taken back from invalid keys
+  // a caller holds handles from sp_ecdsa_register_keys: the verify policy must not start a new generation
+  // behind its back (its items would all come back SP_VERIFY_STALE_SLOT) - it falls back to the ladder instead
+  bool external_handles = false;
 };
 static KeyCache g_keys;
 static std::unordered_map<KeyId, uint8_t, KeyIdHash> g_seen_keys;  // unregistered keys met before (verify policy)
@@ -844,6 +847,7 @@ void release_ecdsa_state() {
   g_keys.slot_of.clear();
   g_keys.invalid.clear();
   g_keys.free_slots.clear();
+  g_keys.external_handles = false;
   g_seen_keys.clear();
 }
 }
@@ -991,12 +995,14 @@ static int build_key_tables(const std::vector<uint64_t>& qx, const std::vector<u
   return SP_OK;
 }
 
-int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uint32_t* slots) {
-  SP_REQUIRE_READY();
-  if (n == 0) return SP_OK;
-  ctx_lock lk(ctx().mu);
+// Registration proper; the caller holds the context lock (and keeps it until the launch that uses the handles
+// is enqueued when it is the verify policy that registers: ADVICE r3).
+static int register_keys_locked(const uint64_t* qx, const uint64_t* qy, size_t n, uint32_t* slots) {
   int rc = key_cache_ready();
   if (rc != SP_OK) return rc;
+  // size cap of the "known not to be a key" map, applied BEFORE this call records anything: a clear between two
+  // bad keys of one call would forget the first one and leave its handle on a slot that has been freed
+  if (g_keys.invalid.size() > ((size_t)1 << 20)) g_keys.invalid.clear();
   std::vector<uint64_t> fx, fy;
   std::vector<uint8_t> fh;
   std::vector<uint32_t> fs;
@@ -1054,31 +1060,47 @@ int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uin
   // curve: flagged by key_rows_kernel) gives its slot back and is remembered in the host map: an untrusted
   // key stream cannot fill the cache with keys that will never verify anything.
   if (!fs.empty()) {
-    std::vector<uint8_t> all_flags(g_keys.used), flags(fs.size());  // ONE copy (<= 128 KiB), not one per new key
-    SP_HIP(hipMemcpy(all_flags.data(), g_keys.flag.ptr, g_keys.used, hipMemcpyDeviceToHost));
-    bool any_bad = false;
-    for (size_t j = 0; j < fs.size(); ++j) {
-      flags[j] = all_flags[fs[j]];
-      any_bad |= flags[j] == KEY_INVALID_X || flags[j] == KEY_OFF_CURVE;
+    // flags of the NEW slots only: they are fs[] - mostly one contiguous run handed out by `used++`, plus recycled
+    // slots - so copy the covering range of the run and the recycled ones one by one (round 3 copied all `used`
+    // flag bytes per registration: 16 MiB with the largest STARKPERP_KEY_CACHE_SLOTS)
+    std::vector<uint8_t> flags(fs.size());
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (uint32_t sl : fs) { lo = sl < lo ? sl : lo; hi = sl > hi ? sl : hi; }
+    if ((size_t)(hi - lo) + 1 <= 4 * fs.size() + 64) {
+      std::vector<uint8_t> span((size_t)(hi - lo) + 1);
+      SP_HIP(hipMemcpy(span.data(), (const uint8_t*)g_keys.flag.ptr + lo, span.size(), hipMemcpyDeviceToHost));
+      for (size_t j = 0; j < fs.size(); ++j) flags[j] = span[fs[j] - lo];
+    } else {
+      for (size_t j = 0; j < fs.size(); ++j)
+        SP_HIP(hipMemcpy(&flags[j], (const uint8_t*)g_keys.flag.ptr + fs[j], 1, hipMemcpyDeviceToHost));
     }
-    if (any_bad) {
-      for (size_t j = 0; j < fs.size(); ++j) {
-        if (flags[j] != KEY_INVALID_X && flags[j] != KEY_OFF_CURVE) continue;
-        const uint32_t sentinel = flags[j] == KEY_INVALID_X ? SENTINEL_INVALID_X : SENTINEL_OFF_CURVE;
-        g_keys.slot_of.erase(added[j]);
-        if (g_keys.invalid.size() > ((size_t)1 << 20)) g_keys.invalid.clear();
-        g_keys.invalid.emplace(added[j], sentinel);
-        const uint8_t zero = KEY_EMPTY;
-        SP_HIP(hipMemcpy((uint8_t*)g_keys.flag.ptr + fs[j], &zero, 1, hipMemcpyHostToDevice));
-        g_keys.free_slots.push_back(fs[j]);
-      }
+    std::unordered_map<KeyId, uint32_t, KeyIdHash> bad_here;  // this call's bad keys -> sentinel slot
+    for (size_t j = 0; j < fs.size(); ++j) {
+      if (flags[j] != KEY_INVALID_X && flags[j] != KEY_OFF_CURVE) continue;
+      const uint32_t sentinel = flags[j] == KEY_INVALID_X ? SENTINEL_INVALID_X : SENTINEL_OFF_CURVE;
+      g_keys.slot_of.erase(added[j]);
+      g_keys.invalid.emplace(added[j], sentinel);
+      bad_here.emplace(added[j], sentinel);
+      const uint8_t zero = KEY_EMPTY;
+      SP_HIP(hipMemcpy((uint8_t*)g_keys.flag.ptr + fs[j], &zero, 1, hipMemcpyHostToDevice));
+      g_keys.free_slots.push_back(fs[j]);
+    }
+    if (!bad_here.empty()) {
       for (size_t i : pending) {
-        auto bad = g_keys.invalid.find(key_id(qx + 4 * i, qy ? qy + 4 * i : nullptr));
-        if (bad != g_keys.invalid.end()) slots[i] = (g_keys.generation << SLOT_INDEX_BITS) | bad->second;
+        auto bad = bad_here.find(key_id(qx + 4 * i, qy ? qy + 4 * i : nullptr));
+        if (bad != bad_here.end()) slots[i] = (g_keys.generation << SLOT_INDEX_BITS) | bad->second;
       }
     }
   }
   return rc;
+}
+
+int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uint32_t* slots) {
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  ctx_lock lk(ctx().mu);
+  g_keys.external_handles = true;
+  return register_keys_locked(qx, qy, n, slots);
 }
 
 int sp_ecdsa_key_cache_info(size_t* capacity, size_t* used) {
@@ -1098,6 +1120,7 @@ int sp_ecdsa_key_cache_reset(void) {
   g_keys.slot_of.clear();
   g_keys.invalid.clear();
   g_keys.free_slots.clear();
+  g_keys.external_handles = false;  // every handle is stale from here on, the caller that resets knows it
   g_keys.used = g_keys.capacity ? FIRST_KEY_SLOT : 0;
   g_keys.generation = g_keys.generation % 255u + 1u;
   if (g_keys.capacity) {
@@ -1161,7 +1184,9 @@ static bool use_key_tables(const uint64_t* qx, const uint64_t* qy, size_t n) {
   if (!keyed) return false;
   if (fresh.size() + registered + FIRST_KEY_SLOT > g_keys.limit) return false;  // more keys in one batch than the cache holds
   if (g_keys.used - g_keys.free_slots.size() + fresh.size() > g_keys.limit) {
-    // full: evict everything (new generation) rather than leave the tables to the keys that came first
+    // full: evict everything (new generation) rather than leave the tables to the keys that came first -
+    // unless a caller holds handles of this generation (sp_ecdsa_register_keys): then the ladder serves the batch
+    if (g_keys.external_handles) return false;
     if (sp_ecdsa_key_cache_reset() != SP_OK) return false;
   }
   return true;
@@ -1184,11 +1209,13 @@ int sp_ecdsa_get_verify_policy(void) {
 }
 
 // Host-pointer verification through the key tables: registers the keys it has not seen, then runs
-// the comb kernel.
-int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint64_t* s,
-                                const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
-  SP_REQUIRE_READY();
-  if (n == 0) return SP_OK;
+// the comb kernel.  `policy`: the call comes from sp_ecdsa_verify_batch - the policy decision, the registration
+// and the launch happen under ONE hold of the context lock (round 3 dropped it between the decision and the
+// registration: another host thread could fill the cache or start a new generation in between and the batch
+// failed with SP_ERR_CACHE_FULL instead of running on the ladder); *fell_back is set when the policy chose the
+// ladder or the cache could not take the batch's keys after all, and nothing has been enqueued then.
+static int verify_batch_keyed_impl(const uint64_t* z, const uint64_t* r, const uint64_t* s, const uint64_t* qx,
+                                   const uint64_t* qy, uint8_t* result, size_t n, bool policy, bool* fell_back) {
   // The key cache lives on the primary context: take a host lane of that context.  The lock covers the
   // bookkeeping (registration of new keys, the launch against the current tables); the copies and the
   // kernel run on the lane's stream and the lock is NOT held while the caller waits for them.
@@ -1199,7 +1226,9 @@ int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint
   uint8_t* d_res = nullptr;
   {
     ctx_lock lk(ctx().mu);
-    int rc = sp_ecdsa_register_keys(qx, qy, n, slots.data());
+    if (policy && !use_key_tables(qx, qy, n)) { *fell_back = true; return SP_OK; }
+    int rc = policy ? register_keys_locked(qx, qy, n, slots.data()) : sp_ecdsa_register_keys(qx, qy, n, slots.data());
+    if (policy && rc == SP_ERR_CACHE_FULL) { *fell_back = true; return SP_OK; }  // (cannot happen under one lock; kept as the safe answer)
     if (rc != SP_OK) return rc;
     const uint64_t* host[3] = {z, r, s};
     uint64_t* dev[3];
@@ -1217,18 +1246,29 @@ int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint
   return SP_OK;
 }
 
+int sp_ecdsa_verify_batch_keyed(const uint64_t* z, const uint64_t* r, const uint64_t* s,
+                                const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
+  SP_REQUIRE_READY();
+  if (n == 0) return SP_OK;
+  bool unused = false;
+  return verify_batch_keyed_impl(z, r, s, qx, qy, result, n, false, &unused);
+}
+
 int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* s,
                           const uint64_t* qx, const uint64_t* qy, uint8_t* result, size_t n) {
   if (shard_context() < 0) {  // (a slice of a sharded batch: the policy has spoken for the whole batch)
     SP_REQUIRE_READY();
     if (n == 0) return SP_OK;
-    bool keyed;
+    bool ladder_forced;
     {
-      ctx_lock lk(ctx().mu);  // the policy reads the key cache: shared state (primary context), one caller at a time
-      keyed = use_key_tables(qx, qy, n);
+      ctx_lock lk(ctx().mu);
+      ladder_forced = g_verify_policy == SP_VERIFY_POLICY_LADDER;  // nothing remembered, no lane of context 0 taken
     }
-    // the lock is NOT held across the call: the keyed path takes it only to register keys and to enqueue
-    if (keyed) return sp_ecdsa_verify_batch_keyed(z, r, s, qx, qy, result, n);
+    if (!ladder_forced) {
+      bool fell_back = false;
+      const int rc = verify_batch_keyed_impl(z, r, s, qx, qy, result, n, true, &fell_back);
+      if (rc != SP_OK || !fell_back) return rc;
+    }
   }
   if (ctx_count() > 1 && shard_context() < 0 && n >= SHARD_MIN_ITEMS) {  // one slice per device, side by side
     return shard_over_contexts(n, [&](size_t off, size_t cnt) {

@@ -242,22 +242,27 @@ SP_HD void cols_sqr(cols& t, const fe& a) {
   }
 }
 
-// Montgomery reduction mod p: returns (T + q p) / 2^261 in N-form, value in (T/R, T/R + p).
+// Montgomery reduction mod p: returns (T - Q p) / 2^261 in N-form, value in (T/R - p, T/R].
+// Round 4: the SUBTRACTIVE form.  p = 1 (mod 2^29), so q_i = c_i mod 2^29 is one v_and_b32 and T - q_i p 2^(29 i)
+// clears limb i; what limb i hands on is (c_i - q_i) >> 29 = c_i >> 29 - no "c_i + q" to form first.  The additive
+// form of rounds 1 - 3 (q = -c_i, carry = (c_i + q) >> 29) paid a v_sub and a third multiply-add per limb for the
+// same thing: 174 -> 156 VALU instructions per fe_mul, 144 -> 126 per fe_sqr (tools/ubench/valu_rate.hip: a
+// v_mad_i64_i32 costs 4.5 - 4.9 cycles of issue, a 32-bit and / sub 2.3 - 2.7).
 SP_HD fe fe_reduce(cols& t) {
-  // On the device q * 2^19 is issued as ONE v_mad_u64_u32 (q, 2^19 in an SGPR, accumulator) instead
-  // of the shift + 64-bit add the compiler derives from a visible power of two.
-  uint32_t p8 = (uint32_t)P8, one = 1u;
+  int32_t np6 = -P6, np8 = -P8;
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+s"(p8), "+s"(one));  // keep both as SGPR multiplicands (q * 1 + c_i is one mad)
+  // both stay SGPR multiplicands of a v_mad_i64_i32: from a visible -2^19 the compiler derives a 64-bit shift
+  // and a 64-bit subtraction (two instructions at the issue cost of a multiply-add each)
+  asm volatile("" : "+s"(np6), "+s"(np8));
 #endif
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    const uint32_t q = (0u - (uint32_t)t.c[i]) & LMASK;  // p = 1 mod 2^29  =>  q = -c_i
-    t.c[i + 1] += (int64_t)((uint64_t)q * (uint64_t)one + (uint64_t)t.c[i]) >> LB;  // exact: low 29 bits are zero
-    SP_CHK64((__int128)t.c[i + 6] + (__int128)q * P6);
-    t.c[i + 6] += (int64_t)q * (int64_t)P6;
-    SP_CHK64((__int128)t.c[i + 8] + ((__int128)q << 19));
-    t.c[i + 8] += (int64_t)((uint64_t)q * (uint64_t)p8);  // P8 = 2^19; i + 8 <= 16
+    const int32_t q = (int32_t)((uint32_t)t.c[i] & LMASK);
+    t.c[i + 1] += t.c[i] >> LB;  // arithmetic shift = floor: exactly (c_i - q) / 2^29
+    SP_CHK64((__int128)t.c[i + 6] - (__int128)q * P6);
+    t.c[i + 6] += (int64_t)q * (int64_t)np6;
+    SP_CHK64((__int128)t.c[i + 8] - ((__int128)q << 19));
+    t.c[i + 8] += (int64_t)q * (int64_t)np8;  // i + 8 <= 16
   }
   fe r;
   int64_t carry = 0;
@@ -666,6 +671,12 @@ SP_HD void lehmer_step(double& a, double& ua, double& va, const double b, const 
                        const bool live) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const double rc = __builtin_amdgcn_rcp(b);
+#elif defined(SP_LEHMER_RCP_ERROR)
+  // host tests: a reciprocal that is deliberately worse than anything v_rcp_f64 delivers (relative error
+  // sp_lehmer_rcp_error, sign alternating) - the quotients go wrong more often, the result must not
+  extern double sp_lehmer_rcp_error;
+  static thread_local int flip__ = 0;
+  const double rc = (1.0 / b) * (1.0 + ((flip__++ & 1) ? sp_lehmer_rcp_error : -sp_lehmer_rcp_error));
 #else
   const double rc = 1.0 / b;
 #endif
@@ -732,12 +743,20 @@ SP_HD fe lehmer_finish(const fe& d, int32_t sf) {
 // [0, 2^29) and |x| < 16 modulus (reduced or not: A E - B D = +-modulus holds from the start, so |D| < 2 modulus
 // whatever the size of x).  On return (true) D sign = x^-1 (mod modulus), sign = sf ? -1 : +1, and D = 0 when
 // x is a multiple of the modulus.  false: some value of the wave needs the divsteps form.
+constexpr int LEHMER_MAX_BATCHES = 24;  // ~10 on average, ~13 at most on random 252-bit input; 22 by the worst-case bound
+#if defined(SP_LEHMER_RCP_ERROR)
+extern int sp_lehmer_batches;      // host tests: batches the last lehmer_bezout calls ran (reset by the test)
+extern int sp_lehmer_max_batches;  // host tests: a smaller budget than LEHMER_MAX_BATCHES, to run out of it on purpose
+#define SP_LEHMER_BUDGET sp_lehmer_max_batches
+#else
+#define SP_LEHMER_BUDGET LEHMER_MAX_BATCHES
+#endif
 SP_HD bool lehmer_bezout(const fe& modulus, const fe& x, fe& D, int32_t& sf) {
   fe A = modulus, B = x, E = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
   D = FE_ZERO;
   double ad = 0.0;
   bool ok = true;
-  for (int it = 0; it < 24; ++it) {
+  for (int it = 0; it < SP_LEHMER_BUDGET; ++it) {
     ad = lehmer_to_double(A);
     const double bd = lehmer_to_double(B);
     lehmer_rows m;
@@ -753,7 +772,15 @@ SP_HD bool lehmer_bezout(const fe& modulus, const fe& x, fe& D, int32_t& sf) {
     const fe A2 = lehmer_row(A, B, ua, va), B2 = lehmer_row(A, B, ub, vb);
     const fe D2 = lehmer_row(D, E, ua, va), E2 = lehmer_row(D, E, ub, vb);
     A = A2; B = B2; D = D2; E = E2;
+#if defined(SP_LEHMER_RCP_ERROR)
+    ++sp_lehmer_batches;
+#endif
   }
+  // Out of batches with a remainder left (worst case ~22 of the 24 for 252-bit inputs, and the
+  // device's bare v_rcp_f64 loses a little progress per wrong quotient): NOT converged - the caller redoes the
+  // value with the divsteps form instead of reading a stale A.  A is re-read: the loop leaves `ad` one batch old.
+  ok &= lehmer_to_double(B) == 0.0;
+  ad = lehmer_to_double(A);
   sf = ad < 0.0 ? -1 : 0;  // A = +-1 - or +-modulus for a multiple of the modulus (reduced or not): answer 0
   if (__builtin_fabs(ad) != 1.0) D = FE_ZERO;
 #if defined(__HIP_DEVICE_COMPILE__)

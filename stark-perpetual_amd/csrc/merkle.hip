@@ -770,7 +770,10 @@ int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t
   if (chain_status != 0) {  // a word out of range / an unhashable pair: nothing else runs
     if (tree_status) *tree_status = chain_status;
     for (size_t i = 0; i < n; ++i) verdicts[i] = 0;
-    return sp_tree_root(tree, old_root) == SP_OK ? (std::memcpy(new_root, old_root, 32), SP_OK) : SP_ERR_BAD_ARGUMENT;
+    rc = sp_tree_root(tree, old_root);  // its own code and error text (a bad handle is not a HIP failure and v.v.)
+    if (rc != SP_OK) return rc;
+    std::memcpy(new_root, old_root, 32);
+    return SP_OK;
   }
   // A message hash of 2^251 or more is not a signed message (constants.cairo:57 SIGNED_MESSAGE_BOUND,
   // order.cairo:22; signature.py:227 asserts the same bound): its order id would not fit the 64-bit field, so
@@ -820,6 +823,8 @@ int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t
       rc = tree_update_locked(*ts.t, keys.data(), sorted_leaves.data(), n, old_root, new_root, tree_status, &all_verified);
   }
   if (!joined) verifier.join();
+  // the error text is process-wide (set_error), so what the verifier thread reported is what sp_last_error says;
+  // when both legs failed the tree's code wins and the text is whichever leg failed last
   if (rc != SP_OK) return rc;
   return vrc;
 }

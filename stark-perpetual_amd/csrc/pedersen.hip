@@ -861,7 +861,18 @@ int get_scratch_public(size_t n, Scratch& s, hipStream_t st) {
 }
 
 static size_t g_finish_lanes = getenv("STARKPERP_FINISH_LANES") ? (size_t)atoll(getenv("STARKPERP_FINISH_LANES")) : 65536;
-static size_t g_split_lanes = getenv("STARKPERP_SPLIT_LANES") ? (size_t)atoll(getenv("STARKPERP_SPLIT_LANES")) : 65536;
+// Lanes one round of the chip holds (a development knob).  The level plan cuts a level into n_bulk = a multiple of
+// this many hashes for the one-lane-per-hash body, and ped_accumulate_mixed_kernel hands them out in blocks of 256:
+// a value that is not a multiple of 256 would leave up to 255 hashes per level uncomputed, so the
+// environment value is rounded up to one and kept inside [256, 2^24].
+static size_t parse_split_lanes() {
+  const char* e = getenv("STARKPERP_SPLIT_LANES");
+  long long v = e ? atoll(e) : 65536;
+  if (v < 256) v = 256;
+  if (v > (1ll << 24)) v = 1ll << 24;
+  return ((size_t)v + 255) & ~(size_t)255;
+}
+static size_t g_split_lanes = parse_split_lanes();
 static size_t finish_threads(size_t n) {
   // K hashes share one inversion (Montgomery's trick, 3 multiplications per extra hash).  The
   // inversion is a ~14 k-instruction dependent chain of mostly 32-bit ops, and a SIMD is already

@@ -209,7 +209,7 @@ __device__ __forceinline__ fe fe_inv_plain_quad(const fe& x, int k) {
   fe own = k == 0 ? FE_P : (k == 1 ? x : (k == 2 ? FE_ZERO : one));  // A | B | D | E
   double ad = 0.0;
   bool ok = true;
-  for (int it = 0; it < 24; ++it) {
+  for (int it = 0; it < LEHMER_MAX_BATCHES; ++it) {
     const double od = lehmer_to_double(own);
     ad = f64_dpp<quad_perm(0, 0, 0, 0)>(od);
     const double bd = f64_dpp<quad_perm(1, 1, 1, 1)>(od);
@@ -220,6 +220,13 @@ __device__ __forceinline__ fe fe_inv_plain_quad(const fe& x, int k) {
     const double co = odd ? lehmer_flip(m.vb, bd) : lehmer_flip(m.ua, ad);
     const double cp = odd ? lehmer_flip(m.ub, ad) : lehmer_flip(m.va, bd);
     own = lehmer_row(own, fe_dpp<quad_perm(1, 0, 3, 2)>(own), (int32_t)co, (int32_t)cp);
+  }
+  {
+    // out of batches with a remainder left = not converged (fallback below); A is re-read, the loop leaves `ad`
+    // one batch old
+    const double od = lehmer_to_double(own);
+    ad = f64_dpp<quad_perm(0, 0, 0, 0)>(od);
+    ok &= f64_dpp<quad_perm(1, 1, 1, 1)>(od) == 0.0;
   }
   if (__any(!ok)) {  // a partial quotient above 2^27 somewhere in the wave: the divsteps form wants [0, p)
     return fe_inv_plain_quad_divsteps(fe_canon(fe_mul(x, FE_ONE_M)), k);  // x * R / R: the value, reduced

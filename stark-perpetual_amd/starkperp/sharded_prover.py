@@ -305,6 +305,16 @@ def commit_job(ops, dist, trace_cols, alphas: Sequence[int], betas: Sequence[int
                 sent += (world - 1) * (layer.shape[0] >> log_block) * 32
             else:
                 roots.append(ops.commit_root(layer.unsqueeze(0)))
+    if sharded:
+        # A final layer that is still sharded (a caller-chosen final_log with 2^final_log >= world * B: the loop
+        # ended before the one-block-per-rank gather; ADVICE r3 - round 3 returned this rank's slice as "the" final
+        # layer).  Every rank holds blocks r, r + N, r + 2 N, ...: gather and put them back in natural order.
+        ops.sync()
+        nb = layer.shape[0] >> log_block
+        sent += (world - 1) * layer.shape[0] * 32
+        allr = _all_gather_rows(dist, torch, layer, world)                  # [world * nb * B, 4], rank-major
+        layer = allr.view(world, nb, B, 4).transpose(0, 1).reshape(world * nb * B, 4).contiguous()
+        sharded = False
     final = ops.to_ints(layer)
     if stats is not None:
         stats.update({"bytes_sent_by_this_rank": sent, "log_block": log_block, "blocks_per_rank": nb_loc,

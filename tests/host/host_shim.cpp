@@ -6,6 +6,25 @@
 #include <string.h>
 using namespace sp;
 
+#if defined(SP_LEHMER_RCP_ERROR)
+// second build of this shim (tests/test_field_host.py::test_lehmer_with_an_imprecise_reciprocal): the Euclid steps
+// are steered by a reciprocal with a chosen relative error, and the batches of every inversion are counted
+namespace sp {
+double sp_lehmer_rcp_error = 0x1p-24;
+int sp_lehmer_batches = 0;
+int sp_lehmer_max_batches = LEHMER_MAX_BATCHES;
+}
+extern "C" void t_set_lehmer_budget(int n) { sp::sp_lehmer_max_batches = n; }
+extern "C" void t_set_rcp_error(double e) { sp::sp_lehmer_rcp_error = e; }
+extern "C" int t_take_lehmer_batches() { const int v = sp::sp_lehmer_batches; sp::sp_lehmer_batches = 0; return v; }
+// 1: the double-steered form converged and answered; 0: it asked for the divsteps fallback
+extern "C" int t_lehmer_bezout_ok(const uint32_t* a) {
+  u256 w; memcpy(w.w, a, 32);
+  fe D; int32_t sf;
+  return lehmer_bezout(FE_P, fe_unpack(w), D, sf) ? 1 : 0;
+}
+#endif
+
 static fe load_plain(const uint32_t* w) { u256 a; memcpy(a.w, w, 32); return fe_unpack(a); }
 static void store_plain(const fe& canon, uint32_t* w) { u256 r = fe_pack(canon); memcpy(w, r.w, 32); }
 static fe to_m(const uint32_t* w) { return fe_to_mont(load_plain(w)); }

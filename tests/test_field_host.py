@@ -310,6 +310,47 @@ def test_fe_inv_lehmer(shim):
     assert shim.t_lehmer_batch(W(12345), W(0), rows) == 1 and list(rows) == [1.0, 0.0, 0.0, 1.0]
 
 
+def test_lehmer_with_an_imprecise_reciprocal(tmp_path):
+    """the device steers Euclid with the bare v_rcp_f64, the host tests with an exact 1.0 / b.  Second
+    build of the shim whose reciprocal carries a chosen relative error (alternating sign): every result stays
+    exact (a wrong quotient costs progress only; SP_CHECK_BOUNDS watches the cofactors), the batch count stays
+    inside the 24 of the loop for errors far beyond the instruction's (2^-24 ... 2^-12), and a value that does run
+    out of batches is REPORTED (divsteps fallback), not answered from a stale remainder."""
+    so = str(tmp_path / "host_shim_rcp.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-DSP_LEHMER_RCP_ERROR=1", "-o", so,
+                           os.path.join(HERE, "host", "host_shim.cpp")])
+    lib = ctypes.CDLL(so)
+    lib.t_set_rcp_error.argtypes = [ctypes.c_double]
+    rng = random.Random(12)
+    out = (ctypes.c_uint32 * 8)()
+    vals = [rng.randrange(1, P) for _ in range(1500)] + [P // k + 1 for k in range(2, 60)] + \
+        [rng.randrange(1, 2**k) for k in (64, 128, 200, 251) for _ in range(50)] + [P - 1, P - 2, (P + 1) // 2]
+    worst = {}
+    for err in (0.0, 2.0**-40, 2.0**-24, 2.0**-20, 2.0**-12, 2.0**-3):
+        lib.t_set_rcp_error(err)
+        lib.t_take_lehmer_batches()
+        most = 0
+        for a in vals:
+            lib.t_fe_inv_plain_lehmer(W(a), out)
+            assert I(out) == pow(a, -1, P), (hex(a), err)
+            most = max(most, lib.t_take_lehmer_batches())
+        worst[err] = most
+    assert worst[0.0] <= 13 and worst[2.0**-24] <= 14 and worst[2.0**-12] <= 24, worst
+    print("lehmer batches at most, by reciprocal error:", worst)
+    # running out of batches on purpose (a budget of 8 where a 252-bit inversion needs ~10): the value is REPORTED
+    # as not converged - round 3 answered 0 from a stale remainder - and the public form takes the divsteps path
+    lib.t_set_rcp_error(2.0**-24)
+    lib.t_set_lehmer_budget(8)
+    reported = 0
+    for a in vals[:300]:
+        reported += 1 - lib.t_lehmer_bezout_ok(W(a))
+        lib.t_fe_inv_plain_lehmer(W(a), out)
+        assert I(out) == pow(a, -1, P), hex(a)
+    assert reported > 200, reported
+    lib.t_set_lehmer_budget(24)
+    assert all(lib.t_lehmer_bezout_ok(W(a)) == 1 for a in vals[:300])
+
+
 def test_extreme_limb_patterns_keep_every_bound(shim):
     """Every pair of the extreme-limb-pattern felts (tests/workloads.py extreme_felts: all-ones limbs, p - small,
     2^k at the limb boundaries) through the bound-checked build of the multiplier, the lazy expression and the XYZZ

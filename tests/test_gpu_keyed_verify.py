@@ -262,11 +262,35 @@ batch.set_verify_policy(batch.VERIFY_POLICY_KEYED)
 rs, ss = [r for r, _ in sigs], [s for _, s in sigs]
 assert batch.verify_codes(zs[:3], rs[:3], ss[:3], keys[:3]) == [1, 1, 1]
 assert batch.key_cache_info() == (4, 3)
-old_handles = batch.register_keys(keys[:3])
 assert batch.verify_codes(zs[3:], rs[3:], ss[3:], keys[3:]) == [1, 1, 1]   # 3 + 3 > 4: rolled
 assert batch.key_cache_info() == (4, 3)
-assert batch.register_keys(keys[3:]) != old_handles                         # a new generation
-assert batch.verify_codes(zs[:3], rs[:3], ss[:3], keys[:3]) == [1, 1, 1]   # and again
+# ... but never behind handles a caller holds (ADVICE r3): after an explicit registration the policy serves a
+# batch that does not fit from the ladder and the handles stay good
+handles = batch.register_keys(keys[3:])
+assert batch.verify_codes(zs[:3], rs[:3], ss[:3], keys[:3]) == [1, 1, 1]
+assert batch.key_cache_info() == (4, 3)
+assert batch.register_keys(keys[3:]) == handles
+assert batch.verify_codes(zs[3:], rs[3:], ss[3:], keys[3:], key_tables=True) == [1, 1, 1]
+# host threads racing for a 4-slot cache through the policy path: the decision, the registration and the launch
+# are one locked section, so no call may fail or see a stale slot whatever the interleaving
+batch.key_cache_reset()
+import threading
+errors = []
+def worker(t):
+    try:
+        for rep in range(12):
+            lo = (t + rep) % 4
+            idx = [lo, lo + 1, lo + 2]
+            got = batch.verify_codes([zs[i] for i in idx], [rs[i] for i in idx], [ss[i] for i in idx],
+                                     [keys[i] for i in idx])
+            if got != [1, 1, 1]:
+                errors.append((t, rep, got))
+    except Exception as e:  # noqa: BLE001
+        errors.append((t, repr(e)))
+threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+[t.start() for t in threads]
+[t.join() for t in threads]
+assert not errors, errors[:3]
 print("ok")
 ''' % (root, os.path.join(root, "stark-perpetual_amd"))
     env = dict(os.environ, STARKPERP_KEY_CACHE_SLOTS="4", STARKPERP_WINDOW_BITS="16")

@@ -1,0 +1,126 @@
+"""Program-hash harness twin (reference starkware/cairo/bootloaders/program_hash_test_utils.py:7-33,
+call site services/perpetual/cairo/program_hash_test.py:15-21).  The chain shape is a restatement of public
+cairo-lang behaviour - PARITY UNPINNED (no cairo-lang, no compiled program in the reference tree); every link is the
+pinned Pedersen hash.  CPU tests inject the oracle's hash through the `hash_func=` seam; the GPU test folds a
+12 000-word synthetic program in one launch and compares with the C oracle link by link."""
+import json
+import os
+import random
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "stark-perpetual_amd"))
+from oracle import ref_py as R  # noqa: E402
+
+PRIME_HEX = hex(R.FIELD_PRIME)
+
+
+def synthetic_program(n_words, seed, builtins=("output", "pedersen", "range_check", "ecdsa"), main=17):
+    rnd = random.Random(seed)
+    data = [rnd.randrange(R.FIELD_PRIME) for _ in range(n_words)]
+    data[0], data[-1] = 0, R.FIELD_PRIME - 1  # edge words
+    return {
+        "prime": PRIME_HEX,
+        "data": [hex(w) for w in data],
+        "builtins": list(builtins),
+        "main_scope": "__main__",
+        "identifiers": {"__main__.main": {"pc": main, "type": "function", "decorators": []},
+                        "__main__.other": {"pc": 3, "type": "function"}},
+        "hints": {}, "reference_manager": {"references": []}, "attributes": [], "debug_info": None,
+        "compiler_version": "0.0.0+local",
+    }, data
+
+
+def oracle_chain(words, hash2):
+    acc = words[-1]
+    for w in reversed(words[:-1]):
+        acc = hash2(w, acc)
+    return acc
+
+
+def expected_words(data, builtins, main, version=0):
+    rest = [version, main, len(builtins)] + [int.from_bytes(b.encode("ascii"), "big") for b in builtins] + data
+    return [len(rest)] + rest
+
+
+def test_loader_and_chain_words(tmp_path):
+    from starkperp import program_hash as ph
+    obj, data = synthetic_program(40, seed=1)
+    prog = ph.CompiledProgram.load(obj)
+    assert prog.prime == R.FIELD_PRIME == ph.CAIRO_PRIME and prog.main == 17 and prog.data == data
+    assert ph.builtin_words(["pedersen"]) == [0x706564657273656E]
+    assert ph.program_chain_words(prog) == expected_words(data, prog.builtins, 17)
+    assert ph.program_chain_words(prog, bootloader_version=2)[1] == 2
+    # what the loader refuses
+    for key in ("prime", "data", "builtins", "identifiers"):
+        bad = dict(obj)
+        del bad[key]
+        with pytest.raises(ValueError):
+            ph.CompiledProgram.load(bad)
+    with pytest.raises(ValueError):
+        ph.CompiledProgram.load(dict(obj, prime=hex(2**251 + 1)))
+    with pytest.raises(ValueError):
+        ph.CompiledProgram.load(dict(obj, data=[hex(R.FIELD_PRIME)]))
+    with pytest.raises(ValueError):
+        ph.CompiledProgram.load(dict(obj, identifiers={}))
+    with pytest.raises(ValueError):
+        ph.CompiledProgram.load(dict(obj, builtins=["péd"]))
+
+
+def test_harness_with_the_oracle_hash_injected(tmp_path):
+    """run_generate_hash_test end to end on the CPU: --fix writes the reference's file layout, the check passes on
+    it and fails with the reference's text on another program."""
+    from starkperp import program_hash as ph
+    from starkware.cairo.bootloaders import program_hash_test_utils as overlay
+    from starkware.cairo.bootloaders.hash_program import compute_program_hash_chain
+    assert overlay.run_generate_hash_test is ph.run_generate_hash_test
+    assert overlay.program_hash_test_main is ph.program_hash_test_main
+    H = R.pedersen_hash
+    obj, data = synthetic_program(12, seed=2)
+    program_path, hash_path = str(tmp_path / "compiled.json"), str(tmp_path / "program_hash.json")
+    json.dump(obj, open(program_path, "w"))
+    want = oracle_chain(expected_words(data, obj["builtins"], 17), H)
+    assert compute_program_hash_chain(ph.CompiledProgram.load(obj), hash_func=H) == want
+    ph.run_generate_hash_test(True, program_path, hash_path, "generate_x", hash_func=H)
+    assert open(hash_path).read() == '{\n    "program_hash": "%s"\n}\n' % hex(want)  # program_hash_test_utils.py:14-15
+    ph.run_generate_hash_test(False, program_path, hash_path, "generate_x", hash_func=H)
+    obj2, _ = synthetic_program(12, seed=3)
+    json.dump(obj2, open(program_path, "w"))
+    found = hex(compute_program_hash_chain(ph.CompiledProgram.load(obj2), hash_func=H))
+    with pytest.raises(AssertionError) as err:
+        ph.run_generate_hash_test(False, program_path, hash_path, "generate_x", hash_func=H)
+    assert str(err.value) == ("Wrong program hash in program_hash.json. Found: %s. Expected: %s. "
+                              "Please run generate_x." % (found, hex(want)))
+    # the reference's stored hash file parses with the same key
+    ref = {"program_hash": "0x1b40021cbe547dc19f55932fb9e92bd930917978c6b82cfe2cc1516e47407b2"}
+    json.dump(ref, open(hash_path, "w"))
+    with pytest.raises(AssertionError):
+        ph.run_generate_hash_test(False, program_path, hash_path, "generate_perpetual_cairo_program_hash", hash_func=H)
+    with pytest.raises(AssertionError):
+        ph.compute_hash_chain([], hash_func=H)
+
+
+@pytest.mark.gpu
+def test_program_hash_on_gpu_matches_c_oracle(tmp_path):
+    """A 12 000-word program (the size class of perpetual_cairo_compiled.json) through the harness on the GPU -
+    one sp_pedersen_chain_right call - against the C oracle's fold, plus --fix / check / mismatch through main()."""
+    from oracle import cref
+    from starkperp import program_hash as ph
+    obj, data = synthetic_program(12000, seed=4)
+    program_path, hash_path = str(tmp_path / "compiled.json"), str(tmp_path / "program_hash.json")
+    json.dump(obj, open(program_path, "w"))
+    words = expected_words(data, obj["builtins"], 17)
+    acc = words[-1]
+    for w in reversed(words[:-1]):
+        acc = cref.pedersen_hash_many([w], [acc])[0]
+    ph.program_hash_test_main(program_path, hash_path, "generate_x", argv=["--fix"])
+    assert json.load(open(hash_path)) == {"program_hash": hex(acc)}
+    ph.program_hash_test_main(program_path, hash_path, "generate_x", argv=[])
+    json.dump({"program_hash": hex(acc ^ 1)}, open(hash_path, "w"))
+    with pytest.raises(AssertionError, match="Wrong program hash in program_hash.json. Found: %s" % hex(acc)):
+        ph.program_hash_test_main(program_path, hash_path, "generate_x", argv=[])
+    # the injected-hash path and the one-launch path agree on a short program
+    small, sdata = synthetic_program(6, seed=5, builtins=("pedersen",))
+    prog = ph.CompiledProgram.load(small)
+    assert ph.compute_program_hash_chain(prog) == ph.compute_program_hash_chain(prog, hash_func=R.pedersen_hash)

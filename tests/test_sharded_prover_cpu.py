@@ -16,7 +16,7 @@ import oracle_ops as O
 P = O.P
 
 
-def _worker(rank, world, port, n_hashes, log_block, q):
+def _worker(rank, world, port, n_hashes, log_block, q, final_log=6):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -26,12 +26,13 @@ def _worker(rank, world, port, n_hashes, log_block, q):
     inputs = [(rng.randrange(P), rng.randrange(P)) for _ in range(n_hashes)]
     alphas = [rng.randrange(P) for _ in range(O.S.N_CONSTRAINTS)]
     log_lde = (512 * n_hashes).bit_length() - 1 + 2
-    betas = [rng.randrange(P) for _ in range(log_lde - 6)]
-    trace, want_roots, want_final = O.single_process_job(inputs, alphas, betas) if rank == 0 else (None, None, None)
+    betas = [rng.randrange(P) for _ in range(log_lde - final_log)]
+    trace, want_roots, want_final = O.single_process_job(inputs, alphas, betas, final_log) if rank == 0 else (None, None, None)
     trace = O.S.pedersen_trace(inputs) if trace is None else trace
     cols = torch.stack([O.to_tensor(c) for c in trace])
     stats = {}
-    roots, final = SP.commit_job(O.OracleOps(), dist, cols, alphas, betas, log_block=log_block, stats=stats)
+    roots, final = SP.commit_job(O.OracleOps(), dist, cols, alphas, betas, final_log=final_log, log_block=log_block,
+                                stats=stats)
     # every rank must end with the same roots; rank 0 also holds the single-process answer
     gathered = [None] * world
     dist.all_gather_object(gathered, (roots, final, stats))
@@ -67,6 +68,23 @@ def test_sharded_job_equals_single_process_job(world, n_hashes, log_block):
     for p in procs:
         p.join(timeout=60)
     n_roots = 2 + ((512 * n_hashes).bit_length() - 1 + 2 - 7)
+    assert sorted(results) == [(r, True, n_roots) for r in range(world)]
+
+
+def test_final_layer_that_is_still_sharded_is_gathered():
+    """final_log chosen so that 2^final_log >= world * B: the fold loop ends while the layer is block-cyclic; every
+    rank must still return the WHOLE final layer in natural order, equal to the single-process one."""
+    world, n_hashes, log_block, final_log = 2, 2, 4, 7   # world * B = 32 positions, final layer 128
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000) + 977
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_hashes, log_block, q, final_log)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    n_roots = 2 + ((512 * n_hashes).bit_length() - 1 + 2 - final_log - 1)
     assert sorted(results) == [(r, True, n_roots) for r in range(world)]
 
 

@@ -10,7 +10,7 @@
 #include <vector>
 #include <algorithm>
 
-#define ITERS 2048
+#define ITERS 8192
 
 struct Stamp { unsigned long long c0, c1, r0, r1; };
 
@@ -54,6 +54,32 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, Stamp* stamps, uint32_t 
       }
       if (OP == 25) asm volatile("v_bfe_i32 %0, %0, 0, 29" : "+v"(r[c]));
       if (OP == 26) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(r[c]) : "v"(a));
+      if (OP == 27) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(r[c]) : "v"(a));
+      if (OP == 28) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(r[c]));
+      if (OP == 29) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(r[c]));
+      if (OP == 30) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(r[c]) : "v"(a));
+      if (OP == 31) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[c]) : "v"(a));
+      if (OP == 32) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(r[c]) : "v"(a));
+      if (OP == 33) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[c]) : "v"(a) : "vcc");
+      if (OP == 34) asm volatile("v_mov_b64 %0, %1" : "+v"(acc[c]) : "v"(pk));
+      if (OP == 35) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(acc[c]));
+      if (OP == 36) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(r[c]));
+      if (OP == 37) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[c]));
+      if (OP == 38) asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(r[c]) : "v"(a) : "vcc");
+      if (OP == 39) asm volatile("v_cvt_f64_i32 %0, %1" : "+v"(d[c]) : "v"(a));
+      if (OP == 40) asm volatile("v_rndne_f64 %0, %0" : "+v"(d[c]));
+      if (OP == 41) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[c]));
+      if (OP == 42) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[c]) : "v"(da));
+      if (OP == 43) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[c]) : "v"(da));
+      if (OP == 44) asm volatile("v_cvt_i32_f64 %0, %1" : "+v"(r[c]) : "v"(da));
+      if (OP == 45) asm volatile("v_cmp_ne_u32 vcc, %0, %1" : : "v"(r[c]), "v"(a) : "vcc");
+      if (OP == 46) {  // the reduction step of fe_reduce (round 4): and, 64-bit shift, 64-bit add, two multiply-adds
+        asm volatile("v_and_b32 %0, %1, %2" : "=v"(r[c]) : "v"((uint32_t)acc[c]), "v"(a));
+        asm volatile("v_ashrrev_i64 %0, 29, %1" : "=v"(acc[c]) : "v"(acc[(c + 1) % CHAINS]));
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[(c + 2) % CHAINS]) : "v"(acc[c]));
+        asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[(c + 3) % CHAINS]) : "v"(r[c]), "v"(b) : "vcc");
+        asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[(c + 4) % CHAINS]) : "v"(r[c]), "v"(a) : "vcc");
+      }
     }
   }
   unsigned long long c1 = __builtin_readcyclecounter();
@@ -102,10 +128,13 @@ void run(const char* name, int waves_per_simd, int per_instr = 1) {
   double med_cyc = cyc[nwaves / 2], med_mhz = mhz[nwaves / 2];
   // cross-check with events: wall time per launch * measured clock
   double ev_cyc = ms * 1e-3 / REPS * med_mhz * 1e6;
-  printf("%-26s chains=%2d waves/SIMD=%d  %7.3f ms/launch  clock %6.0f MHz  "
-         "%5.2f cyc/instr/SIMD (in-wave counter, median)  %5.2f (events x measured clock)  %5.2f (events x 2.4 GHz)\n",
-         name, CHAINS, waves_per_simd, ms / REPS, med_mhz, med_cyc / instr_per_simd_per_launch,
-         ev_cyc / instr_per_simd_per_launch, ms * 1e-3 / REPS * 2.4e9 / instr_per_simd_per_launch);
+  // PRIMARY figure: launch duration from HIP events x the clock the waves measured, per instruction a SIMD issued.
+  // The in-wave span is printed next to it: when it is much smaller, the waves of a SIMD did not run side by side
+  // for the whole launch (oldest-first arbitration lets the first waves finish early).
+  printf("%-28s chains=%2d waves/SIMD=%d  %7.3f ms/launch  clock %4.0f MHz  %5.2f cycles/instr/SIMD   "
+         "(in-wave median span %5.2f, at nominal 2.4 GHz %5.2f)\n",
+         name, CHAINS, waves_per_simd, ms / REPS, med_mhz, ev_cyc / instr_per_simd_per_launch,
+         med_cyc / instr_per_simd_per_launch, ms * 1e-3 / REPS * 2.4e9 / instr_per_simd_per_launch);
   hipFree(out);
   hipFree(stamps);
 }
@@ -134,6 +163,26 @@ void sweep(int w) {
   run<20, CHAINS>("v_pk_fma_f32", w);
   run<3, CHAINS>("v_fma_f64", w);
   run<24, CHAINS>("mad_i64_i32 + and_b32 pair", w, 2);
+  run<46, CHAINS>("fe_reduce step (5 instr)", w, 5);
+  run<27, CHAINS>("v_sub_u32", w);
+  run<31, CHAINS>("v_xor_b32", w);
+  run<28, CHAINS>("v_lshlrev_b32", w);
+  run<29, CHAINS>("v_ashrrev_i32", w);
+  run<30, CHAINS>("v_lshl_add_u32", w);
+  run<32, CHAINS>("v_lshl_or_b32", w);
+  run<36, CHAINS>("v_bfe_u32", w);
+  run<33, CHAINS>("v_cndmask_b32 (vcc)", w);
+  run<45, CHAINS>("v_cmp_ne_u32", w);
+  run<38, CHAINS>("v_sub_co_u32", w);
+  run<34, CHAINS>("v_mov_b64", w);
+  run<35, CHAINS>("v_lshrrev_b64", w);
+  run<37, CHAINS>("v_mov_b32 dpp quad_perm", w);
+  run<39, CHAINS>("v_cvt_f64_i32", w);
+  run<44, CHAINS>("v_cvt_i32_f64", w);
+  run<40, CHAINS>("v_rndne_f64", w);
+  run<41, CHAINS>("v_rcp_f64", w);
+  run<42, CHAINS>("v_mul_f64", w);
+  run<43, CHAINS>("v_add_f64", w);
 }
 
 int main(int argc, char** argv) {
@@ -141,9 +190,9 @@ int main(int argc, char** argv) {
   hipDeviceProp_t p;
   hipGetDeviceProperties(&p, dev);
   printf("# %s, %d CUs, clockRate %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
-  for (int w : {1, 2, 3, 4, 6, 8}) {
-    sweep<8>(w);
-    sweep<16>(w);
-  }
+  // 16 chains: no instruction waits for its own result (8 chains measured the same from 2 waves per SIMD on)
+  for (int w : {1, 2, 4, 6, 8}) sweep<16>(w);
+  sweep<8>(1);
+  sweep<8>(2);
   return 0;
 }
