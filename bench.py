@@ -292,13 +292,32 @@ def combine_check(slot, world, _lib):
         return None
 
 
-VALU_PEAK_SIMDS, VALU_NOMINAL_GHZ, VALU_CYCLES_PER_INSTR = 1024, 2.4, 4.0
+VALU_PEAK_SIMDS, VALU_NOMINAL_GHZ = 1024, 2.4
+VALU_ISSUE_FILES = ("r04_valu_issue.json", "r03_valu_issue.json", "r02_valu_issue.json", "r01_valu_issue.json")
+
+
+def _valu_issue_file():
+    for name in VALU_ISSUE_FILES:
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name))), name
+        except Exception:
+            continue
+    return {}, None
+
+
+def valu_cycles_per_instr():
+    """Issue interval of the bulk hash kernel's instruction MIX in shader cycles per wave64 instruction per SIMD:
+    every opcode of the kernel priced at the best interval tools/ubench/valu_rate.hip measured for it at any
+    occupancy (profiles/r04_valu_rate_ubench.txt), weighted by the kernel's static histogram (tools/valu_mix.py).
+    4.04 for ped_accumulate_kernel; rounds 1 - 3 used a flat 4."""
+    m, _ = _valu_issue_file()
+    return float(m.get("cycles_per_wave64_valu_instr", 4.0))
 
 
 def _valu_counts(window_bits):
     """SQ_INSTS_VALU per hash of the bulk kernels (rocprofv3 --pmc, profiles/r0N_valu_issue.json, newest
     first); None when there is no measurement for this window width."""
-    for name in ("r03_valu_issue.json", "r02_valu_issue.json", "r01_valu_issue.json"):
+    for name in VALU_ISSUE_FILES:
         try:
             m = json.load(open(os.path.join(ROOT, "profiles", name)))
             w = m["window_bits"][str(window_bits)]
@@ -309,18 +328,22 @@ def _valu_counts(window_bits):
 
 
 def valu_peak():
-    return VALU_PEAK_SIMDS * VALU_NOMINAL_GHZ * 1e9 / VALU_CYCLES_PER_INSTR
+    return VALU_PEAK_SIMDS * VALU_NOMINAL_GHZ * 1e9 / valu_cycles_per_instr()
 
 
-VALU_PEAK_NOTE = ("peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 integer VALU instruction: the issue interval "
-                  "measured on this chip (profiles/r01_valu_rate_ubench.txt: 4.2-5.3 cycles for v_mad_u64_u32, "
-                  "v_add_co, v_mul_lo at 4 waves per SIMD; nothing integer below 4).  MI355X_MICROARCH.md quotes "
-                  "2 cycles for a wave64 v_fma_f32 on the SIMD-32; priced against that figure every VALU "
-                  "fraction here halves (frac_at_2_cycle_peak; v_fma_f32 itself measures 3.1 cycles at 4 waves per SIMD "
-                  "there, every integer instruction 4.3 or more).  Under this kernel the package runs at its power "
-                  "limit (1.34-1.35 kW) and holds 2.08-2.10 GHz of the nominal 2.4 (rocm-smi, "
-                  "profiles/r03_power_clock_bulk.txt): at the clock it holds, back-to-back bulk batches reach 0.91 "
-                  "of the issue rate")
+VALU_PEAK_NOTE = ("peak = 1024 SIMDs x 2.4 GHz / c_mix, c_mix = the issue interval of THIS kernel's instruction mix. "
+                  "Round 4 settled the interval per opcode in real shader cycles (tools/ubench/valu_rate.hip: waves per "
+                  "SIMD 1 - 8, 16 independent chains, clock from s_memtime / s_memrealtime inside every wave; "
+                  "profiles/r04_valu_rate_ubench.txt): v_add / v_sub / v_and / v_xor / v_mov / v_ashrrev_i32 / v_fma_f32 "
+                  "issue every 2.3 - 2.6 cycles - the guide's SIMD-32 figure - but every multiply (v_mad_i64_i32 4.5 - 5.0, "
+                  "v_mul_lo 4.2), every 64-bit shift or add, v_alignbit, v_bfe, every three-operand or carry-writing "
+                  "instruction, every DPP move and all of FP64 issue every 4.1 - 4.8 cycles, and nothing improves past 4 "
+                  "waves per SIMD (v_mad_i64_i32: 4.83 at 2 waves, 4.6 at 4 - 6, 5.0 at 8).  The bulk kernel is 51 % "
+                  "multiply-adds and 78 % four-cycle opcodes: c_mix = 4.04 with every opcode at its best interval "
+                  "(tools/valu_mix.py, profiles/r04_valu_issue.json), 4.34 at the kernel's own 2 waves per SIMD.  "
+                  "frac_at_2_cycle_peak prices the same rate against MI355X_MICROARCH.md's 2-cycle figure, which only "
+                  "the simple 32-bit opcodes reach.  Under this kernel the package runs at its power limit and holds "
+                  "2.08 - 2.10 GHz of the nominal 2.4 (profiles/r03_power_clock_bulk.txt): frac is against the NOMINAL clock")
 
 
 def valu_issue(hashes_per_sec, window_bits, workload, include_finish=True):
@@ -334,10 +357,13 @@ def valu_issue(hashes_per_sec, window_bits, workload, include_finish=True):
     peak = valu_peak()
     return {"bound": "valu_issue", "workload": workload, "instr_per_hash": per_hash,
             "instr_source": "profiles/" + c[2], "achieved": achieved, "peak": peak,
-            "unit": "wave64 VALU instr/s", "frac": achieved / peak, "frac_at_2_cycle_peak": achieved / (2 * peak)}
+            "unit": "wave64 VALU instr/s", "frac": achieved / peak,
+            "cycles_per_instr_of_the_mix": valu_cycles_per_instr(),
+            "frac_at_2_cycle_peak": achieved / (VALU_PEAK_SIMDS * VALU_NOMINAL_GHZ * 1e9 / 2.0),
+            "frac_at_flat_4_cycle_peak": achieved / (VALU_PEAK_SIMDS * VALU_NOMINAL_GHZ * 1e9 / 4.0)}
 
 
-def pmc_traffic(kernel, this_config, files=("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")):
+def pmc_traffic(kernel, this_config, files=("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE
     and --pmc WRITE_SIZE runs, tools/pmc_traffic.py; units and gfx950 calibration in its docstring), and
     the configuration those passes ran - traffic is only comparable with this run when they agree."""
@@ -393,6 +419,11 @@ def main():
                          "treating it as input preparation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    default=os.environ.get("STARKPERP_BENCH_FORCE_DIST") == "1",
+                    help="--gpus 1 only: create a world-size-1 RCCL process group anyway and take every branch the "
+                         "N > 1 runs take (sub-root all_gather + top forest, max / min reductions of the timings, the "
+                         "sharded AIR+FRI path with --workload airfri) - the one-GPU rehearsal of the multi-GPU launch")
     ap.add_argument("--no-airfri", action="store_true",
                     help="merkle workload: skip the `airfri` object (the 2^20-row AIR+FRI half of the metric; at N > 1 "
                          "independent jobs on every GPU)")
@@ -415,9 +446,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    forced_dist = bool(args.force_dist and world == 1)
+    if world > 1 or forced_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced_dist:
+            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if share_gpu:
             dist.init_process_group("gloo")
         else:
@@ -487,7 +523,7 @@ def main():
             h = sl["stream"].cuda_stream
             buf = sl["levels"][nb]
             _lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), nb, HEIGHT, None, h), "forest")
-            if world > 1:
+            if dist is not None:
                 combine_forest_dev(lib, dist, buf[buf.shape[0] - nb :], sl["gathered"], sl["top"], nb, h)
 
     def fence():
@@ -546,7 +582,7 @@ def main():
     # "independent order batches ... shard across the 8 GPUs"), no data-path collective; the ranks start their
     # timed jobs together and the job rate of the node is n_gpus x the slowest rank's rate.
     airfri_multi = None
-    if world > 1 and not args.no_airfri:
+    if dist is not None and not args.no_airfri:
         loc = airfri_object(torch, lib, _lib, dev, False, brief=True, fence=fence)
         t = torch.tensor([loc["commits_per_sec"], 1.0 / loc["seconds_per_job_one_stream"]], dtype=torch.float64, device=dev)
         if dist.get_backend() == "gloo":
@@ -629,11 +665,15 @@ def main():
             },
             "roofline": roof,
         }
-        if world > 1:
+        if dist is not None:
             result["combine_matches_recomputed"] = combine_check(slots[0], world, _lib)
+            result["dist"] = {"backend": dist.get_backend(), "world_size": world, "forced_at_one_gpu": forced_dist}
         if not args.no_airfri:
             result["airfri"] = (airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline) if world == 1
                                 else airfri_multi)
+            if forced_dist and airfri_multi is not None:  # the N > 1 reduction of the job rates, rehearsed at N = 1
+                result["airfri_dist_rehearsal"] = {k: airfri_multi[k] for k in
+                                                   ("commits_per_sec", "commits_per_sec_slowest_gpu", "n_gpus")}
         if world == 1 and not args.no_extras:
             result["extra"] = extras(torch, lib, _lib, dev, stream)
         if world == 1 and not args.no_cpu_baseline:
@@ -686,7 +726,7 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
     alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
     betas = [rng.randrange(P) for _ in range(log_lde - 6)]
     trace = stark.pedersen_trace(xs, ys)  # witness generation is input preparation
-    if world > 1:
+    if dist is not None:  # N > 1, or --force-dist at N = 1: the sharded path on a process group
         return run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, trace, alphas, betas,
                                   total_log_rows)
     per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
@@ -771,8 +811,8 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
                 peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value),
                 hashes_in_timed_launches=int(k_units.value), avg_launch_us=avg_launch_s * 1e6,
                 timing="HIP events around every ped_accumulate_kernel launch inside the timed region",
-                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
-                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
+                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
+                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
                 hbm={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS}),
             "cpu_baseline": (cpu_airfri_baseline(10) if (world == 1 and not args.no_cpu_baseline) else None),
@@ -865,8 +905,8 @@ def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, tr
                 or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None},
                 kernel="ped_accumulate_kernel (row chains and commit-tree levels above 65 536 hashes)",
                 peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value), avg_launch_us=avg_launch_s * 1e6,
-                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
-                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
+                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
+                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
                 hbm={"bound": "hbm", "achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}),
             "cpu_baseline": None,
@@ -952,8 +992,8 @@ def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None):
     roof.update({"kernel": "ped_accumulate_kernel (row chains and the tree levels above 65 536 hashes: %.0f %% of the "
                            "job's hashes)" % (100.0 * k_units.value / (3.0 * hashes)),
                  "launches": int(k_launches.value), "avg_launch_us": (k_ms.value / n_l) * 1e3,
-                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
-                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
+                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
+                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
                  "hbm": {"achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}})
     if brief:
@@ -991,7 +1031,7 @@ def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None):
                          "algorithmic_bytes": algo[k], "hbm_gb_per_s": algo[k] / phase_s[k] / 1e9,
                          "hbm_frac_of_8_tb_per_s": algo[k] / phase_s[k] / 1e9 / HBM_PEAK_GBS,
                          "traffic_per_launch_of_dominant_kernel": pmc_traffic(
-                             "sp::" + dominant[k][0], "airfri", ("r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json"))} for k in phase_s}
+                             "sp::" + dominant[k][0], "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json"))} for k in phase_s}
     out["roofline"] = roof
     stark.prove(xs, ys, n_queries=8, seed=0)
     torch.cuda.synchronize()

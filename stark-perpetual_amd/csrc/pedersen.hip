@@ -373,7 +373,7 @@ ped_accumulate_split_kernel(const uint64_t* __restrict__ x, const uint64_t* __re
 // the others the lane-split body (unfused: X, ZZ to the same scratch planes) on the remaining `rem` hashes.
 // Both populations are resident together, so the remainder's short chain fills issue slots beside the bulk
 // waves instead of costing a launch of its own at one latency-bound wave per SIMD (measured for 163 840 and
-// 81 920 hashes, profiles/r03_levels_forest_20.txt).
+// 81 920 hashes, profiles/r03_levels_forest_20_fused.txt).
 template <int LOG_L>
 __global__ void __launch_bounds__(256, SP_ACC_WAVES)
 ped_accumulate_mixed_kernel(const uint64_t* __restrict__ x, const uint64_t* __restrict__ y, size_t xstride,

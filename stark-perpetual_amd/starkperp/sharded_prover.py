@@ -169,8 +169,14 @@ def _exchange(dist, torch, sends, recvs, rank):
         i.copy_(o)
     if dist is None:
         return
-    out_t = [(dst, t.cpu() if _staged(dist, t) else t) for dst, t in sends if dst != rank]
-    in_t = [(src, t, torch.empty(t.shape, dtype=t.dtype) if _staged(dist, t) else t) for src, t in recvs if src != rank]
+    _p2p_batch(dist, torch, [(dst, t) for dst, t in sends if dst != rank], [(src, t) for src, t in recvs if src != rank])
+
+
+def _p2p_batch(dist, torch, out_msgs, in_msgs):
+    """One grouped batch of point-to-point operations (ncclGroupStart / Send / Recv / End under RCCL): out_msgs
+    [(dst, tensor)], in_msgs [(src, tensor)]; device tensors go as they are except under gloo (staged)."""
+    out_t = [(dst, t.cpu() if _staged(dist, t) else t) for dst, t in out_msgs]
+    in_t = [(src, t, torch.empty(t.shape, dtype=t.dtype) if _staged(dist, t) else t) for src, t in in_msgs]
     ops = [dist.P2POp(dist.isend, t, dst) for dst, t in out_t]
     ops += [dist.P2POp(dist.irecv, buf, src) for src, _, buf in in_t]
     if ops:
@@ -183,9 +189,9 @@ def _exchange(dist, torch, sends, recvs, rank):
 
 def _all_gather_rows(dist, torch, rows, world):
     """[k, 4] per rank -> [world * k, 4] in rank order."""
-    if dist is None or world == 1:
+    if dist is None:
         return rows
-    src = rows.contiguous()
+    src = rows.contiguous()  # (a world of one still goes through the backend: bench.py --force-dist rehearses RCCL so)
     if _staged(dist, src):
         host = src.cpu()
         parts = [torch.empty_like(host) for _ in range(world)]

@@ -279,7 +279,7 @@ errors = []
 def worker(t):
     try:
         for rep in range(12):
-            lo = (t + rep) % 4
+            lo = (t + rep) %% 4
             idx = [lo, lo + 1, lo + 2]
             got = batch.verify_codes([zs[i] for i in idx], [rs[i] for i in idx], [ss[i] for i in idx],
                                      [keys[i] for i in idx])

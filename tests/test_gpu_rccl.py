@@ -1,0 +1,109 @@
+"""RCCL rehearsal on the box's one GPU: the code the 8-GPU run takes for its exchanges has
+only ever run under gloo.  Here a world-size-1 process group with backend "nccl" (= RCCL on ROCm) is created in a
+subprocess (a hang must not take the suite with it) and the product's collectives go through it with DEVICE
+tensors: `combine_forest_dev` (all_gather_into_tensor + the top forest), `_all_gather_rows`, `_p2p_batch` (the
+grouped send / recv of `_exchange`, addressed to the rank itself), and bench.py with --force-dist in both workloads.
+Proves: librccl loads next to libstarkperp under the torch runtime `_lib.load()` pins, the un-staged (device
+pointer) branches are type- and stream-correct, and every `dist is not None` branch of bench.py executes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(**extra):
+    return dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", **extra)
+
+
+def test_product_collectives_through_rccl_world_1():
+    code = r'''
+import os, sys
+sys.path[:0] = [%r, %r, %r]
+import torch, torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+from starkperp import _lib, sharded_prover as SP
+from starkperp.distributed import combine_forest_dev, gather_subroots, felt_to_tensor
+from oracle import cref
+import workloads as wl
+lib = _lib.ensure_init(0)
+stream = torch.cuda.current_stream().cuda_stream
+# 1. combine_forest_dev: three sub-roots of this rank -> all_gather_into_tensor (RCCL) -> top forest of height 0
+nb = 3
+leaves = wl.leaves(nb * 8, seed=5)
+buf = torch.zeros((nb * 15, 4), dtype=torch.int64, device=dev)
+buf[: nb * 8] = torch.stack([felt_to_tensor(torch, v) for v in leaves]).to(dev)
+_lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), nb, 3, None, stream), "forest")
+gathered = torch.zeros((nb, 4), dtype=torch.int64, device=dev)
+top = torch.zeros((nb, 4), dtype=torch.int64, device=dev)
+roots = combine_forest_dev(lib, dist, buf[buf.shape[0] - nb:], gathered, top, nb, stream)
+torch.cuda.synchronize()
+from starkperp.distributed import tensor_to_felt
+got = [tensor_to_felt(r.cpu()) for r in roots]
+want = [cref.merkle_levels(leaves[8 * t: 8 * t + 8])[-1][0] for t in range(nb)]
+assert got == want, (got, want)
+assert gather_subroots(dist, torch, want[0], device=dev) == [want[0]]
+# 2. _all_gather_rows with a device tensor: not staged under nccl, result stays on the device
+rows = torch.arange(4 * 1000, dtype=torch.int64, device=dev).reshape(1000, 4)
+assert not SP._staged(dist, rows)
+allr = SP._all_gather_rows(dist, torch, rows, 1)
+assert allr.is_cuda and torch.equal(allr, rows)
+# 3. the grouped point-to-point batch of _exchange, addressed to this rank (ncclGroupStart / Send / Recv / End)
+src = [torch.full((64, 17, 4), 7 + i, dtype=torch.int64, device=dev) for i in range(3)]
+dst = [torch.zeros_like(t) for t in src]
+SP._p2p_batch(dist, torch, [(0, t) for t in src], [(0, t) for t in dst])
+torch.cuda.synchronize()
+assert all(torch.equal(a, b) for a, b in zip(src, dst))
+# 4. reductions the timing code uses, on device scalars
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+assert float(t.item()) == 1.5
+import ctypes
+maps = open("/proc/self/maps").read()
+assert "librccl" in maps and "libstarkperp.so" in maps
+dist.destroy_process_group()
+print("ok")
+''' % (ROOT, os.path.join(ROOT, "stark-perpetual_amd"), os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=_env(STARKPERP_WINDOW_BITS="16"), cwd=ROOT)
+    # (RCCL prints its version banner to stdout when the group is torn down: "ok" is a line, not the last one)
+    assert out.returncode == 0 and "ok" in out.stdout.split(), out.stdout[-1500:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("workload,extra", [("merkle", ["--steps", "4", "--warmup", "1"]),
+                                            ("airfri", ["--steps", "1", "--warmup", "1", "--log-rows", "14"])])
+def test_bench_force_dist_takes_the_multi_gpu_branches(workload, extra):
+    """`bench.py --gpus 1 --force-dist`: the driver's one-GPU lease runs init_process_group("nccl"), the sub-root
+    all_gather + top forest after every call, the MAX / MIN reductions, and (airfri) the sharded commit_job."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--workload", workload,
+           "--window-bits", "0", "--no-extras", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(STARKPERP_WINDOW_BITS="16"), cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    if workload == "merkle":
+        assert d["dist"] == {"backend": "nccl", "world_size": 1, "forced_at_one_gpu": True}
+        assert d["combine_matches_recomputed"] is True
+        assert d["airfri_dist_rehearsal"]["n_gpus"] == 1 and d["airfri_dist_rehearsal"]["commits_per_sec"] > 0
+        assert list(d)[-1] == "summary"
+    else:
+        assert d["config"]["exchange"]["backend"] == "nccl"
+        assert d["sharded_roots_match_single_gpu"] is True

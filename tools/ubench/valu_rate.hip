@@ -23,6 +23,7 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, Stamp* stamps, uint32_t 
   for (int c = 0; c < CHAINS; ++c) { acc[c] = a + c; r[c] = b + c; d[c] = (double)(a + c); }
   double da = (double)a * 1e-9, db = (double)b * 1e-9;
   uint64_t pk = ((uint64_t)a << 32) | b;
+  if (OP == 33) asm volatile("s_mov_b32 s12, 0x55555555\n\ts_mov_b32 s13, 0x33333333" ::: "s12", "s13");
   unsigned long long c0 = __builtin_readcyclecounter();  // s_memtime
   unsigned long long r0 = wall_clock64();                // s_memrealtime
   for (int i = 0; i < ITERS; ++i) {
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, Stamp* stamps, uint32_t 
       if (OP == 30) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(r[c]) : "v"(a));
       if (OP == 31) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r[c]) : "v"(a));
       if (OP == 32) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(r[c]) : "v"(a));
-      if (OP == 33) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[c]) : "v"(a) : "vcc");
+      if (OP == 33) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[12:13]" : "+v"(r[c]) : "v"(a));  // mask set before the loop
       if (OP == 34) asm volatile("v_mov_b64 %0, %1" : "+v"(acc[c]) : "v"(pk));
       if (OP == 35) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(acc[c]));
       if (OP == 36) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(r[c]));
@@ -171,7 +172,7 @@ void sweep(int w) {
   run<30, CHAINS>("v_lshl_add_u32", w);
   run<32, CHAINS>("v_lshl_or_b32", w);
   run<36, CHAINS>("v_bfe_u32", w);
-  run<33, CHAINS>("v_cndmask_b32 (vcc)", w);
+  run<33, CHAINS>("v_cndmask_b32 (sgpr)", w);
   run<45, CHAINS>("v_cmp_ne_u32", w);
   run<38, CHAINS>("v_sub_co_u32", w);
   run<34, CHAINS>("v_mov_b64", w);

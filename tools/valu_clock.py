@@ -18,11 +18,17 @@ with open(kt) as f:
         dur[k] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         name[k] = r["Kernel_Name"]
 act = defaultdict(float)
+inst = defaultdict(int)
 with open(cc) as f:
     for r in csv.DictReader(f):
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
             k = r.get("Dispatch_Id") or r.get("Dispatch_ID")
             act[k] += float(r["Counter_Value"])
+            inst[k] += 1
+# the counter is reported once per XCD (or summed over the 8 XCDs in one row): busy cycles of ONE die = sum / 8
+XCDS = 8
+for k in act:
+    act[k] /= XCDS
 rows = defaultdict(list)
 for k, a in act.items():
     if k in dur and dur[k] > 0:
