@@ -338,8 +338,8 @@ VALU_PEAK_NOTE = ("peak = 1024 SIMDs x 2.4 GHz / c_mix, c_mix = the issue interv
                   "issue every 2.3 - 2.6 cycles - the guide's SIMD-32 figure - but every multiply (v_mad_i64_i32 4.5 - 5.0, "
                   "v_mul_lo 4.2), every 64-bit shift or add, v_alignbit, v_bfe, every three-operand or carry-writing "
                   "instruction, every DPP move and all of FP64 issue every 4.1 - 4.8 cycles, and nothing improves past 4 "
-                  "waves per SIMD (v_mad_i64_i32: 4.83 at 2 waves, 4.6 at 4 - 6, 5.0 at 8).  The bulk kernel is 51 % "
-                  "multiply-adds and 78 % four-cycle opcodes: c_mix = 4.04 with every opcode at its best interval "
+                  "waves per SIMD (v_mad_i64_i32: 4.8 - 4.9 at 2 waves, 4.5 - 4.8 at 4 - 6, 5.0 at 8).  The bulk kernel is 52 % "
+                  "multiply-adds and 81 % four-cycle opcodes: c_mix = 4.04 with every opcode at its best interval "
                   "(tools/valu_mix.py, profiles/r04_valu_issue.json), 4.34 at the kernel's own 2 waves per SIMD.  "
                   "frac_at_2_cycle_peak prices the same rate against MI355X_MICROARCH.md's 2-cycle figure, which only "
                   "the simple 32-bit opcodes reach.  Under this kernel the package runs at its power limit and holds "
@@ -458,6 +458,20 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+            # RCCL writes a version banner ("RCCL version : ...", five lines) to the C stdout when its first
+            # communicator comes up; through a pipe it would sit in the stdio buffer and land AFTER the JSON line at
+            # exit.  Bring the communicator up now with fd 1 pointed at stderr and flush: stdout carries ONE line.
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                t0 = torch.zeros(1, device=dev)
+                dist.all_reduce(t0)
+                torch.cuda.synchronize()
+                ctypes.CDLL(None).fflush(None)
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
 
     from starkperp import _lib
     from starkperp.distributed import combine_forest_dev
@@ -1021,7 +1035,7 @@ def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None):
         "commit_composition_2p22_rows": 32 * n_lde + 64 * n_lde,
         "fri_fold_first_layer_2p22": (32 + 16) * n_lde,
     }
-    dominant = {"lde_4cols_2p20_to_2p22": ("ntt_tile_kernel", "valu (one 174-instruction multiplication per butterfly "
+    dominant = {"lde_4cols_2p20_to_2p22": ("ntt_tile_kernel", "valu (one 156-instruction multiplication per butterfly "
                                            "and 64 B; 0.30 of 8 TB/s would be 100 % VALU issue)"),
                 "commit_trace_lde_4cols_2p22_rows": ("ped_accumulate_kernel", "valu_issue"),
                 "air_eval_2p22_points": ("air_eval_kernel", "valu"),

@@ -1,15 +1,15 @@
 // Field arithmetic for the Stark prime p = 2^251 + 17*2^192 + 1 and the curve order N, built for
 // the gfx950 VALU: nine SIGNED 29-bit limbs per element and 64-bit signed column accumulators.
 //
-// Why this shape (measured on MI355X, tools/ubench/valu_rate.hip): v_mad_i64_i32 issues at
-// ~5.2 cycles per wave64 instruction, essentially the same as v_add_co/v_addc (~4.8).  Carry
-// handling therefore costs as much as multiplying, so the representation is chosen to have NO
-// carries inside a product: 9 limbs x 29 bits give 81 multiply-accumulates into 17 columns whose
-// sums stay below 2^63, additions and subtractions are plain limb-wise adds (lazy, signed), and
-// the Montgomery radix R = 2^261 leaves ~9 bits of value headroom so no conditional subtraction
-// is ever needed between multiplications.  p = 1 + 17*2^18 * 2^(6*29) + 2^19 * 2^(8*29) has only
-// three non-zero limbs and p = 1 (mod 2^29), so a reduction step is q = -c_i mod 2^29 followed by
-// two multiply-adds.
+// Why this shape (measured on MI355X, tools/ubench/valu_rate.hip, profiles/r04_valu_rate_ubench.txt): a
+// v_mad_i64_i32 issues every 4.5 - 5.0 cycles per SIMD, a 64-bit add or shift every 4.2 - 4.7, a carry-writing
+// add every 4.4, a plain 32-bit and / add / sub every 2.3 - 2.6.  Carry handling in 64 bits costs as much as
+// multiplying, so the representation is chosen to have NO carries inside a product: 9 limbs x 29 bits give 81
+// multiply-accumulates into 17 columns whose sums stay below 2^63, additions and subtractions are plain limb-wise
+// 32-bit adds (lazy, signed), and the Montgomery radix R = 2^261 leaves ~9 bits of value headroom so no
+// conditional subtraction is ever needed between multiplications.  p = 1 + 17*2^18 * 2^(6*29) + 2^19 * 2^(8*29)
+// has only three non-zero limbs and p = 1 (mod 2^29), so a reduction step is q = c_i mod 2^29 (one v_and)
+// followed by two multiply-adds with -P6, -P8 and the 64-bit carry (fe_reduce).
 //
 // Conventions
 //   * "N-form": limbs 0..7 in [0, 2^29), limb 8 small and signed; value in (-4p, 4p).  This is

@@ -83,7 +83,9 @@ __device__ __forceinline__ sha256_state sha256_init() {
 //    0  1  2 | 3  4 | 5  6 | 7  8  9 | 10 11 | 12 13 | 14 15 | (16 17 | 18 19 | 20 21 -> 14)
 //    K = HMAC(0, V 00 d h1 e)   V = HMAC(K, V)   K = HMAC(K, V 01 d h1 e)   V = HMAC(K, V)   V = HMAC(K, V) -> k
 // The all-zero key of step 0 / 2 is a constant: compress(IV, 0x36 x 64), compress(IV, 0x5c x 64).
-__device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint64_t seed) {
+// MAX_REJECTED / rejected_out: for tools/ubench/rfc6979_chain.hip (what the retry chain costs); the library uses the defaults.
+template <int MAX_REJECTED = 64>
+__device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint64_t seed, int* rejected_out = nullptr) {
   uint32_t X[19];  // d, h1 big-endian, entropy + marker
 #pragma unroll
   for (int i = 0; i < 8; ++i) { X[i] = d.w[7 - i]; X[8 + i] = z.w[7 - i]; }
@@ -158,7 +160,7 @@ __device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint
         cand.w[i] = (lo >> 4) | (hi << 28);
       }
       if (!u256_is_zero(cand) && u256_lt(cand, U256_N)) break;
-      if (++rejected == 64) {  // unreachable in practice; the caller reports SP_SIGN_RETRY for k = 0
+      if (++rejected == MAX_REJECTED) {  // 64: unreachable in practice; the caller reports SP_SIGN_RETRY for k = 0
 #pragma unroll
         for (int i = 0; i < 8; ++i) cand.w[i] = 0;
         break;
@@ -166,6 +168,7 @@ __device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint
     }
     step = step == 21 ? 14 : step + 1;
   }
+  if (rejected_out) *rejected_out = rejected;
   return cand;
 }
 
