@@ -48,6 +48,15 @@ def pedersen_hash_many(xs, ys):
     return _unpack(out, n), list(bytes(st))
 
 
+def pedersen_chain_right(elements):
+    """H(e0, H(e1, ... H(e_{n-2}, e_{n-1}))) in one C call (12 000 links in about a second)."""
+    n = len(elements)
+    out = (ctypes.c_uint64 * 4)()
+    status = lib().cref_pedersen_chain_right(_pack(elements), ctypes.c_size_t(n), out)
+    assert status == 0, "unhashable link"
+    return _unpack(out, 1)[0]
+
+
 def opt_pedersen_hash_many(xs, ys):
     """The optimised comparator (windowed tables + batched affine additions): same outputs."""
     n = len(xs)

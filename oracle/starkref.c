@@ -240,6 +240,23 @@ void cref_pedersen_batch(const uint64_t* x, const uint64_t* y, uint64_t* out, ui
     memcpy(out + 4 * i, &o, 32);
   }
 }
+/* right fold h = H(e_i, h) from h = e_{n-1} (cairo-lang compute_hash_chain, the consumer behind
+ * starkware/cairo/bootloaders/program_hash_test_utils.py:9): serial by nature, one thread.  Returns the OR of the
+ * per-link status bytes. */
+int cref_pedersen_chain_right(const uint64_t* elems, size_t n, uint64_t* out) {
+  init_tables();
+  u256 acc;
+  int status = 0;
+  memcpy(&acc, elems + 4 * (n - 1), 32);
+  for (size_t i = n - 1; i-- > 0;) {
+    u256 w, o = {{0, 0, 0, 0}};
+    memcpy(&w, elems + 4 * i, 32);
+    status |= pedersen_one(&w, &acc, &o);
+    acc = o;
+  }
+  memcpy(out, &acc, 32);
+  return status;
+}
 /* full rebuild over 2^height leaves; levels holds 2^(height+1) - 1 felts, leaves first */
 void cref_merkle_build(uint64_t* levels, unsigned height) {
   init_tables();
