@@ -200,6 +200,49 @@ build_window_kernel(aff_packed* tab, const aff_packed* bits, const aff_packed* o
   tab[v] = out;
 }
 
+// Round 4: the doubling schedule of the table build.  tab[v | 2^b] = tab[v] + bits[b] for v < 2^b: ONE affine
+// addition per new entry instead of one per set bit (13 on average at 26 bits), the division shared by the EXTEND_K
+// entries of a thread (Montgomery's trick around one lane-private inversion).  Pass b reads entries
+// [0, 2^b) and writes [2^b, 2^(b+1)): passes of one window run one after the other on the stream.  An exceptional
+// addition (x1 = x2: impossible for these points, context.hip header) would zero the shared inverse and leave the
+// thread's entries off the curve - the on-curve check below reports it like build_window_kernel does.
+// 26-bit windows: 1.1 s -> ~0.2 s per process (profiles/r04_table_build.txt).
+constexpr int EXTEND_K = 8;
+__global__ void __launch_bounds__(256)
+extend_window_kernel(aff_packed* tab, const aff_packed* bit, int b, fe beta_m, unsigned* bad) {
+  const size_t half = (size_t)1 << b;
+  const size_t stride = half / EXTEND_K;  // entry k of thread t is t + k * stride: the lanes of a wave touch consecutive entries
+  const size_t v0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v0 >= stride) return;
+  const aff q = ld_aff(bit);
+  fe prefix[EXTEND_K];
+  fe run = FE_ONE_M;
+#pragma unroll
+  for (int k = 0; k < EXTEND_K; ++k) {
+    const fe px = fe_unpack(ld_u256((const uint64_t*)&tab[v0 + k * stride].x));
+    prefix[k] = run;  // product of the denominators before entry k
+    run = fe_mul(run, fe_sub(q.x, px));  // B = 1 signed operand
+  }
+  fe inv = fe_inv(run);
+#pragma unroll
+  for (int k = EXTEND_K - 1; k >= 0; --k) {
+    const aff p1 = ld_aff(tab + v0 + k * stride);
+    const fe dx = fe_sub(q.x, p1.x);
+    const fe idx = fe_mul(inv, prefix[k]);  // 1 / dx_k
+    inv = fe_mul(inv, dx);
+    const fe lam = fe_mul(fe_sub(q.y, p1.y), idx);
+    const fe x3 = fe_carry(fe_sub(fe_sub(fe_sqr(lam), p1.x), q.x));
+    const fe y3 = fe_carry(fe_sub(fe_mul(lam, fe_sub(p1.x, x3)), p1.y));
+    const fe lhs = fe_sqr(y3);
+    const fe rhs = fe_carry(fe_add(fe_add(fe_mul(fe_sqr(x3), x3), x3), beta_m));
+    if (!fe_eq(lhs, rhs)) atomicAdd(bad, 1u);
+    aff_packed out;
+    out.x = fe_pack(fe_canon(x3));
+    out.y = fe_pack(fe_canon(y3));
+    tab[half + v0 + k * stride] = out;
+  }
+}
+
 static aff_packed pack_point(const haff& p) {
   aff_packed r;
   r.x = fe_pack(fe_canon(p.x));
@@ -239,10 +282,20 @@ static int build_windows(aff_packed* dev_tab, const std::vector<haff>& bit_pts, 
   SP_HIP(hipMemcpy(d_offs, h_offs.data(), h_offs.size() * sizeof(aff_packed), hipMemcpyHostToDevice));
   SP_HIP(hipMemset(d_bad, 0, sizeof(unsigned)));
   const fe beta_m = fe_to_mont(fe_unpack(CURVE_BETA));
+  // the first 2^13 entries of a window from their set bits, every further bit by one doubling pass
+  // (STARKPERP_TABLE_BUILD=direct: every entry from its set bits, the round 1 - 3 build, kept for A/B and as the
+  // independent construction tests/test_gpu_pedersen.py compares the tables of the two builds through)
+  static const bool direct = getenv("STARKPERP_TABLE_BUILD") && !strcmp(getenv("STARKPERP_TABLE_BUILD"), "direct");
   for (size_t g = 0; g < nw; ++g) {
-    const size_t count = (size_t)1 << nb[g];
+    const int seed_bits = direct || nb[g] < 13 ? nb[g] : 13;
+    const size_t count = (size_t)1 << seed_bits;
     hipLaunchKernelGGL(build_window_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0,
-                       dev_tab + base[g], d_bits + first[g], d_offs + g, nb[g], beta_m, d_bad);
+                       dev_tab + base[g], d_bits + first[g], d_offs + g, seed_bits, beta_m, d_bad);
+    for (int b = seed_bits; b < nb[g]; ++b) {
+      const size_t threads = ((size_t)1 << b) / EXTEND_K;
+      hipLaunchKernelGGL(extend_window_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, 0,
+                         dev_tab + base[g], d_bits + first[g] + b, b, beta_m, d_bad);
+    }
   }
   SP_HIP(hipGetLastError());
   SP_HIP(hipDeviceSynchronize());

@@ -145,6 +145,44 @@ def test_shutdown_and_reinit_with_other_window(batch):
     _lib.ensure_init()
 
 
+def test_table_build_schedules_agree(batch):
+    """Round 4: the tables are built by doubling passes (one affine addition per entry).  The round 1 - 3 build (every
+    entry from its set bits, STARKPERP_TABLE_BUILD=direct) in a subprocess must hash the reference's goldens and 4096
+    random pairs exactly like this process does - under a window width whose windows take several doubling passes."""
+    import subprocess
+    import sys
+    from starkperp import _lib
+    g = load("g1_pedersen.json")
+    lib = _lib.load()
+    lib.sp_shutdown()
+    _lib.check(lib.sp_init(0, 18), "sp_init")  # 2^18-entry windows: five doubling passes on top of the 2^13 seed entries
+    pairs = wl.pedersen_pairs(g["n"], seed=g["seed"])
+    rng = random.Random(5)
+    extra = [(rng.randrange(P), rng.randrange(P)) for _ in range(4096)]
+    ours = batch.pedersen_hash_many([p[0] for p in pairs + extra], [p[1] for p in pairs + extra])
+    assert ours[: g["n"]] == [h(v) for v in g["all"]]
+    lib.sp_shutdown()
+    _lib.ensure_init()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, random, hashlib
+sys.path[:0] = [%r, %r, %r]
+from starkperp import batch
+import workloads as wl
+from oracle import ref_py as R
+pairs = wl.pedersen_pairs(%d, seed=%d)
+rng = random.Random(5)
+extra = [(rng.randrange(R.FIELD_PRIME), rng.randrange(R.FIELD_PRIME)) for _ in range(4096)]
+out = batch.pedersen_hash_many([p[0] for p in pairs + extra], [p[1] for p in pairs + extra])
+print(hashlib.sha256(repr(out).encode()).hexdigest())
+''' % (root, os.path.join(root, "stark-perpetual_amd"), os.path.join(root, "tests"), g["n"], g["seed"])
+    env = dict(os.environ, STARKPERP_TABLE_BUILD="direct", STARKPERP_WINDOW_BITS="18")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-1500:]
+    import hashlib
+    assert out.stdout.split()[-1] == hashlib.sha256(repr(ours).encode()).hexdigest()
+
+
 def test_bulk_and_split_paths_vs_c_oracle(batch):
     """Every accumulate variant (1, 2, 4, 8 lanes per hash are picked by batch size) against the C
     oracle on seeded inputs, plus out-of-range status propagation inside a large batch."""
