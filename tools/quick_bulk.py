@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Bulk Pedersen rate for one window plan (development aid): python tools/quick_bulk.py [log2_n=22] [window_bits=0]"""
+"""Bulk Pedersen rate for one window plan (development aid): python tools/quick_bulk.py [log2_n=22] [window_bits=0] [same]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stark-perpetual_amd"))
@@ -14,6 +14,12 @@ def felts():
     t = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, generator=g); t[:, 3] &= (1 << 58) - 1
     return t.cuda()
 x, y = felts(), felts(); o = torch.empty_like(x)
+if len(sys.argv) > 3 and sys.argv[3] == "same":  # every hash the same pair: all gathers hit 19 cached entries (the kernel without its memory side)
+    x[:] = x[0]; y[:] = y[0]
+if len(sys.argv) > 3 and sys.argv[3].startswith("few"):  # few<k>: 2^k distinct pairs repeated: random-looking lanes, gathers served by L2
+    m = 1 << int(sys.argv[3][3:] or 10)
+    idx = torch.arange(n, device="cuda") % m
+    x, y = x[idx].contiguous(), y[idx].contiguous()
 s = torch.cuda.current_stream().cuda_stream
 def run():
     _lib.check(lib.sp_pedersen_batch_dev(x.data_ptr(), y.data_ptr(), o.data_ptr(), None, n, s), "ped")
