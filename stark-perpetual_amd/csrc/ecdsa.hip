@@ -1227,7 +1227,9 @@ static int verify_batch_keyed_impl(const uint64_t* z, const uint64_t* r, const u
   {
     ctx_lock lk(ctx().mu);
     if (policy && !use_key_tables(qx, qy, n)) { *fell_back = true; return SP_OK; }
-    int rc = policy ? register_keys_locked(qx, qy, n, slots.data()) : sp_ecdsa_register_keys(qx, qy, n, slots.data());
+    // the handles never leave this call, so this is not an `external_handles` registration (sp_order_batch comes
+    // through here on every batch: it must not switch the policy's eviction off)
+    int rc = register_keys_locked(qx, qy, n, slots.data());
     if (policy && rc == SP_ERR_CACHE_FULL) { *fell_back = true; return SP_OK; }  // (cannot happen under one lock; kept as the safe answer)
     if (rc != SP_OK) return rc;
     const uint64_t* host[3] = {z, r, s};

@@ -264,6 +264,14 @@ assert batch.verify_codes(zs[:3], rs[:3], ss[:3], keys[:3]) == [1, 1, 1]
 assert batch.key_cache_info() == (4, 3)
 assert batch.verify_codes(zs[3:], rs[3:], ss[3:], keys[3:]) == [1, 1, 1]   # 3 + 3 > 4: rolled
 assert batch.key_cache_info() == (4, 3)
+# an explicit keyed CALL hands out no handles (sp_order_batch verifies this way on every batch): the policy may
+# still roll the cache afterwards
+assert batch.verify_codes(zs[3:], rs[3:], ss[3:], keys[3:], key_tables=True) == [1, 1, 1]
+assert batch.verify_codes(zs[:3], rs[:3], ss[:3], keys[:3]) == [1, 1, 1]     # 3 + 3 > 4: rolled again
+assert batch.key_cache_info() == (4, 3)
+batch.key_cache_reset()
+assert batch.verify_codes(zs[3:], rs[3:], ss[3:], keys[3:]) == [1, 1, 1]
+assert batch.key_cache_info() == (4, 3)
 # ... but never behind handles a caller holds (ADVICE r3): after an explicit registration the policy serves a
 # batch that does not fit from the ladder and the handles stay good
 handles = batch.register_keys(keys[3:])
