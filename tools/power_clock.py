@@ -2,7 +2,7 @@
 """Power and clock telemetry under the bulk hash kernel: 2^22 independent hashes in a loop for ~10 s while
 `rocm-smi` is sampled from a side thread (board power, sclk, temperature).  Evidence for the clock the VALU-issue
 fractions are priced against (peak at the nominal 2.4 GHz; the chip holds less under this kernel).
-    python tools/power_clock.py [window_bits=26] [seconds=10]"""
+    python tools/power_clock.py [window_bits=26] [seconds=10] [few<k>]"""
 import json, os, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stark-perpetual_amd"))
@@ -18,6 +18,9 @@ def felts():
     t = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, generator=g); t[:, 3] &= (1 << 58) - 1
     return t.cuda()
 x, y = felts(), felts(); o = torch.empty_like(x)
+if len(sys.argv) > 3 and sys.argv[3].startswith("few"):  # few<k>: 2^k distinct pairs repeated - gathers served by L2 / MALL
+    idx = torch.arange(n, device="cuda") % (1 << int(sys.argv[3][3:] or 10))
+    x, y = x[idx].contiguous(), y[idx].contiguous()
 s = torch.cuda.current_stream().cuda_stream
 samples, stop = [], threading.Event()
 
