@@ -766,6 +766,120 @@ ecdsa_sign_rfc6979_kernel(const uint64_t* __restrict__ pz, const uint64_t* __res
   status[e] = st;
 }
 
+// ---- the batch signer with compaction between RFC 6979 candidates (round 4) ------------------------------------
+// Half of all candidates are rejected (a 252-bit candidate against N ~ 2^251), so in the one-kernel signer above a
+// wave of 64 items runs 16 + 8 x 6.2 compressions per lane where an item needs 24 on average
+// (profiles/r04_rfc6979_chain_ubench.txt).  For large batches the nonce phase is cut into rounds: every item's FIRST
+// candidate in one launch, the rejected items' states (kin, kout, V: 24 words, word-major planes) appended to a
+// compact list, the next launch runs one retry (8 compressions) for exactly those, and so on; a last launch loops
+// the stragglers to the end.  The nonces land in a buffer and ecdsa_sign_kernel signs with them; an item whose
+// attempt asks for the next seed (a 2^-55 event) is redone by the one-kernel signer, which owns that rule.
+// The serial retry chain of the batch's slowest item bounds any schedule, so this pays where the batch is much larger
+// than the chip: 2^20 items 5.30 -> 3.60 ms (2.0 -> 2.9 x 10^8 signatures/s), 2^18 1.71 -> 1.48 ms; at 2^16 it is
+// a tie (0.84 against 0.86 ms), at 2^12 0.50 against 0.61 ms (the survivors run on lone waves); below 4096 items the
+// one-kernel form stays (one launch instead of thirteen).  profiles/r04_sign_compaction.txt.
+constexpr int RFC_STATE_WORDS = 24;
+
+__device__ __forceinline__ void rfc_append(bool rejected, uint32_t item, const rfc_state& st, uint32_t* __restrict__ idx_out,
+                                           uint32_t* __restrict__ state_out, size_t cap, uint32_t* __restrict__ counter) {
+  const uint64_t m = __ballot(rejected);
+  if (m == 0) return;
+  const int lane = (int)__lane_id();
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  if (rejected) {
+    const size_t slot = (size_t)base + (size_t)__popcll(m & ((1ull << lane) - 1ull));
+    idx_out[slot] = item;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      state_out[(size_t)w * cap + slot] = st.kin.h[w];
+      state_out[(size_t)(8 + w) * cap + slot] = st.kout.h[w];
+      state_out[(size_t)(16 + w) * cap + slot] = st.v.h[w];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(128)
+sign_nonce_first_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pd,
+                        const uint64_t* __restrict__ pseed, uint64_t* __restrict__ kbuf, size_t n,
+                        uint32_t* __restrict__ idx_out, uint32_t* __restrict__ state_out, uint32_t* __restrict__ counter) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = e < n;
+  const size_t ee = active ? e : n - 1;
+  const u256 z = ld_u256(pz + 4 * ee), d = ld_u256(pd + 4 * ee);
+  const bool valid = active && u256_lt(z, U256_2P251) && !u256_is_zero(d) && u256_lt(d, U256_N);
+  rfc_input in;
+  rfc6979_prepare(z, d, pseed ? pseed[ee] : 0, in);
+  rfc_state st;
+  u256 cand;
+  const bool accepted = rfc6979_run<true>(in, st, 1, cand);
+  if (active && (accepted || !valid)) {
+    if (!valid) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) cand.w[i] = 0;  // ecdsa_sign_kernel answers SP_SIGN_BAD_INPUT for such an item
+    }
+    st_u256(kbuf + 4 * e, cand);
+  }
+  rfc_append(valid && !accepted, (uint32_t)ee, st, idx_out, state_out, n, counter);
+}
+
+// One more candidate (max_rejected = 1) for the items of a compact list, or - the last launch - as many as it takes.
+__global__ void __launch_bounds__(128)
+sign_nonce_retry_kernel(const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ state_in,
+                        const uint32_t* __restrict__ count_in, size_t cap, int max_rejected,
+                        uint64_t* __restrict__ kbuf, uint32_t* __restrict__ idx_out, uint32_t* __restrict__ state_out,
+                        uint32_t* __restrict__ counter) {
+  const size_t count = *count_in;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const rfc_input none = {};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; (i & ~(size_t)63) < count; i += stride) {
+    const bool active = i < count;
+    const size_t slot = active ? i : count - 1;
+    const uint32_t item = idx_in[slot];
+    rfc_state st;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      st.kin.h[w] = state_in[(size_t)w * cap + slot];
+      st.kout.h[w] = state_in[(size_t)(8 + w) * cap + slot];
+      st.v.h[w] = state_in[(size_t)(16 + w) * cap + slot];
+    }
+    u256 cand;
+    const bool accepted = rfc6979_run<false>(none, st, max_rejected, cand);
+    const bool last = idx_out == nullptr;
+    // (64 rejected candidates in a row in the last launch - a 2^-64 event - leave k = 0: the attempt then answers
+    // SP_SIGN_BAD_INPUT where the one-kernel signer says SP_SIGN_RETRY; either way the item is the caller's)
+    if (active && (accepted || last)) st_u256(kbuf + 4 * (size_t)item, cand);
+    if (!last) rfc_append(active && !accepted, item, st, idx_out, state_out, cap, counter);
+  }
+}
+
+// The one-kernel signer for exactly the items whose attempt asked for another seed (status SP_SIGN_RETRY).
+__global__ void __launch_bounds__(128)
+ecdsa_sign_rfc6979_redo_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pd,
+                               const uint64_t* __restrict__ pseed, uint64_t* __restrict__ orr,
+                               uint64_t* __restrict__ os, uint8_t* __restrict__ status, size_t n,
+                               const aff_packed* __restrict__ gen, int wbits, int nwin) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n || status[e] != SP_SIGN_RETRY) return;
+  const u256 z = ld_u256(pz + 4 * e), d = ld_u256(pd + 4 * e);
+  uint64_t seed = pseed ? pseed[e] : 0;
+  uint8_t st = SP_SIGN_RETRY;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    const u256 k = rfc6979_nonce(z, d, seed);
+    u256 r, s;
+    st = sign_attempt(z, d, k, gen, wbits, nwin, r, s);
+    if (st == SP_SIGN_OK) {
+      st_u256(orr + 4 * e, r);
+      st_u256(os + 4 * e, s);
+    }
+    if (st != SP_SIGN_RETRY) break;
+    ++seed;
+  }
+  status[e] = st;
+}
+
 }  // namespace sp
 
 using namespace sp;
@@ -773,6 +887,7 @@ using namespace sp;
 // Per-stream, like the Pedersen scratch: verifications in flight on different streams (or issued by
 // different host threads) never share a window table.
 static std::map<sp::StreamKey, sp::DeviceBuffer> g_verify_tab;
+static std::map<sp::StreamKey, sp::DeviceBuffer> g_sign_scratch;  // nonces + compact lists of the batch signer, per stream
 // Key-table cache (see "Key tables" above): slot -> 128-entry comb table, curve-model constant c and
 // a flag, all in HBM; the host keeps the (qx, qy | x-only) -> slot map.
 struct KeyId {
@@ -839,6 +954,8 @@ namespace sp {
 void release_ecdsa_state() {
   for (auto& kv : g_verify_tab) kv.second.release();
   g_verify_tab.clear();
+  for (auto& kv : g_sign_scratch) kv.second.release();
+  g_sign_scratch.clear();
   g_keys.tab.release();
   g_keys.c.release();
   g_keys.flag.release();
@@ -1294,6 +1411,53 @@ int sp_ecdsa_verify_batch(const uint64_t* z, const uint64_t* r, const uint64_t* 
   return SP_OK;
 }
 
+// The whole of sign() for a batch on device pointers, enqueued on `st` (the context lock is held by the caller).
+// Below the threshold (4096 items; STARKPERP_SIGN_COMPACT_MIN): ONE launch of the one-kernel signer.  From it on: first candidates -> rounds of one retry on
+// the compacted survivors -> the stragglers -> the attempts -> the (practically empty) next-seed redo.
+static size_t sign_compact_min() {
+  static const size_t v = [] {
+    const char* e = getenv("STARKPERP_SIGN_COMPACT_MIN");  // 0 = never compact
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)4096;
+  }();
+  return v;
+}
+static int enqueue_sign_rfc6979(Context& c, const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
+                                uint64_t* s, uint8_t* status, size_t n, hipStream_t st) {
+  const size_t min_n = sign_compact_min();
+  if (min_n == 0 || n < min_n || n >= ((size_t)1 << 31)) {
+    hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n, 128)), dim3(128), 0, st, z, d, seeds, r, s, status, n,
+                       c.gen, c.wbits, c.nwin);
+    SP_HIP(hipGetLastError());
+    return SP_OK;
+  }
+  constexpr int ROUNDS = 10;  // after them n / 2^11 items are left for the straggler launch
+  DeviceBuffer& buf = g_sign_scratch[stream_key(st)];
+  const size_t kb = n * 32, ib = n * 4, sb = n * 4 * RFC_STATE_WORDS;
+  SP_HIP(buf.reserve(kb + 2 * ib + 2 * sb + 256));
+  char* b = (char*)buf.ptr;
+  uint64_t* kbuf = (uint64_t*)b;
+  uint32_t* idx[2] = {(uint32_t*)(b + kb), (uint32_t*)(b + kb + ib)};
+  uint32_t* state[2] = {(uint32_t*)(b + kb + 2 * ib), (uint32_t*)(b + kb + 2 * ib + sb)};
+  uint32_t* counters = (uint32_t*)(b + kb + 2 * ib + 2 * sb);  // one per list: counters[j] = items that enter round j
+  SP_HIP(hipMemsetAsync(counters, 0, 256, st));
+  hipLaunchKernelGGL(sign_nonce_first_kernel, dim3(nblocks(n, 128)), dim3(128), 0, st, z, d, seeds, kbuf, n, idx[0],
+                     state[0], counters);
+  for (int j = 0; j < ROUNDS; ++j) {
+    const size_t expect = (n >> (j + 1)) + (n >> (j + 3)) + 8192;  // half of the previous list, + 25 % and slack; the loop in the kernel covers any count
+    hipLaunchKernelGGL(sign_nonce_retry_kernel, dim3(nblocks(expect, 128)), dim3(128), 0, st, idx[j & 1], state[j & 1],
+                       counters + j, n, 1, kbuf, idx[(j + 1) & 1], state[(j + 1) & 1], counters + j + 1);
+  }
+  hipLaunchKernelGGL(sign_nonce_retry_kernel, dim3(nblocks((n >> (ROUNDS + 1)) + 8192, 128)), dim3(128), 0, st,
+                     idx[ROUNDS & 1], state[ROUNDS & 1], counters + ROUNDS, n, 64, kbuf, (uint32_t*)nullptr,
+                     (uint32_t*)nullptr, (uint32_t*)nullptr);
+  hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(n, 128)), dim3(128), 0, st, z, d, kbuf, r, s, status, n, c.gen,
+                     c.wbits, c.nwin);
+  hipLaunchKernelGGL(ecdsa_sign_rfc6979_redo_kernel, dim3(nblocks(n, 128)), dim3(128), 0, st, z, d, seeds, r, s, status, n,
+                     c.gen, c.wbits, c.nwin);
+  SP_HIP(hipGetLastError());
+  return SP_OK;
+}
+
 int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r,
                         uint64_t* s, uint8_t* status, size_t n) {
   LaneScope ls;
@@ -1342,9 +1506,11 @@ int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint
   uint8_t* dst = (uint8_t*)(extra + 2 * fb + n * 8);
   SP_HIP(hipMemsetAsync(dr, 0, 2 * fb, L.stream));
   if (seeds) SP_HIP(hipMemcpyAsync(dseed, seeds, n * 8, hipMemcpyHostToDevice, L.stream));
-  hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n, 128)), dim3(128), 0, L.stream, dev[0], dev[1],
-                     seeds ? dseed : nullptr, dr, ds, dst, n, c.gen, c.wbits, c.nwin);
-  SP_HIP(hipGetLastError());
+  {
+    ctx_lock lk(c.mu);  // the compacted pipeline keeps per-stream scratch in a shared map
+    rc = enqueue_sign_rfc6979(c, dev[0], dev[1], seeds ? dseed : nullptr, dr, ds, dst, n, L.stream);
+    if (rc != SP_OK) return rc;
+  }
   SP_HIP(hipMemcpyAsync(r, dr, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(s, ds, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
@@ -1378,10 +1544,7 @@ int sp_ecdsa_sign_rfc6979_batch_dev(const uint64_t* z, const uint64_t* d, const 
   if (!z || !d || !r || !s || !status) { set_error("sp_ecdsa_sign_rfc6979_batch_dev: null pointer"); return SP_ERR_BAD_ARGUMENT; }
   Context& c = ctx();
   ctx_lock lk(c.mu);
-  hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z, d, seeds, r,
-                     s, status, n, c.gen, c.wbits, c.nwin);
-  SP_HIP(hipGetLastError());
-  return SP_OK;
+  return enqueue_sign_rfc6979(c, z, d, seeds, r, s, status, n, (hipStream_t)stream);
 }
 
 // (qx, qy) = d * EC_GEN on device pointers; qy and status may be null.  Outputs of a rejected item are left as they were.

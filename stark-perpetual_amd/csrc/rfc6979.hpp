@@ -83,9 +83,18 @@ __device__ __forceinline__ sha256_state sha256_init() {
 //    0  1  2 | 3  4 | 5  6 | 7  8  9 | 10 11 | 12 13 | 14 15 | (16 17 | 18 19 | 20 21 -> 14)
 //    K = HMAC(0, V 00 d h1 e)   V = HMAC(K, V)   K = HMAC(K, V 01 d h1 e)   V = HMAC(K, V)   V = HMAC(K, V) -> k
 // The all-zero key of step 0 / 2 is a constant: compress(IV, 0x36 x 64), compress(IV, 0x5c x 64).
-// MAX_REJECTED / rejected_out: for tools/ubench/rfc6979_chain.hip (what the retry chain costs); the library uses the defaults.
-template <int MAX_REJECTED = 64>
-__device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint64_t seed, int* rejected_out = nullptr) {
+// Round 4: the nonce generator in two pieces so that a batch signer can COMPACT between candidates
+// (ecdsa.hip sign_nonce_first_kernel / sign_nonce_retry_kernel): the fixed word layouts of the key material
+// (rfc6979_prepare) and a resumable run of the step loop (rfc6979_run).
+struct rfc_input {
+  uint32_t T[20];      // sep || d || h1 || entropy || 0x80 shifted right by one byte; the separator is OR-ed in per use
+  uint32_t long_bits;  // bit length of the long messages
+};
+struct rfc_state {
+  sha256_state kin, kout, v;  // the HMAC key as its two pad midstates, and V
+};
+
+__device__ __forceinline__ void rfc6979_prepare(const u256& z, const u256& d, uint64_t seed, rfc_input& in) {
   uint32_t X[19];  // d, h1 big-endian, entropy + marker
 #pragma unroll
   for (int i = 0; i < 8; ++i) { X[i] = d.w[7 - i]; X[8 + i] = z.w[7 - i]; }
@@ -99,45 +108,56 @@ __device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint
     for (int i = 0; i < 3; ++i)
       if ((int)(nb >> 2) == i) X[16 + i] |= mark;
   }
-  uint32_t T[20];  // the byte-shifted stream; the separator byte is OR-ed into T[0] per use
-  T[0] = X[0] >> 8;
+  in.T[0] = X[0] >> 8;
 #pragma unroll
-  for (int i = 1; i < 19; ++i) T[i] = (X[i - 1] << 24) | (X[i] >> 8);
-  T[19] = X[18] << 24;
-  const uint32_t long_bits = (64u + 97u + nb) * 8u;
+  for (int i = 1; i < 19; ++i) in.T[i] = (X[i - 1] << 24) | (X[i] >> 8);
+  in.T[19] = X[18] << 24;
+  in.long_bits = (64u + 97u + nb) * 8u;
+}
 
-  sha256_state kin = {{0xf454dead, 0x9725214f, 0x90daf2a0, 0xdf1228ea, 0x64e5750f, 0xa3924181, 0x824a932b, 0xf8e04e32}};
-  sha256_state kout = {{0xd385480f, 0x7abb6477, 0x37c9c538, 0x5dd82467, 0x8e043a72, 0x753434b0, 0xdeb82818, 0x361d45a6}};
-  sha256_state v, kk = sha256_init(), acc = sha256_init();  // V, the new key K, the running digest
+// Runs the step loop until a candidate is accepted (returns true, the candidate in `cand`) or `max_rejected`
+// candidates were rejected (returns false; `st` is then the state right after the last rejected candidate).
+// START: from step 0 with `in` (st is initialised here); otherwise from step 16 with the state a previous call
+// left behind - `in` is not read (steps 0, 1, 7, 8 are the only ones that touch the key material).
+template <bool START>
+__device__ __forceinline__ bool rfc6979_run(const rfc_input& in, rfc_state& st, int max_rejected, u256& cand,
+                                            int* rejected_out = nullptr) {
+  sha256_state kin, kout, v, kk = sha256_init(), acc = sha256_init();  // V, the new key K, the running digest
+  if (START) {
+    kin = sha256_state{{0xf454dead, 0x9725214f, 0x90daf2a0, 0xdf1228ea, 0x64e5750f, 0xa3924181, 0x824a932b, 0xf8e04e32}};
+    kout = sha256_state{{0xd385480f, 0x7abb6477, 0x37c9c538, 0x5dd82467, 0x8e043a72, 0x753434b0, 0xdeb82818, 0x361d45a6}};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v.h[i] = 0x01010101u;
-  u256 cand;
+    for (int i = 0; i < 8; ++i) v.h[i] = 0x01010101u;
+  } else {
+    kin = st.kin; kout = st.kout; v = st.v;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) cand.w[i] = 0;
-  int step = 0, rejected = 0;
+  int step = START ? 0 : 16, rejected = 0;
+  bool accepted = false;
   for (;;) {
     // ---- the block and the state it is compressed onto ----
     sha256_block blk;
-    sha256_state st;
-    const bool long_a = step == 0 || step == 7, long_b = step == 1 || step == 8;
+    sha256_state cs;
+    const bool long_a = START && (step == 0 || step == 7), long_b = START && (step == 1 || step == 8);
     const bool pad_in = step == 3 || step == 10 || step == 18, pad_out = step == 4 || step == 11 || step == 19;
     const bool outer = step == 2 || step == 6 || step == 9 || step == 13 || step == 15 || step == 17 || step == 21;
     if (long_a) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { blk.w[i] = v.h[i]; blk.w[8 + i] = T[i]; }
+      for (int i = 0; i < 8; ++i) { blk.w[i] = v.h[i]; blk.w[8 + i] = in.T[i]; }
       blk.w[8] |= step == 7 ? 0x01000000u : 0u;
-      st = kin;
+      cs = kin;
     } else if (long_b) {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) blk.w[i] = T[8 + i];
+      for (int i = 0; i < 12; ++i) blk.w[i] = in.T[8 + i];
       blk.w[12] = blk.w[13] = blk.w[14] = 0;
-      blk.w[15] = long_bits;
-      st = acc;
+      blk.w[15] = in.long_bits;
+      cs = acc;
     } else if (pad_in || pad_out) {
       const uint32_t pad = pad_in ? 0x36363636u : 0x5c5c5c5cu;
 #pragma unroll
       for (int i = 0; i < 16; ++i) blk.w[i] = (i < 8 ? kk.h[i] : 0u) ^ pad;
-      st = sha256_init();
+      cs = sha256_init();
     } else {  // a 32-byte message behind a 64-byte pad block: V (or V || 00 at step 16), or an inner digest
 #pragma unroll
       for (int i = 0; i < 8; ++i) blk.w[i] = outer ? acc.h[i] : v.h[i];
@@ -145,9 +165,9 @@ __device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint
 #pragma unroll
       for (int i = 9; i < 15; ++i) blk.w[i] = 0;
       blk.w[15] = step == 16 ? (64u + 33u) * 8u : (64u + 32u) * 8u;
-      st = outer ? kout : kin;
+      cs = outer ? kout : kin;
     }
-    acc = sha256_compress(st, blk);
+    acc = sha256_compress(cs, blk);
     // ---- where the result goes ----
     if (step == 2 || step == 9 || step == 17) kk = acc;                      // K = HMAC(K, ...)
     else if (pad_in) kin = acc;
@@ -159,16 +179,30 @@ __device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint
         const uint32_t lo = v.h[7 - i], hi = i < 7 ? v.h[6 - i] : 0u;
         cand.w[i] = (lo >> 4) | (hi << 28);
       }
-      if (!u256_is_zero(cand) && u256_lt(cand, U256_N)) break;
-      if (++rejected == MAX_REJECTED) {  // 64: unreachable in practice; the caller reports SP_SIGN_RETRY for k = 0
-#pragma unroll
-        for (int i = 0; i < 8; ++i) cand.w[i] = 0;
-        break;
-      }
+      if (!u256_is_zero(cand) && u256_lt(cand, U256_N)) { accepted = true; break; }
+      if (++rejected == max_rejected) break;
     }
     step = step == 21 ? 14 : step + 1;
   }
+  if (!accepted) {
+    st.kin = kin; st.kout = kout; st.v = v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cand.w[i] = 0;
+  }
   if (rejected_out) *rejected_out = rejected;
+  return accepted;
+}
+
+// The whole generator in one call (the scalar path and batches below the compaction threshold).  After 64 rejected
+// candidates - unreachable in practice - the nonce is 0 and the caller reports SP_SIGN_RETRY.
+// MAX_REJECTED / rejected_out: for tools/ubench/rfc6979_chain.hip (what the retry chain costs).
+template <int MAX_REJECTED = 64>
+__device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint64_t seed, int* rejected_out = nullptr) {
+  rfc_input in;
+  rfc6979_prepare(z, d, seed, in);
+  rfc_state st;
+  u256 cand;
+  (void)rfc6979_run<true>(in, st, MAX_REJECTED, cand, rejected_out);
   return cand;
 }
 

@@ -177,6 +177,61 @@ def test_verify_double_branch(sig):
     pytest.skip("no suitable k found")
 
 
+def test_compacted_signer_equals_the_one_kernel_signer():
+    """Round 4: from 4096 items on, the device signer cuts the RFC 6979 nonce phase into rounds with compaction of
+    the rejected candidates in between (ecdsa.hip enqueue_sign_rfc6979).  (a) The reference's goldens (256 signatures
+    incl. the seeded retries, the pad rule, NumPy and device-pointer entry points) through that pipeline, forced on
+    for every batch size in a subprocess; (b) 150 000 random items incl. invalid ones through it in this process
+    against the one-kernel signer of a subprocess, bit for bit."""
+    import hashlib
+    import subprocess
+    import sys
+    import torch
+    from starkperp import batch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STARKPERP_SIGN_COMPACT_MIN="1", STARKPERP_WINDOW_BITS="16")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ecdsa.py"), "-m", "gpu", "-q",
+                          "-k", "test_sign_all or test_sign_on_device_pointers_and_numpy or test_reference_signature"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+    def run_batch():
+        n = 150000
+        g = torch.Generator().manual_seed(77)
+        z = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, generator=g)
+        d = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, generator=g)
+        z[:, 3] &= (1 << 58) - 1
+        d[:, 3] &= (1 << 58) - 1
+        z[5, 3] = 1 << 60          # message hash >= 2^251: SIGN_BAD_INPUT
+        d[7] = 0                   # private key 0: SIGN_BAD_INPUT
+        seeds = torch.randint(0, 2**40, (n,), dtype=torch.int64, generator=g)
+        seeds[::3] = 0
+        r, s, st = batch.sign_dev(z.cuda(), d.cuda(), seeds=seeds.cuda())
+        torch.cuda.synchronize()
+        st = st.cpu()
+        assert int(st[5]) != 0 and int(st[7]) != 0 and int((st == 0).sum()) == n - 2
+        return hashlib.sha256(r.cpu().numpy().tobytes() + s.cpu().numpy().tobytes() + st.numpy().tobytes()).hexdigest()
+
+    ours = run_batch()  # 150 000 >= the default threshold (4096): compacted
+    probe = (
+        "import os, sys, hashlib, torch\n"
+        "sys.path[:0] = [%r]\n"
+        "from starkperp import batch\n"
+        "n = 150000\n"
+        "g = torch.Generator().manual_seed(77)\n"
+        "z = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, generator=g)\n"
+        "d = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, generator=g)\n"
+        "z[:, 3] &= (1 << 58) - 1; d[:, 3] &= (1 << 58) - 1; z[5, 3] = 1 << 60; d[7] = 0\n"
+        "seeds = torch.randint(0, 2**40, (n,), dtype=torch.int64, generator=g); seeds[::3] = 0\n"
+        "r, s, st = batch.sign_dev(z.cuda(), d.cuda(), seeds=seeds.cuda()); torch.cuda.synchronize()\n"
+        "print(hashlib.sha256(r.cpu().numpy().tobytes() + s.cpu().numpy().tobytes() + st.cpu().numpy().tobytes()).hexdigest())\n"
+    ) % os.path.join(root, "stark-perpetual_amd")
+    env = dict(os.environ, STARKPERP_SIGN_COMPACT_MIN="0")
+    out = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert out.stdout.split()[-1] == ours
+
+
 def test_reference_signature_kat(sig):
     a = load("reference_kats.json")["party_a_order"]
     z, pub = h(a["message_hash"]), h(a["public_key"])
