@@ -639,7 +639,7 @@ def main():
             "hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hbm_gbs / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_hash": ALGO_BYTES_PER_HASH,
-                    "note": "the roofline the contract names; this kernel is integer-ALU bound (about 31 k VALU "
+                    "note": "the roofline the contract names; this kernel is integer-ALU bound (about 28 k VALU "
                             "instructions per 96 algorithmic bytes), so the HBM fraction says nothing about it"},
             "whole_region": valu_issue(value / max(world, 1), wbits,
                                        "every kernel of the timed region: hashes/s per GPU over the wall time "
