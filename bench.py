@@ -246,6 +246,13 @@ def summary_object(result):
         "ms_per_step": result.get("ms_per_step"),
         "roofline_frac_bulk_launches": g(result, "roofline", "frac"),
         "roofline_frac_whole_region": g(result, "roofline", "whole_region", "frac"),
+        "roofline_frac_at_held_clock": g(result, "roofline", "frac_at_held_clock"),
+        "sclk_mhz_median": g(result, "telemetry", "sclk_mhz_median"),
+        "power_w_median": g(result, "telemetry", "power_w_median"),
+        "timed_total_s": g(result, "timed_regions", "total_s"),
+        "burst_pedersen_hashes_per_sec": g(result, "burst", "value"),
+        "sustained_over_burst": result.get("sustained_over_burst"),
+        "lib_sha256_16": (g(result, "build", "lib_sha256") or "")[:16],
         "airfri_commits_per_sec": g(result, "airfri", "commits_per_sec"),
         "airfri_seconds_per_job": g(result, "airfri", "seconds_per_job_one_stream"),
         "airfri_roofline_frac": g(result, "airfri", "roofline", "frac"),
@@ -384,6 +391,246 @@ def pmc_traffic(kernel, this_config, files=("r04_pmc_traffic.json", "r03_pmc_tra
     return None
 
 
+def self_spawn(n):
+    """bench.py --gpus N started without torch.distributed.run: launch N ranks on this node through it (one process
+    per GPU, rendezvous on 127.0.0.1 at a free port), same arguments, stdout / stderr passed through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench: --gpus %d without RANK/WORLD_SIZE: launching %s\n" % (n, " ".join(cmd[1:8])))
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
+class Telemetry:
+    """Shader clock, package power and junction temperature of ONE device, sampled from a side thread while the
+    timed regions run (the 50 ms window of rounds 1 - 4 sat inside the power controller's ramp,
+    profiles/r03_power_clock_bulk.txt).  Source: the amdgpu hwmon files of the PCI function HIP reports for the
+    device (freq1_input = sclk in Hz, power1_input = socket power in uW, temp2_input = junction in mC); a box whose
+    sysfs does not show them falls back to `rocm-smi --json`.  Reading costs well under a millisecond and the
+    timed loop spends its time inside ctypes calls that release the GIL."""
+
+    def __init__(self, dev_index, period_s=0.02):
+        import threading
+        self.period = period_s
+        self.samples = []  # (t, sclk_mhz, power_w, temp_c)
+        self._stop = threading.Event()
+        self._thread = None
+        self.source = None
+        self._files = self._find_hwmon(dev_index)
+        if self._files:
+            self.source = "sysfs hwmon " + self._files["dir"]
+        else:
+            import shutil
+            if shutil.which("rocm-smi"):
+                self.source = "rocm-smi --showpower --showclocks --json (card0)"
+                self.period = max(period_s, 0.25)
+
+    @staticmethod
+    def _find_hwmon(dev_index):
+        import glob
+        try:
+            # the HIP runtime this process already runs on (torch's, loaded RTLD_GLOBAL by starkperp._lib): never
+            # dlopen a second libamdhip64 by name
+            bus = None
+            try:
+                buf = ctypes.create_string_buffer(64)
+                if ctypes.CDLL(None).hipDeviceGetPCIBusId(buf, 64, int(dev_index)) == 0:
+                    bus = buf.value.decode().lower()
+            except (AttributeError, OSError):
+                bus = None
+            if not bus:
+                import torch
+                pr = torch.cuda.get_device_properties(int(dev_index))
+                bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for d in glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bus):
+                if os.path.exists(os.path.join(d, "freq1_input")) and (
+                        os.path.exists(os.path.join(d, "power1_input")) or os.path.exists(os.path.join(d, "power1_average"))):
+                    return {"dir": d, "bus": bus, "sclk": os.path.join(d, "freq1_input"),
+                            "power": os.path.join(d, "power1_input") if os.path.exists(os.path.join(d, "power1_input"))
+                            else os.path.join(d, "power1_average"),
+                            "temp": os.path.join(d, "temp2_input"), "cap": os.path.join(d, "power1_cap")}
+        except Exception:  # noqa: BLE001 - telemetry never breaks the measurement
+            return None
+        return None
+
+    @staticmethod
+    def _read_num(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:  # noqa: BLE001
+            return None
+
+    def sample(self):
+        t = time.perf_counter()
+        if self._files:
+            sclk, pw, tc = (self._read_num(self._files[k]) for k in ("sclk", "power", "temp"))
+            self.samples.append((t, None if sclk is None else sclk / 1e6, None if pw is None else pw / 1e6,
+                                 None if tc is None else tc / 1e3))
+        elif self.source:
+            import subprocess
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True,
+                                     text=True, timeout=10).stdout
+                card = next(iter(json.loads(out).values()))
+                sclk = pw = None
+                for k, v in card.items():
+                    if k.lower().startswith("sclk clock speed"):
+                        sclk = float("".join(ch for ch in v if ch.isdigit() or ch == "."))
+                    if "power (w)" in k.lower():
+                        pw = float(v)
+                self.samples.append((t, sclk, pw, None))
+            except Exception:  # noqa: BLE001
+                pass
+
+    def start(self):
+        import threading
+        if not self.source or self._thread is not None:
+            return self
+
+        def run():
+            while not self._stop.is_set():
+                self.sample()
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+
+    def window(self, t0, t1):
+        """Median / min / max of the samples taken between the perf_counter times t0 and t1."""
+        rows = [s for s in self.samples if t0 <= s[0] <= t1]
+
+        def stat(i):
+            v = sorted(x[i] for x in rows if x[i] is not None)
+            if not v:
+                return None
+            return {"median": v[len(v) // 2], "min": v[0], "max": v[-1]}
+        sclk, pw, tc = stat(1), stat(2), stat(3)
+        return {"samples": len(rows), "seconds": t1 - t0,
+                "sclk_mhz_median": sclk and sclk["median"], "sclk_mhz_min": sclk and sclk["min"],
+                "sclk_mhz_max": sclk and sclk["max"],
+                "power_w_median": pw and pw["median"], "power_w_min": pw and pw["min"], "power_w_max": pw and pw["max"],
+                "junction_c_median": tc and tc["median"]}
+
+    def describe(self):
+        cap = self._read_num(self._files["cap"]) if self._files else None
+        return {"source": self.source, "period_s": self.period, "pci_bus": self._files and self._files["bus"],
+                "power_cap_w": None if cap is None else cap / 1e6}
+
+
+def build_provenance(lib):
+    """Which binary produced this line: sha256 of the loaded libstarkperp.so, what the
+    library says it was compiled with (sp_build_info: compiler, HIP version, offload arch, compile date) and the
+    toolchain found on THIS box."""
+    import hashlib
+    import subprocess
+    from starkperp import _lib
+    out = {"lib": os.path.relpath(_lib.LIB_PATH, ROOT)}
+    try:
+        h = hashlib.sha256()
+        with open(_lib.LIB_PATH, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 20), b""):
+                h.update(blk)
+        out["lib_sha256"] = h.hexdigest()
+        out["lib_bytes"] = os.path.getsize(_lib.LIB_PATH)
+        out["lib_mtime_utc"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(_lib.LIB_PATH)))
+    except OSError as e:
+        out["lib_sha256"] = "unreadable: %s" % e
+    try:
+        lib.sp_build_info.restype = ctypes.c_char_p
+        out["compiled_with"] = lib.sp_build_info().decode()
+    except Exception as e:  # noqa: BLE001
+        out["compiled_with"] = "sp_build_info unavailable: %s" % e
+    try:
+        v = subprocess.run(["hipcc", "--version"], capture_output=True, text=True, timeout=20).stdout.splitlines()
+        out["hipcc_on_this_box"] = "; ".join(l.strip() for l in v[:2])
+    except Exception as e:  # noqa: BLE001
+        out["hipcc_on_this_box"] = "not found (%s)" % type(e).__name__
+    try:
+        out["bench_py_sha16"] = hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16]
+    except OSError:
+        pass
+    return out
+
+
+TELEMETRY = None
+
+
+def dist_report(torch, dist, dev, dev_index, world, rank, forced, value, lib):
+    """What the process group looked like - collective: every rank calls it.  Rank 0 gets
+    {backend, world_size, rccl_version, per-rank device name / PCI bus / free HBM / window bits, the N x N
+    hipDeviceCanAccessPeer matrix, the link types rocm-smi reports}; nothing here may break the line."""
+    info = {"backend": dist.get_backend(), "world_size": world, "forced_at_one_gpu": forced}
+    try:
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        pr = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device_index": dev_index, "name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None),
+                "pci": "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                             getattr(pr, "pci_device_id", 0)),
+                "free_hbm_gib": free_b / 2**30, "total_hbm_gib": total_b / 2**30,
+                "window_bits": int(lib.sp_window_bits()), "table_gib": lib.sp_table_bytes() / 2**30,
+                "pid": os.getpid(), "cpus_allowed": len(os.sched_getaffinity(0)),
+                "local_hashes_per_sec": value}
+    except Exception as e:  # noqa: BLE001
+        mine = {"rank": rank, "error": repr(e)}
+    try:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        info["ranks"] = gathered
+    except Exception as e:  # noqa: BLE001
+        info["ranks"] = [mine]
+        info["ranks_error"] = repr(e)
+    if rank != 0:
+        return info
+    lv = [r.get("local_hashes_per_sec") for r in info["ranks"] if isinstance(r, dict) and r.get("local_hashes_per_sec")]
+    if lv:
+        info["per_rank_value"] = {"min": min(lv), "max": max(lv), "unit": "hashes/s on a rank's own clock (its 2^16-leaf "
+                                  "subtrees per step; the job's value uses the slowest rank's region)"}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+    except Exception as e:  # noqa: BLE001
+        info["rccl_version"] = "unknown (%s)" % type(e).__name__
+    info["env"] = {k: os.environ[k] for k in ("NCCL_DEBUG", "NCCL_P2P_DISABLE", "NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE",
+                                               "HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
+                                               "GPU_MAX_HW_QUEUES") if k in os.environ}
+    try:  # peer access between the devices the ranks run on, from this process (it sees all of them under torchrun)
+        devs = [r.get("device_index", i) for i, r in enumerate(info["ranks"])]
+        n_vis = torch.cuda.device_count()
+        info["visible_devices"] = n_vis
+        info["peer_access"] = [[(1 if a == b else int(torch.cuda.can_device_access_peer(a, b)))
+                                if a < n_vis and b < n_vis else None for b in devs] for a in devs]
+    except Exception as e:  # noqa: BLE001
+        info["peer_access"] = "unavailable (%s)" % type(e).__name__
+    if world > 1:
+        try:
+            import subprocess
+            t = subprocess.run(["rocm-smi", "--showtopotype", "--json"], capture_output=True, text=True, timeout=30).stdout
+            info["link_types"] = json.loads(t)
+        except Exception as e:  # noqa: BLE001
+            info["link_types"] = "unavailable (%s)" % type(e).__name__
+    return info
+
+
+def median(v):
+    s = sorted(v)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -424,6 +671,14 @@ def main():
                     help="--gpus 1 only: create a world-size-1 RCCL process group anyway and take every branch the "
                          "N > 1 runs take (sub-root all_gather + top forest, max / min reductions of the timings, the "
                          "sharded AIR+FRI path with --workload airfri) - the one-GPU rehearsal of the multi-GPU launch")
+    ap.add_argument("--min-timed-s", type=float, default=float(os.environ.get("STARKPERP_BENCH_MIN_TIMED_S", "2.0")),
+                    help="the timed regions (each EXACTLY --steps steps between fences) are repeated until this many "
+                         "seconds have been timed; value = the median region of that sustained window")
+    ap.add_argument("--preheat-s", type=float, default=float(os.environ.get("STARKPERP_BENCH_PREHEAT_S", "1.0")),
+                    help="seconds of the timed call itself issued (untimed) in front of the sustained window, so that "
+                         "the power controller has settled (profiles/r03_power_clock_bulk.txt: ~0.7 s)")
+    ap.add_argument("--burst-s", type=float, default=0.05,
+                    help="the 50 ms window of rounds 1 - 4, taken first, straight out of idle: reported as `burst`")
     ap.add_argument("--no-airfri", action="store_true",
                     help="merkle workload: skip the `airfri` object (the 2^20-row AIR+FRI half of the metric; at N > 1 "
                          "independent jobs on every GPU)")
@@ -435,8 +690,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # `python bench.py --gpus N` without a launcher: start the N ranks ourselves,
+            # exactly as the driver would, and hand their single JSON line through
+            return self_spawn(args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # Test hook for boxes with ONE GPU (tests/test_gpu_bench_ranks.py): every rank on device 0 and the
@@ -476,13 +734,31 @@ def main():
     from starkperp import _lib
     from starkperp.distributed import combine_forest_dev
 
+    wide_error = None
     try:
         lib = _lib.ensure_init(dev_index, args.window_bits or None)
     except _lib.StarkPerpError as e:
         if not args.window_bits:
             raise
-        sys.stderr.write("bench: %d-bit tables unavailable (%s); using the library default\n" % (args.window_bits, e))
+        wide_error = str(e)
+        lib = None
+    if dist is not None and args.window_bits:
+        # ONE table plan for the job: a single rank that cannot allocate the wide tables (a GPU
+        # with less free HBM) takes every rank to the library default - ranks on different plans would still agree on
+        # every hash, but the weak-scaling figure would mix two kernels' rates
+        okt = torch.tensor([0 if lib is None else 1], dtype=torch.int32, device=dev)
+        if dist.get_backend() == "gloo":
+            okt = okt.cpu()
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0 and lib is not None:
+            wide_error = "another rank could not allocate the %d-bit tables" % args.window_bits
+            _lib.load().sp_shutdown()
+            lib = None
+    if lib is None:
+        sys.stderr.write("bench: %d-bit tables unavailable (%s); using the library default\n" % (args.window_bits, wide_error))
         lib = _lib.ensure_init(dev_index, None)
+    global TELEMETRY
+    TELEMETRY = Telemetry(dev_index).start() if rank == 0 else None
     if args.workload == "airfri":
         return run_airfri(args, torch, dist, lib, _lib, dev, rank, world)
     n_leaves = 1 << HEIGHT
@@ -562,32 +838,65 @@ def main():
             timed_targets.append((sl, nb))
             sl["levels"][nb][n_leaves * nb:] = 0
     fence()
-    # One region = EXACTLY --steps steps between two fences.  A region of 20 lockstep trees lasts ~2 ms, so
-    # the region is repeated until >= 50 ms have been timed and the MEDIAN region is reported (min / max next
-    # to it); every region is bracketed by barrier + synchronize on both sides.
-    MAX_REGIONS, MIN_TIMED_S = 64, 0.05
-    _lib.check(lib.sp_profile_begin(MAX_REGIONS * len(timed_plan) * launches_per_call), "profile_begin")
-    regions = []
-    while True:
-        t0 = time.perf_counter()
-        for nb in timed_plan:
-            issue(nb)
-        fence()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            if dist.get_backend() == "gloo":
-                t = t.cpu()
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        regions.append(dt)
-        if sum(regions) >= MIN_TIMED_S or len(regions) >= MAX_REGIONS:
-            break
-    k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
-    _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)),
-               "profile_end")
+    # One region = EXACTLY --steps steps between two fences (barrier + synchronize on both sides); a region of 20
+    # lockstep trees lasts ~1.7 ms.  Three windows of such regions, one after the other:
+    #   burst      --burst-s (50 ms) straight after the CPU-only set-up: what rounds 1 - 4 reported.  The power
+    #              controller is still ramping (clock above its steady state), so this is NOT the headline any more;
+    #   pre-heat   --preheat-s (1 s) of the same call, untimed;
+    #   sustained  regions repeated until --min-timed-s (2 s) have been timed: `value` = the MEDIAN region of this
+    #              window, with the shader clock and package power sampled beside it (Telemetry).
+    # Every rank takes the same decisions: a region's time is MAX-reduced over the ranks before it is used.
+    MAX_REGIONS = 1 << 15
+
+    def run_regions(min_s, max_regions):
+        regs = []
+        w0_ = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            for nb in timed_plan:
+                issue(nb)
+            fence()
+            dt = time.perf_counter() - t0
+            local_regions.append(dt)
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                if dist.get_backend() == "gloo":
+                    t = t.cpu()
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            regs.append(dt)
+            if sum(regs) >= min_s or len(regs) >= max_regions:
+                break
+        return regs, w0_, time.perf_counter()
+
+    local_regions = []  # this rank's own clock for every region (the MAX over ranks is what `value` uses)
+
+    def profiled(min_s, max_regions, est_regions):
+        """run_regions with HIP events around every ped_accumulate_kernel launch of the window."""
+        # levels of more than 65 536 hashes per call: at most log2(trees) of them
+        slots = min(int(est_regions) * sum(nb.bit_length() + 1 for nb in timed_plan) + 64, 100000)
+        _lib.check(lib.sp_profile_begin(slots), "profile_begin")
+        regs, a, b = run_regions(min_s, max_regions)
+        k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)),
+                   "profile_end")
+        return regs, a, b, (k_ms.value, int(k_launches.value), int(k_units.value))
+
+    idle_tel = TELEMETRY.window(time.perf_counter() - 0.5, time.perf_counter()) if TELEMETRY else None
+    burst_regions, burst_t0, burst_t1, burst_prof = profiled(args.burst_s, 64, 64)
+    burst_med = median(burst_regions)
+    preheat_regions, _, _ = run_regions(args.preheat_s, MAX_REGIONS) if args.preheat_s > 0 else ([], 0, 0)
+    est = args.min_timed_s / max(burst_med, 1e-5) * 1.25 + 16
+    del local_regions[:]
+    regions, sus_t0, sus_t1, (k_ms_v, k_launches_v, k_units_v) = profiled(args.min_timed_s, MAX_REGIONS, est)
+    local_value = (n_leaves - 1) * args.steps / median(local_regions)  # this rank's own subtrees over its own clock
+
+    class _V:  # the names the roofline code below reads
+        def __init__(self, v):
+            self.value = v
+    k_ms, k_launches, k_units = _V(k_ms_v), _V(k_launches_v), _V(k_units_v)
     srt = sorted(regions)
-    elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    elapsed = median(regions)
 
     hashes_per_step = world * (n_leaves - 1) + (world - 1)
     value = hashes_per_step * args.steps / elapsed
@@ -597,7 +906,8 @@ def main():
     # timed jobs together and the job rate of the node is n_gpus x the slowest rank's rate.
     airfri_multi = None
     if dist is not None and not args.no_airfri:
-        loc = airfri_object(torch, lib, _lib, dev, False, brief=True, fence=fence)
+        loc = airfri_object(torch, lib, _lib, dev, False, brief=True, fence=fence, min_timed_s=args.min_timed_s,
+                            preheat_s=0.7 * args.preheat_s)
         t = torch.tensor([loc["commits_per_sec"], 1.0 / loc["seconds_per_job_one_stream"]], dtype=torch.float64, device=dev)
         if dist.get_backend() == "gloo":
             t = t.cpu()
@@ -611,6 +921,8 @@ def main():
                            "the slowest rank's rate (seconds_per_job_one_stream = the slowest rank's); ONE trace over "
                            "all ranks is `--workload airfri`")
         airfri_multi = loc
+
+    dist_info = dist_report(torch, dist, dev, dev_index, world, rank, forced_dist, local_value, lib) if dist is not None else None
 
     if rank == 0:
         wbits = int(lib.sp_window_bits())
@@ -644,7 +956,33 @@ def main():
             "whole_region": valu_issue(value / max(world, 1), wbits,
                                        "every kernel of the timed region: hashes/s per GPU over the wall time "
                                        "(latency-bound upper levels included)"),
+            "frac_basis": "peak at the NOMINAL 2.4 GHz with c_mix = %.2f cycles per wave64 instruction (the basis since "
+                          "round 4; rounds 1 - 3 printed what is now frac_at_flat_4_cycle_peak)" % valu_cycles_per_instr(),
         })
+        tel_sus = TELEMETRY.window(sus_t0, sus_t1) if TELEMETRY else None
+        tel_burst = TELEMETRY.window(burst_t0, burst_t1) if TELEMETRY else None
+        held_mhz = tel_sus and tel_sus.get("sclk_mhz_median")
+        if held_mhz and roof.get("achieved"):
+            # the same issue rate against the clock the chip HELD while it was measured (the package sits at its
+            # power limit under this kernel): what the kernel reaches of the attainable issue rate
+            held_peak = VALU_PEAK_SIMDS * held_mhz * 1e6 / valu_cycles_per_instr()
+            roof["held_clock_mhz"] = held_mhz
+            roof["frac_at_held_clock"] = roof["achieved"] / held_peak
+            if roof.get("whole_region"):
+                roof["whole_region"]["frac_at_held_clock"] = roof["whole_region"]["achieved"] / held_peak
+        b_ms, b_l, b_u = burst_prof
+        burst_value = hashes_per_step * args.steps / burst_med
+        burst = {"value": burst_value, "unit": "hashes/s", "median_s": burst_med, "count": len(burst_regions),
+                 "total_s": sum(burst_regions),
+                 "bulk_kernel_hashes_per_sec": (b_u / (b_ms / 1e3)) if b_ms > 0 else None,
+                 "telemetry": tel_burst,
+                 "note": "the %.0f ms window rounds 1 - 4 reported as `value`, taken first, straight after the CPU-only "
+                         "set-up: the power controller has not settled yet" % (1e3 * args.burst_s)}
+        telemetry = dict(TELEMETRY.describe(), sustained=tel_sus, burst=tel_burst, idle_before=idle_tel,
+                         sclk_mhz_median=held_mhz, power_w_median=tel_sus and tel_sus.get("power_w_median"),
+                         note="rank 0's device, sampled every %.0f ms from a side thread while the regions run; "
+                              "`sustained` covers exactly the window `value` comes from"
+                              % (1e3 * TELEMETRY.period)) if TELEMETRY else None
         result = {
             "metric": "pedersen_hashes_per_sec",
             "value": value,
@@ -653,10 +991,18 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "timed_regions": {"count": len(regions), "median_s": elapsed, "min_s": srt[0], "max_s": srt[-1],
-                              "total_s": sum(regions),
-                              "note": "value and ms_per_step come from the MEDIAN region; every region is exactly "
-                                      "--steps steps between barrier + synchronize fences, repeated until 50 ms are timed"},
+            "timed_regions": {"count": len(regions), "median_s": elapsed, "mean_s": sum(regions) / len(regions),
+                              "min_s": srt[0], "max_s": srt[-1], "p10_s": srt[len(srt) // 10],
+                              "p90_s": srt[(9 * len(srt)) // 10], "total_s": sum(regions),
+                              "preheat_s": sum(preheat_regions), "preheat_regions": len(preheat_regions),
+                              "value_from_mean_region": hashes_per_step * args.steps * len(regions) / sum(regions),
+                              "note": "SUSTAINED: after %.2f s of the same call as pre-heat, the region (exactly "
+                                      "--steps steps between barrier + synchronize fences) is repeated until %.1f s "
+                                      "have been timed; value and ms_per_step come from the MEDIAN region of that "
+                                      "window" % (sum(preheat_regions), args.min_timed_s)},
+            "burst": burst,
+            "sustained_over_burst": value / burst_value if burst_value else None,
+            "telemetry": telemetry,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -667,7 +1013,9 @@ def main():
                 "tree_height": HEIGHT,
                 "leaves_per_gpu": n_leaves,
                 "hashes_per_step": hashes_per_step,
-                "trees_per_call": B,
+                "trees_in_timed_call": timed_plan[0] if len(set(timed_plan)) == 1 else max(timed_plan),
+                "calls_per_region": len(timed_plan),
+                "trees_per_call_cap": B,
                 "streams": n_streams,
                 "timed_calls": timed_plan,
                 "ms_per_step_note": "steps advance in lockstep: ms_per_step is wall time / steps, not the latency "
@@ -681,9 +1029,13 @@ def main():
         }
         if dist is not None:
             result["combine_matches_recomputed"] = combine_check(slots[0], world, _lib)
-            result["dist"] = {"backend": dist.get_backend(), "world_size": world, "forced_at_one_gpu": forced_dist}
+            result["dist"] = dist_info
+            if wide_error:
+                result["dist"]["window_plan_fallback"] = wide_error
+        result["build"] = build_provenance(lib)
         if not args.no_airfri:
-            result["airfri"] = (airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline) if world == 1
+            result["airfri"] = (airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline, min_timed_s=args.min_timed_s,
+                                              preheat_s=0.7 * args.preheat_s) if world == 1
                                 else airfri_multi)
             if forced_dist and airfri_multi is not None:  # the N > 1 reduction of the job rates, rehearsed at N = 1
                 result["airfri_dist_rehearsal"] = {k: airfri_multi[k] for k in
@@ -929,7 +1281,7 @@ def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, tr
     dist.destroy_process_group()
 
 
-def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None):
+def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None, min_timed_s=2.0, preheat_s=0.7):
     """BASELINE.json configs[3], the second half of the metric: one 2^20-row Pedersen-step trace ->
     4-column LDE to 2^22 -> commit -> composition -> commit -> 16 folds with 15 layer commits (25.2 M
     Pedersen hashes).  Inputs (the witness) resident in HBM.  commits_per_sec times independent jobs
@@ -974,14 +1326,8 @@ def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None):
     hashes = 4 * n_lde + n_lde + sum((1 << k) for k in range(7, 22))
     out = {"workload": "2^20-row trace, blowup 4, 11 constraints, folds down to 64 points (BASELINE.json configs[3])",
            "pedersen_hashes_per_job": hashes, "data": "synthetic", "dtype": "u32x9 (29-bit limbs) mod p"}
-    # one job after the other on one stream, with HIP events around the bulk hash launches
     job()
     torch.cuda.synchronize()
-    _lib.check(lib.sp_profile_begin(3 * 64), "profile_begin")
-    t_seq = timed(job, 2)
-    k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
-    _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)), "profile_end")
-    out["seconds_per_job_one_stream"] = t_seq
     streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
 
     def pipelined(njobs):
@@ -990,14 +1336,39 @@ def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None):
                 job()
         torch.cuda.synchronize()
 
+    # Three windows, like the headline: a burst of 9 jobs straight away (what rounds 1 - 4
+    # reported), pre-heat, then batches of 9 jobs until `min_timed_s` seconds have been timed: commits_per_sec is the
+    # rate over that whole sustained window, with the clock and power the chip held in it.
     pipelined(3)
     if fence is not None:
         fence()
     t0 = time.perf_counter()
     pipelined(9)
-    out["commits_per_sec"] = 9 / (time.perf_counter() - t0)
-    out["commits_per_sec_note"] = "9 independent jobs alternating over 3 streams (tree tops of one job beside the row " \
-                                  "hashing of the next); one job at a time: %.1f commits/s" % (1.0 / t_seq)
+    burst_rate = 9 / (time.perf_counter() - t0)
+    heat_t0 = time.perf_counter()
+    while time.perf_counter() - heat_t0 < preheat_s:
+        pipelined(9)
+    if fence is not None:
+        fence()
+    n_batches = max(1, int(min_timed_s * burst_rate / 9 + 0.999))  # fixed in advance: ranks stay in step
+    sus_t0 = time.perf_counter()
+    for _ in range(n_batches):
+        pipelined(9)
+    sus_t1 = time.perf_counter()
+    out["commits_per_sec"] = 9 * n_batches / (sus_t1 - sus_t0)
+    out["commits_per_sec_burst"] = burst_rate
+    out["timed"] = {"jobs": 9 * n_batches, "seconds": sus_t1 - sus_t0, "preheat_s": sus_t0 - heat_t0,
+                    "telemetry": TELEMETRY.window(sus_t0, sus_t1) if TELEMETRY else None}
+    # one job after the other on one stream (the chip is hot now), with HIP events around the bulk hash launches
+    _lib.check(lib.sp_profile_begin(3 * 64), "profile_begin")
+    t_seq = timed(job, 2)
+    k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)), "profile_end")
+    out["seconds_per_job_one_stream"] = t_seq
+    out["commits_per_sec_note"] = "%d independent jobs alternating over 3 streams (tree tops of one job beside the row " \
+                                  "hashing of the next) in %.2f s after %.2f s of pre-heat; the first 9 jobs out of idle " \
+                                  "ran at %.1f commits/s; one job at a time: %.1f commits/s" % (
+                                      9 * n_batches, sus_t1 - sus_t0, sus_t0 - heat_t0, burst_rate, 1.0 / t_seq)
     n_l = max(int(k_launches.value), 1)
     rate = (k_units.value / n_l) / ((k_ms.value / 1e3) / n_l) if k_ms.value > 0 else 0.0
     roof = valu_issue(rate, int(lib.sp_window_bits()),
@@ -1010,6 +1381,10 @@ def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None):
                  "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
                  "hbm": {"achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}})
+    held = ((out["timed"]["telemetry"] or {}).get("sclk_mhz_median")) if out.get("timed") else None
+    if held and roof.get("achieved"):
+        roof["held_clock_mhz"] = held
+        roof["frac_at_held_clock"] = roof["achieved"] / (VALU_PEAK_SIMDS * held * 1e6 / valu_cycles_per_instr())
     if brief:
         out["roofline"] = roof
         return out
@@ -1084,13 +1459,25 @@ def extras(torch, lib, _lib, dev, stream):
     n = 1 << 22
     x, y = seeded_felts(torch, n, 7, dev), seeded_felts(torch, n, 8, dev)
     o = torch.empty_like(x)
-    s = timed(lambda: _lib.check(lib.sp_pedersen_batch_dev(x.data_ptr(), y.data_ptr(), o.data_ptr(), None,
-                                                           n, stream), "ped"), 3)
+    bulk = lambda: _lib.check(lib.sp_pedersen_batch_dev(x.data_ptr(), y.data_ptr(), o.data_ptr(), None,  # noqa: E731
+                                                        n, stream), "ped")
+    s_burst = timed(bulk, 3)
+    timed(bulk, max(3, int(0.5 / s_burst)))  # pre-heat
+    b_t0 = time.perf_counter()
+    s = timed(bulk, max(3, int(1.0 / s_burst)))  # sustained: about one second of back-to-back 2^22-hash batches
+    b_t1 = time.perf_counter()
     out["bulk_pedersen_hashes_per_sec"] = n / s
+    out["bulk_pedersen_hashes_per_sec_burst"] = n / s_burst
     out["bulk_pedersen_batch"] = n
+    out["bulk_pedersen_telemetry"] = TELEMETRY.window(b_t0, b_t1) if TELEMETRY else None
     del x, y, o
     out["valu_issue"] = valu_issue(n / s, int(lib.sp_window_bits()),
                                    "2^22 independent hashes, accumulate + finish kernels (bulk_pedersen_hashes_per_sec)")
+    _held = (out["bulk_pedersen_telemetry"] or {}).get("sclk_mhz_median")
+    if _held and out["valu_issue"]:
+        out["valu_issue"]["held_clock_mhz"] = _held
+        out["valu_issue"]["frac_at_held_clock"] = out["valu_issue"]["achieved"] / (
+            VALU_PEAK_SIMDS * _held * 1e6 / valu_cycles_per_instr())
 
     # BASELINE.json configs[0]: the reference's scalar API, one call at a time through the import overlay
     # (host-inclusive latency per call; the reference itself: 11 ms / 16 ms / 60 ms per hash / sign / verify)

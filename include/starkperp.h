@@ -106,6 +106,11 @@ int sp_is_initialised(void);
 int sp_window_bits(void);
 size_t sp_table_bytes(void);
 int sp_synchronize(void* stream);
+/* Build provenance (no reference counterpart: the reference is interpreted Python): one static line naming the
+ * compiler, the HIP version, the offload architecture, the compile date of the library and the sanitizer it was
+ * instrumented with, if any - bench.py prints it next to the sha256 of the .so, so that the binary a record was
+ * produced by can be identified.  Callable before sp_init. */
+const char* sp_build_info(void);
 
 /* Measurement aid: between sp_profile_begin and sp_profile_end every launch of the dominant kernel
  * (ped_accumulate_kernel) is bracketed by HIP events on the stream it is launched on; _end returns

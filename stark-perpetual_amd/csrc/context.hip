@@ -582,6 +582,16 @@ size_t sp_table_bytes(void) {  // all contexts
   return total;
 }
 
+#ifndef SP_SANITIZER
+#define SP_SANITIZER "none"
+#endif
+#define SP_STR2(x) #x
+#define SP_STR(x) SP_STR2(x)
+const char* sp_build_info(void) {
+  return "libstarkperp; compiler: clang " __clang_version__ "; HIP " SP_STR(HIP_VERSION_MAJOR) "." SP_STR(HIP_VERSION_MINOR) "." SP_STR(
+      HIP_VERSION_PATCH) "; offload-arch: gfx950; compiled: " __DATE__ " " __TIME__ "; sanitizer: " SP_SANITIZER;
+}
+
 int sp_synchronize(void* stream) {
   SP_REQUIRE_READY();
   SP_HIP(hipStreamSynchronize((hipStream_t)stream));

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "sp_window_bits": (ctypes.c_int, []),
     "sp_table_bytes": (ctypes.c_size_t, []),
     "sp_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "sp_build_info": (ctypes.c_char_p, []),
     "sp_profile_begin": (ctypes.c_int, [ctypes.c_size_t]),
     "sp_profile_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sp_pedersen_batch": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_size_t]),
