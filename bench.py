@@ -653,7 +653,7 @@ def main():
                          "streams) for the TIMED steps; must sum to --steps.  Default: see plan()")
     ap.add_argument("--window-bits", type=int, default=26,
                     help="log2 of the entries per signed window of the Pedersen tables: 26 = 75 GiB of the "
-                         "288 GB HBM as tables, 19 table entries per hash (~0.15 s to build, outside the timed "
+                         "288 GB HBM as tables, 19 table entries per hash (0.12 - 0.13 s to build, outside the timed "
                          "region; 27 = 155 GiB / 18 entries is no faster: its gathers stop hiding behind the "
                          "arithmetic); 0 = the library default 21 = 4.3 GiB, 23 entries per hash.  If the "
                          "wide tables cannot be allocated the bench falls back to the library default and "

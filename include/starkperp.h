@@ -239,7 +239,31 @@ int sp_ecdsa_key_cache_info(size_t* capacity, size_t* used);
  * (generation << 24) | index; handles from before the reset are answered with SP_VERIFY_STALE_SLOT by
  * sp_ecdsa_verify_keyed_dev (never with another key's verdict): callers register their keys again. */
 int sp_ecdsa_key_cache_reset(void);
-/* One signing attempt per item with caller-supplied nonce k (host RFC 6979, signature.py:117-134):
+/* ---- signing: what the batch signer is for, and its threat model ------------------------------------------
+ * The batch signer exists to MAKE order batches (BASELINE configs[2]: 4096 signed limit orders) - test vectors,
+ * load generators, a market maker that signs its own quotes on its own device.  It is NOT a hardened signing
+ * service for keys of third parties on a device shared with untrusted tenants:
+ *   data-independent   the RFC 6979 nonce derivation (HMAC-SHA256: fixed schedule, no secret-dependent branch or
+ *                      address), both inversions that involve secrets (k^-1 and the (z + r d) denominator: fixed
+ *                      length Bernstein-Yang divsteps, 21 x 29 branch-free steps, identical for every lane,
+ *                      fp29.hpp), all field / scalar multiplications (no secret-dependent branches);
+ *   NOT independent    k*G and d*G are sums of EC_GEN table entries gathered from HBM at addresses that are windows
+ *                      of the secret scalar (12 random 64-byte reads per nonce at the default 21-bit windows): an
+ *                      observer of the memory system of the SAME device (another process time-slicing the GPU, a
+ *                      co-tenant with cache / HBM-channel contention counters) can learn bits of k; the nonce
+ *                      pipeline's compaction makes the NUMBER of rejected candidates of an item visible in timing
+ *                      (it depends on k's HMAC chain, not on d); the exceptional-case branches of the attempt
+ *                      (r = 0, out-of-range w: 2^-55 events) are data dependent;
+ *   at rest            nonces and HMAC states of the compacted pipeline are scrubbed on the stream behind their
+ *                      last reader, staged private keys of the host-pointer calls likewise; r, s and the public
+ *                      key are public.  Buffers the CALLER owns (d in the _dev calls) are the caller's to scrub.
+ * The reference is no different in kind: signature.py:137-173 signs with Python big integers, a recursive
+ * double-and-add ec_mult whose branches follow the bits of k (math_utils.py:91-100) and sympy's variable-time
+ * igcdex - it is not constant-time either.  A deployment that must sign on a shared device should keep using an
+ * HSM / a constant-time CPU signer and use this library for hashing and verification (which handle public data
+ * only).
+ *
+ * One signing attempt per item with caller-supplied nonce k (host RFC 6979, signature.py:117-134):
  * the body of the loop at signature.py:146-173. */
 int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r,
                         uint64_t* s, uint8_t* status, size_t n);
@@ -250,10 +274,18 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
  * caller. */
 int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
                                 uint64_t* s, uint8_t* status, size_t n);
-/* The two signing calls on DEVICE pointers (signature.py:137-173 per item, as above): one launch on `stream`,
+/* The two signing calls on DEVICE pointers (signature.py:137-173 per item, as above): enqueued on `stream`,
  * nothing staged and nothing waited for - the batch signer of a device-resident pipeline (message hashes left
  * in HBM by sp_pedersen_chains_dev are signed where they lie).  status is required; r / s of an item whose
- * status is not SP_SIGN_OK are left as they were.  seeds may be NULL (no seed for any item). */
+ * status is not SP_SIGN_OK are left as they were.  seeds may be NULL (no seed for any item).
+ * Launches and scratch: sp_ecdsa_sign_batch_dev is ONE launch with no shared state.
+ * sp_ecdsa_sign_rfc6979_batch_dev is one launch below 4096 items; from 4096 items on the nonce phase runs as
+ * rounds over the compacted list of rejected candidates - 15 launches and one scrubbing memset per chunk of at
+ * most 2^20 items (STARKPERP_SIGN_CHUNK) - on 232 bytes of per-stream scratch per item of a chunk (at most
+ * 290 MiB per stream).  The first such call on a stream allocates the scratch (hipMalloc: a device-wide
+ * synchronisation, not capturable into a hipGraph): warm the stream up first, or set STARKPERP_SIGN_COMPACT_MIN=0
+ * to keep the one-launch signer at every size (same signatures, 2.0 instead of 2.9 x 10^8 /s at 2^20 items).  If
+ * the scratch cannot be allocated the call falls back to the one-launch signer instead of failing. */
 int sp_ecdsa_sign_batch_dev(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r, uint64_t* s,
                             uint8_t* status, size_t n, void* stream);
 int sp_ecdsa_sign_rfc6979_batch_dev(const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,

@@ -206,7 +206,7 @@ build_window_kernel(aff_packed* tab, const aff_packed* bits, const aff_packed* o
 // [0, 2^b) and writes [2^b, 2^(b+1)): passes of one window run one after the other on the stream.  An exceptional
 // addition (x1 = x2: impossible for these points, context.hip header) would zero the shared inverse and leave the
 // thread's entries off the curve - the on-curve check below reports it like build_window_kernel does.
-// 26-bit windows: 1.1 s -> ~0.2 s per process (profiles/r04_table_build.txt).
+// 26-bit windows: 1.1 s -> 0.12 - 0.13 s per process (profiles/r04_table_build.txt).
 constexpr int EXTEND_K = 8;
 __global__ void __launch_bounds__(256)
 extend_window_kernel(aff_packed* tab, const aff_packed* bit, int b, fe beta_m, unsigned* bad) {

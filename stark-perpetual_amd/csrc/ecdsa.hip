@@ -954,7 +954,10 @@ namespace sp {
 void release_ecdsa_state() {
   for (auto& kv : g_verify_tab) kv.second.release();
   g_verify_tab.clear();
-  for (auto& kv : g_sign_scratch) kv.second.release();
+  for (auto& kv : g_sign_scratch) {  // scrubbed behind every call already; once more before the memory goes back
+    if (kv.second.ptr) (void)hipMemset(kv.second.ptr, 0, kv.second.bytes);
+    kv.second.release();
+  }
   g_sign_scratch.clear();
   g_keys.tab.release();
   g_keys.c.release();
@@ -1216,8 +1219,13 @@ int sp_ecdsa_register_keys(const uint64_t* qx, const uint64_t* qy, size_t n, uin
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
   ctx_lock lk(ctx().mu);
-  g_keys.external_handles = true;
-  return register_keys_locked(qx, qy, n, slots);
+  const int rc = register_keys_locked(qx, qy, n, slots);
+  // Handles of this generation are in a caller's hands from here on: the verify policy must not evict behind them
+  // (it serves a batch that does not fit on the ladder instead) until sp_ecdsa_key_cache_reset.  Set only when the
+  // registration succeeded - a failed call hands out nothing (it used to be set before the attempt, so
+  // one stray failing call switched the policy's eviction off for the rest of the process).
+  if (rc == SP_OK) g_keys.external_handles = true;
+  return rc;
 }
 
 int sp_ecdsa_key_cache_info(size_t* capacity, size_t* used) {
@@ -1336,18 +1344,29 @@ static int verify_batch_keyed_impl(const uint64_t* z, const uint64_t* r, const u
   // The key cache lives on the primary context: take a host lane of that context.  The lock covers the
   // bookkeeping (registration of new keys, the launch against the current tables); the copies and the
   // kernel run on the lane's stream and the lock is NOT held while the caller waits for them.
+  // The policy speaks first, under the lock alone: a batch that ends on the ladder (fresh keys, the slices of a
+  // multi-GPU caller) takes no lane and no stream of the primary device.  The lock is dropped while
+  // the lane is acquired (a thread that waits for a lane must not hold the lock the lanes' owners need to
+  // enqueue); registration and launch then share ONE hold, and a cache that another thread filled in between
+  // answers SP_ERR_CACHE_FULL, which the policy path turns into the ladder.
+  if (policy) {
+    ctx_lock lk(ctx().mu);
+    if (!use_key_tables(qx, qy, n)) { *fell_back = true; return SP_OK; }
+  }
   LaneScope ls(0);
-  if (ls.open() != SP_OK) return SP_ERR_HIP;
+  if (ls.open() != SP_OK) {
+    if (policy) { *fell_back = true; return SP_OK; }  // no stream for the tables: the ladder has its own lanes
+    return SP_ERR_HIP;
+  }
   HostLane& L = *ls.lane;
   std::vector<uint32_t> slots(n);
   uint8_t* d_res = nullptr;
   {
     ctx_lock lk(ctx().mu);
-    if (policy && !use_key_tables(qx, qy, n)) { *fell_back = true; return SP_OK; }
     // the handles never leave this call, so this is not an `external_handles` registration (sp_order_batch comes
     // through here on every batch: it must not switch the policy's eviction off)
     int rc = register_keys_locked(qx, qy, n, slots.data());
-    if (policy && rc == SP_ERR_CACHE_FULL) { *fell_back = true; return SP_OK; }  // (cannot happen under one lock; kept as the safe answer)
+    if (policy && rc == SP_ERR_CACHE_FULL) { *fell_back = true; return SP_OK; }  // filled by another thread since the decision
     if (rc != SP_OK) return rc;
     const uint64_t* host[3] = {z, r, s};
     uint64_t* dev[3];
@@ -1421,39 +1440,73 @@ static size_t sign_compact_min() {
   }();
   return v;
 }
+// Scratch of the compacted pipeline: 232 B per item of a chunk (the nonces, two index lists, two lists of HMAC
+// states).  Both lists are sized for the whole chunk - a batch of copies of one rejected item rejects everywhere,
+// so n / 2 + slack would not be memory-safe - but a batch is cut into chunks of at most 2^20 items (the size from
+// which the pipeline runs at its full rate, profiles/r04_sign_compaction.txt), so the scratch of a stream never
+// exceeds 232 MiB + 25 % whatever n is.  STARKPERP_SIGN_CHUNK overrides the chunk size.
+static size_t sign_chunk_items() {
+  static const size_t v = [] {
+    const char* e = getenv("STARKPERP_SIGN_CHUNK");
+    const size_t c = e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 20);
+    return c < 4096 ? (size_t)4096 : (c > ((size_t)1 << 30) ? ((size_t)1 << 30) : c);
+  }();
+  return v;
+}
 static int enqueue_sign_rfc6979(Context& c, const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
                                 uint64_t* s, uint8_t* status, size_t n, hipStream_t st) {
   const size_t min_n = sign_compact_min();
-  if (min_n == 0 || n < min_n || n >= ((size_t)1 << 31)) {
-    hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n, 128)), dim3(128), 0, st, z, d, seeds, r, s, status, n,
-                       c.gen, c.wbits, c.nwin);
+  auto one_kernel = [&](const uint64_t* z_, const uint64_t* d_, const uint64_t* seeds_, uint64_t* r_, uint64_t* s_,
+                        uint8_t* status_, size_t n_) {
+    hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n_, 128)), dim3(128), 0, st, z_, d_, seeds_, r_, s_,
+                       status_, n_, c.gen, c.wbits, c.nwin);
+  };
+  if (min_n == 0 || n < min_n) {
+    one_kernel(z, d, seeds, r, s, status, n);
     SP_HIP(hipGetLastError());
     return SP_OK;
   }
   constexpr int ROUNDS = 10;  // after them n / 2^11 items are left for the straggler launch
+  const size_t chunk = n < sign_chunk_items() ? n : sign_chunk_items();
   DeviceBuffer& buf = g_sign_scratch[stream_key(st)];
-  const size_t kb = n * 32, ib = n * 4, sb = n * 4 * RFC_STATE_WORDS;
-  SP_HIP(buf.reserve(kb + 2 * ib + 2 * sb + 256));
+  const size_t kb = chunk * 32, ib = chunk * 4, sb = chunk * 4 * RFC_STATE_WORDS;
+  if (buf.reserve(kb + 2 * ib + 2 * sb + 256) != hipSuccess) {
+    // no scratch, no compaction: the one-kernel signer needs none and computes the same signatures
+    (void)hipGetLastError();
+    one_kernel(z, d, seeds, r, s, status, n);
+    SP_HIP(hipGetLastError());
+    return SP_OK;
+  }
   char* b = (char*)buf.ptr;
   uint64_t* kbuf = (uint64_t*)b;
   uint32_t* idx[2] = {(uint32_t*)(b + kb), (uint32_t*)(b + kb + ib)};
   uint32_t* state[2] = {(uint32_t*)(b + kb + 2 * ib), (uint32_t*)(b + kb + 2 * ib + sb)};
   uint32_t* counters = (uint32_t*)(b + kb + 2 * ib + 2 * sb);  // one per list: counters[j] = items that enter round j
-  SP_HIP(hipMemsetAsync(counters, 0, 256, st));
-  hipLaunchKernelGGL(sign_nonce_first_kernel, dim3(nblocks(n, 128)), dim3(128), 0, st, z, d, seeds, kbuf, n, idx[0],
-                     state[0], counters);
-  for (int j = 0; j < ROUNDS; ++j) {
-    const size_t expect = (n >> (j + 1)) + (n >> (j + 3)) + 8192;  // half of the previous list, + 25 % and slack; the loop in the kernel covers any count
-    hipLaunchKernelGGL(sign_nonce_retry_kernel, dim3(nblocks(expect, 128)), dim3(128), 0, st, idx[j & 1], state[j & 1],
-                       counters + j, n, 1, kbuf, idx[(j + 1) & 1], state[(j + 1) & 1], counters + j + 1);
+  for (size_t off = 0; off < n; off += chunk) {
+    const size_t m = n - off < chunk ? n - off : chunk;
+    const uint64_t *zc = z + 4 * off, *dc = d + 4 * off, *sc = seeds ? seeds + off : nullptr;
+    uint64_t *rc_ = r + 4 * off, *sc_ = s + 4 * off;
+    uint8_t* stc = status + off;
+    SP_HIP(hipMemsetAsync(counters, 0, 256, st));
+    hipLaunchKernelGGL(sign_nonce_first_kernel, dim3(nblocks(m, 128)), dim3(128), 0, st, zc, dc, sc, kbuf, m, idx[0],
+                       state[0], counters);
+    for (int j = 0; j < ROUNDS; ++j) {
+      const size_t expect = (m >> (j + 1)) + (m >> (j + 3)) + 8192;  // half of the previous list, + 25 % and slack; the loop in the kernel covers any count
+      hipLaunchKernelGGL(sign_nonce_retry_kernel, dim3(nblocks(expect, 128)), dim3(128), 0, st, idx[j & 1], state[j & 1],
+                         counters + j, m, 1, kbuf, idx[(j + 1) & 1], state[(j + 1) & 1], counters + j + 1);
+    }
+    hipLaunchKernelGGL(sign_nonce_retry_kernel, dim3(nblocks((m >> (ROUNDS + 1)) + 8192, 128)), dim3(128), 0, st,
+                       idx[ROUNDS & 1], state[ROUNDS & 1], counters + ROUNDS, m, 64, kbuf, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(m, 128)), dim3(128), 0, st, zc, dc, kbuf, rc_, sc_, stc, m, c.gen,
+                       c.wbits, c.nwin);
+    hipLaunchKernelGGL(ecdsa_sign_rfc6979_redo_kernel, dim3(nblocks(m, 128)), dim3(128), 0, st, zc, dc, sc, rc_, sc_, stc,
+                       m, c.gen, c.wbits, c.nwin);
+    // Secret material does not outlive the chunk in HBM: kbuf holds every nonce of the chunk - one
+    // leaked k gives that item's private key away - and the state planes the HMAC K, V derived from d.  The
+    // one-kernel signer keeps all of it in registers; here it is scrubbed on the same stream, behind its last reader.
+    SP_HIP(hipMemsetAsync(b, 0, kb + 2 * ib + 2 * sb, st));
   }
-  hipLaunchKernelGGL(sign_nonce_retry_kernel, dim3(nblocks((n >> (ROUNDS + 1)) + 8192, 128)), dim3(128), 0, st,
-                     idx[ROUNDS & 1], state[ROUNDS & 1], counters + ROUNDS, n, 64, kbuf, (uint32_t*)nullptr,
-                     (uint32_t*)nullptr, (uint32_t*)nullptr);
-  hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(n, 128)), dim3(128), 0, st, z, d, kbuf, r, s, status, n, c.gen,
-                     c.wbits, c.nwin);
-  hipLaunchKernelGGL(ecdsa_sign_rfc6979_redo_kernel, dim3(nblocks(n, 128)), dim3(128), 0, st, z, d, seeds, r, s, status, n,
-                     c.gen, c.wbits, c.nwin);
   SP_HIP(hipGetLastError());
   return SP_OK;
 }
@@ -1482,6 +1535,7 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
   SP_HIP(hipMemcpyAsync(r, dr, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(s, ds, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipMemsetAsync(dev[1], 0, 2 * fb, L.stream));  // the staged private keys and nonces (dev[1], dev[2] are adjacent)
   SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }
@@ -1514,14 +1568,19 @@ int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint
   SP_HIP(hipMemcpyAsync(r, dr, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(s, ds, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipMemsetAsync(dev[1], 0, fb, L.stream));  // the staged private keys do not stay in the lane's buffer
   SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }
 
 // Device-pointer forms of the two signing calls (the batch signer of a device-resident pipeline: message
-// hashes that sp_pedersen_chains_dev left in HBM are signed where they lie).  One launch on the caller's
-// stream, nothing staged, nothing waited for; r / s of an item whose status is not SP_SIGN_OK are left as
-// they were.  No shared state: the lock covers the launch bookkeeping only.
+// hashes that sp_pedersen_chains_dev left in HBM are signed where they lie).  Nothing is staged and nothing waited
+// for; r / s of an item whose status is not SP_SIGN_OK are left as they were.  sp_ecdsa_sign_batch_dev is ONE
+// launch and touches no shared state.  sp_ecdsa_sign_rfc6979_batch_dev is one launch below 4096 items
+// (STARKPERP_SIGN_COMPACT_MIN; 0 = always) and 15 launches + a scrub per chunk of 2^20 items from there on (the
+// compacted nonce pipeline), with 232 B of per-stream scratch per item of a chunk: the first large call on a stream
+// allocates it (hipMalloc: a device-wide synchronisation, not capturable into a graph - warm the stream up
+// first or set STARKPERP_SIGN_COMPACT_MIN=0), and a failed allocation falls back to the one-kernel signer.
 int sp_ecdsa_sign_batch_dev(const uint64_t* z, const uint64_t* d, const uint64_t* k, uint64_t* r, uint64_t* s,
                             uint8_t* status, size_t n, void* stream) {
   CtxByPointer sp_ctx_sel__(z);  // the context of the device these pointers live on
@@ -1584,6 +1643,7 @@ int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* 
   SP_HIP(hipMemcpyAsync(qx, dx, fb, hipMemcpyDeviceToHost, L.stream));
   if (qy) SP_HIP(hipMemcpyAsync(qy, dy, fb, hipMemcpyDeviceToHost, L.stream));
   if (status) SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipMemsetAsync(dev[0], 0, fb, L.stream));  // the staged private keys do not stay in the lane's buffer
   SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }

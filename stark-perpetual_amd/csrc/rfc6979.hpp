@@ -194,7 +194,7 @@ __device__ __forceinline__ bool rfc6979_run(const rfc_input& in, rfc_state& st, 
 }
 
 // The whole generator in one call (the scalar path and batches below the compaction threshold).  After 64 rejected
-// candidates - unreachable in practice - the nonce is 0 and the caller reports SP_SIGN_RETRY.
+// candidates - unreachable in practice - the nonce is 0, which sign_attempt rejects as SP_SIGN_BAD_INPUT (k out of range).
 // MAX_REJECTED / rejected_out: for tools/ubench/rfc6979_chain.hip (what the retry chain costs).
 template <int MAX_REJECTED = 64>
 __device__ __forceinline__ u256 rfc6979_nonce(const u256& z, const u256& d, uint64_t seed, int* rejected_out = nullptr) {

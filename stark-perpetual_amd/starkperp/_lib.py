@@ -5,7 +5,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libstarkperp.so")
+# STARKPERP_LIB: another build of the SAME library (the sanitizer builds of csrc/Makefile, tools/run_sanitizers.sh);
+# never a fallback - the path must exist or load() raises.
+LIB_PATH = os.environ.get("STARKPERP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libstarkperp.so")
 
 U64P = ctypes.POINTER(ctypes.c_uint64)
 U8P = ctypes.POINTER(ctypes.c_uint8)

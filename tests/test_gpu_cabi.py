@@ -19,6 +19,22 @@ def test_c_consumer_runs():
     assert "cabi_smoke ok" in out.stdout
 
 
+@pytest.mark.parametrize("contexts", [1, 2])
+def test_native_threads_program(contexts):
+    """tests/cabi/cabi_threads.cpp - eight NATIVE host threads (no GIL anywhere) on every stateful entry point: hash
+    batches / chains / rebuilds, AUTO and keyed verification on a 16-slot key cache with resets racing, persistent
+    trees, sp_order_batch, both signers; every answer must equal the single-threaded one.  The same program is what
+    tools/run_sanitizers.sh runs under ASan + UBSan and TSan (profiles/r05_sanitizers.txt)."""
+    libdir = os.path.join(ROOT, "stark-perpetual_amd", "lib")
+    exe = os.path.join(ROOT, "tests", "cabi", "cabi_threads")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cabi", "cabi_threads.cpp"), "-o", exe,
+                           "-L" + libdir, "-lstarkperp", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, str(contexts), "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stdout[-1500:], out.stderr[-1500:])
+    assert "cabi_threads ok" in out.stdout
+
+
 def test_host_pointer_entry_points_from_concurrent_threads():
     """every batch call is re-entrant and thread-safe.  Eight host threads hammer the
     host-pointer entry points (which share one staging buffer inside the library; ctypes drops the

@@ -102,7 +102,11 @@ def test_bench_force_dist_takes_the_multi_gpu_branches(workload, extra):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
     if workload == "merkle":
-        assert d["dist"] == {"backend": "nccl", "world_size": 1, "forced_at_one_gpu": True}
+        dist = d["dist"]  # the process-group report (round 5): what RCCL and the devices looked like
+        assert (dist["backend"], dist["world_size"], dist["forced_at_one_gpu"]) == ("nccl", 1, True)
+        assert dist["rccl_version"] and dist["rccl_version"][0].isdigit()
+        assert len(dist["ranks"]) == 1 and dist["ranks"][0]["rank"] == 0 and dist["ranks"][0]["free_hbm_gib"] > 0
+        assert dist["peer_access"] == [[1]] and dist["per_rank_value"]["min"] > 0
         assert d["combine_matches_recomputed"] is True
         assert d["airfri_dist_rehearsal"]["n_gpus"] == 1 and d["airfri_dist_rehearsal"]["commits_per_sec"] > 0
         assert list(d)[-1] == "summary"
