@@ -36,6 +36,35 @@ def run(trees, wbits):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print("forest of %d trees: %.3f ms per build, %.3e hashes/s" % (trees, ms, trees * 65535 / ms * 1e3))
+    if os.environ.get("LEVEL_TIMES_SUSTAINED"):  # 400 builds back to back, then 400 timed: the steady state
+        for rep in range(2):
+            e0.record()
+            for _ in range(400):
+                _lib.check(lib.sp_merkle_forest_dev(lv.data_ptr(), trees, H, None, st), "forest")
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 400
+        print("sustained: %.4f ms per build, %.4e hashes/s" % (ms, trees * 65535 / ms * 1e3))
+    if os.environ.get("LEVEL_TIMES_GRAPH"):
+        # the launches of one forest build captured into a hipGraph and replayed - what the
+        # launch boundaries cost when the host is out of the picture
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            _lib.check(lib.sp_merkle_forest_dev(lv.data_ptr(), trees, H, None, side.cuda_stream), "forest")  # scratch of this stream
+            side.synchronize()
+            graph.capture_begin()
+            _lib.check(lib.sp_merkle_forest_dev(lv.data_ptr(), trees, H, None, side.cuda_stream), "forest")
+            graph.capture_end()
+        torch.cuda.synchronize()
+        for rep in range(2):
+            e0.record()
+            for _ in range(400):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 400
+        print("hipGraph replay: %.4f ms per build, %.4e hashes/s" % (ms, trees * 65535 / ms * 1e3))
 
 
 def parse(path, tail, every_kernel=False):
