@@ -370,7 +370,7 @@ def valu_issue(hashes_per_sec, window_bits, workload, include_finish=True):
             "frac_at_flat_4_cycle_peak": achieved / (VALU_PEAK_SIMDS * VALU_NOMINAL_GHZ * 1e9 / 4.0)}
 
 
-def pmc_traffic(kernel, this_config, files=("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")):
+def pmc_traffic(kernel, this_config, files=("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE
     and --pmc WRITE_SIZE runs, tools/pmc_traffic.py; units and gfx950 calibration in its docstring), and
     the configuration those passes ran - traffic is only comparable with this run when they agree."""
