@@ -671,7 +671,7 @@ def main():
                     help="--gpus 1 only: create a world-size-1 RCCL process group anyway and take every branch the "
                          "N > 1 runs take (sub-root all_gather + top forest, max / min reductions of the timings, the "
                          "sharded AIR+FRI path with --workload airfri) - the one-GPU rehearsal of the multi-GPU launch")
-    ap.add_argument("--min-timed-s", type=float, default=float(os.environ.get("STARKPERP_BENCH_MIN_TIMED_S", "2.0")),
+    ap.add_argument("--min-timed-s", type=float, default=float(os.environ.get("STARKPERP_BENCH_MIN_TIMED_S", "3.0")),
                     help="the timed regions (each EXACTLY --steps steps between fences) are repeated until this many "
                          "seconds have been timed; value = the median region of that sustained window")
     ap.add_argument("--preheat-s", type=float, default=float(os.environ.get("STARKPERP_BENCH_PREHEAT_S", "1.0")),
@@ -843,7 +843,7 @@ def main():
     #   burst      --burst-s (50 ms) straight after the CPU-only set-up: what rounds 1 - 4 reported.  The power
     #              controller is still ramping (clock above its steady state), so this is NOT the headline any more;
     #   pre-heat   --preheat-s (1 s) of the same call, untimed;
-    #   sustained  regions repeated until --min-timed-s (2 s) have been timed: `value` = the MEDIAN region of this
+    #   sustained  regions repeated until --min-timed-s (3 s) have been timed: `value` = the MEDIAN region of this
     #              window, with the shader clock and package power sampled beside it (Telemetry).
     # Every rank takes the same decisions: a region's time is MAX-reduced over the ranks before it is used.
     MAX_REGIONS = 1 << 15
@@ -1033,16 +1033,11 @@ def main():
             if wide_error:
                 result["dist"]["window_plan_fallback"] = wide_error
         result["build"] = build_provenance(lib)
-        if not args.no_airfri:
-            result["airfri"] = (airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline, min_timed_s=args.min_timed_s,
-                                              preheat_s=0.7 * args.preheat_s) if world == 1
-                                else airfri_multi)
-            if forced_dist and airfri_multi is not None:  # the N > 1 reduction of the job rates, rehearsed at N = 1
-                result["airfri_dist_rehearsal"] = {k: airfri_multi[k] for k in
-                                                   ("commits_per_sec", "commits_per_sec_slowest_gpu", "n_gpus")}
-        if world == 1 and not args.no_extras:
-            result["extra"] = extras(torch, lib, _lib, dev, stream)
-        if world == 1 and not args.no_cpu_baseline:
+        # GPU legs and CPU legs alternate, so that the device's activity is spread over the run instead of sitting in
+        # its first seconds (the driver samples gpu_busy every few seconds: round 4's run showed it 0 % eight times).
+        levels = leaf_ints = gpu_root = tnb = None
+        with_cpu = world == 1 and not args.no_cpu_baseline
+        if with_cpu:
             n_sample = 1 << HEIGHT  # up to the whole first level (32768 hashes), bounded by budget_s
             # tree 0 of the forest buffer the FIRST TIMED call wrote (its inner nodes were zeroed before the
             # timed regions): the parity legs check the timed computation, not a warm-up forest
@@ -1062,8 +1057,19 @@ def main():
             gpu_root = _lib.unpack_felts(
                 (ctypes.c_uint64 * 4).from_buffer_copy(
                     levels[levels.shape[0] - tnb : levels.shape[0] - tnb + 1].cpu().numpy().astype("<i8").tobytes()), 1)[0]
+        if not args.no_airfri:
+            result["airfri"] = (airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline, min_timed_s=args.min_timed_s,
+                                              preheat_s=0.7 * args.preheat_s) if world == 1
+                                else airfri_multi)
+            if forced_dist and airfri_multi is not None:  # the N > 1 reduction of the job rates, rehearsed at N = 1
+                result["airfri_dist_rehearsal"] = {k: airfri_multi[k] for k in
+                                                   ("commits_per_sec", "commits_per_sec_slowest_gpu", "n_gpus")}
+        if with_cpu:
             result["cpu_baseline_c"] = cpu_baseline_c(leaf_ints, gpu_root)
             result["cpu_baseline_opt"] = cpu_baseline_opt(leaf_ints, gpu_root)
+        if world == 1 and not args.no_extras:
+            result["extra"] = extras(torch, lib, _lib, dev, stream)
+        if with_cpu:
             result["cpu_baseline_ecdsa"] = cpu_baseline_ecdsa()
         result["summary"] = summary_object(result)  # LAST key: both halves of the metric survive a truncated tail
         print(json.dumps(result))
@@ -1144,7 +1150,8 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
     for _ in range(args.steps):
         step()
     fence()
-    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
     k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
     _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)),
                "profile_end")
@@ -1152,6 +1159,7 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    tel_window = TELEMETRY.window(t0, t1) if TELEMETRY else None
     if rank == 0:
         avg_launch_s = (k_ms.value / 1e3) / max(k_launches.value, 1)
         achieved = (ALGO_BYTES_PER_HASH * k_units.value / max(k_launches.value, 1)) / avg_launch_s / 1e9 \
@@ -1181,6 +1189,8 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
                 traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
                 hbm={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS}),
+            "telemetry": dict(TELEMETRY.describe(), timed=tel_window) if TELEMETRY else None,
+            "build": build_provenance(lib),
             "cpu_baseline": (cpu_airfri_baseline(10) if (world == 1 and not args.no_cpu_baseline) else None),
         }))
     if dist is not None:
