@@ -17,7 +17,7 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids
 } > $O/build_on_gpu_box.txt 2>&1
 cat $O/build_on_gpu_box.txt
 ( time python -m pytest tests -m gpu -q -x ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
-echo "== GPU suite on the box-built library: $(tail -3 $O/pytest_gpu.txt | grep -E 'passed|failed')" >> $O/build_on_gpu_box.txt
+echo "== GPU suite on the box-built library: $(grep -E "passed|failed" $O/pytest_gpu.txt | tail -1 | grep -E 'passed|failed')" >> $O/build_on_gpu_box.txt
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo bench rc=$?
 python -c "
 import json; d=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1]); s=d['summary']
