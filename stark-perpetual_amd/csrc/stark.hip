@@ -23,12 +23,28 @@
 
 namespace sp {
 
-constexpr int TILE_LOG = 11;
-constexpr int TILE = 1 << TILE_LOG;  // 2048 felts = 72 KiB of LDS as 9 x int32 planes
-#ifndef SP_NTT_THREADS
-#define SP_NTT_THREADS 256
+// Tile = 2048 felts = 72 KiB of LDS as 9 x int32 planes, two blocks of 256 threads per CU.  Round 5 measured the
+// two-pass plans the round-4 verdict asked for against this one (profiles/r05_ntt_plans.txt, one box): tiles of 4096
+// felts (144 KiB, ONE block of 512 threads per CU; 2^22 points = 12 local + 10 strided stages with 128-byte segments,
+// -DSP_NTT_TILE_LOG=12) and 2048-felt tiles with an 11-stage strided pass of 32-byte segments
+// (-DSP_NTT_STRIDED_MAX=11).  Both remove one pass over HBM and neither is faster: the single block per CU puts all
+// eight waves of a CU into the same load / compute / store phase (862 + 857 us for the two big passes against
+// 650 + 513 + 522), the 32-byte segments make the strided pass HBM-bound (1012 us against 513 + 522).  The
+// three-pass plan stays; the macros keep the variants buildable.
+#ifndef SP_NTT_TILE_LOG
+#define SP_NTT_TILE_LOG 11
 #endif
-constexpr int NTT_THREADS = SP_NTT_THREADS;  // 256 threads x 8 felts in registers = one radix-8 step of a tile; two blocks per CU (LDS)
+constexpr int TILE_LOG = SP_NTT_TILE_LOG;
+constexpr int TILE = 1 << TILE_LOG;
+#ifndef SP_NTT_THREADS
+#define SP_NTT_THREADS (1 << (SP_NTT_TILE_LOG - 3))
+#endif
+constexpr int NTT_THREADS = SP_NTT_THREADS;  // threads x 8 felts in registers = one radix-8 step of a tile
+constexpr size_t NTT_LDS_BYTES = (size_t)NL * TILE * sizeof(int32_t);
+#ifndef SP_NTT_STRIDED_MAX
+#define SP_NTT_STRIDED_MAX (SP_NTT_TILE_LOG - 2)  // at least 4 adjacent columns = 128-byte segments
+#endif
+constexpr int NTT_STRIDED_MAX = SP_NTT_STRIDED_MAX;  // stages of a strided pass
 
 // Slot of tile element e inside a limb plane: bank bit i = e_i ^ e_(i+3).  The lanes of a wave walk the tile
 // with their six index bits at e3..e8 (radix-8 group of stages 0-2), at e0..e2 + e6..e8 (stages 3-5), at e0..e5
@@ -172,7 +188,7 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
                 int log_lo, int nst, int t_first, int dit, const uint64_t* __restrict__ tw, int log_tw,
                 int use_scale, fe scale, size_t in_col_stride, size_t out_col_stride,
                 const uint64_t* __restrict__ pad_G, int pad_log_b, int pad_log_n) {
-  __shared__ int32_t lds[NL * TILE];
+  extern __shared__ int32_t lds[];  // NL planes of TILE int32 (NTT_LDS_BYTES: above the 64 KiB a static array may have)
   in += 4 * in_col_stride * blockIdx.y;    // grid.y = column: independent columns share one launch
   out += 4 * out_col_stride * blockIdx.y;
   const int E = 1 << log_e;
@@ -218,7 +234,7 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
   int left = nst - s_begin;
   int t_next = dit ? t_first + s_begin : t_first;  // next stage to do
   while (left > 0) {
-    const int r = left >= 3 ? 3 : left;  // stages in this group
+    const int r = left == 4 ? 2 : (left >= 3 ? 3 : left);  // stages in this group: 10 = 3 + 3 + 2 + 2, never 3 + 3 + 3 + 1
     const int t_lo = dit ? t_next : t_next - r + 1;
     const bool unit_low = (t_lo + log_lo) == 0;
     const int groups = E >> r;
@@ -1060,25 +1076,37 @@ static int coset_table(int log_n, int log_blowup, const uint64_t* shift_host, co
 // pad_log_b > 0 (dit only) `in` is the bit-reversed coefficient array of 2^(log_n - pad_log_b) felts per
 // column and the zero-padded, coset-scaled input of the transform exists only in LDS.
 static const bool g_ntt_lazy_store = getenv("STARKPERP_NTT_CANON_ALL") == nullptr;  // A/B switch
+// The tile needs more dynamic LDS than a kernel gets by default: raised once per process (per device: the attribute
+// is per function and device, and the prover's entry points run on the primary context only).
+static int ntt_lds_ready() {
+  static int rc = [] {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES);
+    return e == hipSuccess ? SP_OK : hip_fail(e, "hipFuncSetAttribute(ntt_tile_kernel, MaxDynamicSharedMemorySize)");
+  }();
+  return rc;
+}
 static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse, int dit, int use_scale,
                       fe scale, hipStream_t st, unsigned ncols = 1, size_t in_col_stride = 0,
                       size_t out_col_stride = 0, const uint64_t* pad_G = nullptr, int pad_log_b = 0) {
   const uint64_t* tw;
   int rc = get_twiddles(log_n, inverse, &tw, st);
   if (rc != SP_OK) return rc;
+  rc = ntt_lds_ready();
+  if (rc != SP_OK) return rc;
   if (log_n == 0) {
     // single point: (optionally) scale
-    hipLaunchKernelGGL(ntt_tile_kernel, dim3(1, ncols), dim3(NTT_THREADS), 0, st, in, out, 0, 0, 0, 0, 0, dit, tw, 1,
+    hipLaunchKernelGGL(ntt_tile_kernel, dim3(1, ncols), dim3(NTT_THREADS), NTT_LDS_BYTES, st, in, out, 0, 0, 0, 0, 0, dit, tw, 1,
                        use_scale, scale, in_col_stride, out_col_stride, (const uint64_t*)nullptr, 0, 0);
     SP_HIP(hipGetLastError());
     return SP_OK;
   }
-  // pass plan: local pass covers the low min(11, log_n) stages; the rest in strided passes of <= 9
+  // pass plan: local pass covers the low min(TILE_LOG, log_n) stages; the rest in strided passes of <= NTT_STRIDED_MAX
   struct Pass { int log_e, log_t, log_lo, nst, t_first; };
   std::vector<Pass> plan;
   const int local = log_n < TILE_LOG ? log_n : TILE_LOG;
   const int rest = log_n - local;
-  const int npass = (rest + 8) / 9;
+  const int npass = (rest + NTT_STRIDED_MAX - 1) / NTT_STRIDED_MAX;
   std::vector<Pass> strided;
   int lo = local;
   for (int pi = 0; pi < npass; ++pi) {
@@ -1108,7 +1136,7 @@ static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse,
     const bool first = pi == 0, last = pi + 1 == plan.size();
     const unsigned blocks = (unsigned)(((size_t)1 << log_n) >> ps.log_e);
     const int pb = first ? pad_log_b : 0;
-    hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks, ncols), dim3(NTT_THREADS), 0, st, src, out, ps.log_e, ps.log_t,
+    hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks, ncols), dim3(NTT_THREADS), NTT_LDS_BYTES, st, src, out, ps.log_e, ps.log_t,
                        ps.log_lo, ps.nst, ps.t_first, dit, tw, log_n, last ? (use_scale ? 1 : 0) : (g_ntt_lazy_store ? 2 : 0), scale, src_stride,
                        out_col_stride, pb ? pad_G : (const uint64_t*)nullptr, pb, pb ? log_n - pad_log_b : 0);
     src = out;
