@@ -259,9 +259,15 @@ int sp_ecdsa_key_cache_reset(void);
  *                      key are public.  Buffers the CALLER owns (d in the _dev calls) are the caller's to scrub.
  * The reference is no different in kind: signature.py:137-173 signs with Python big integers, a recursive
  * double-and-add ec_mult whose branches follow the bits of k (math_utils.py:91-100) and sympy's variable-time
- * igcdex - it is not constant-time either.  A deployment that must sign on a shared device should keep using an
- * HSM / a constant-time CPU signer and use this library for hashing and verification (which handle public data
- * only).
+ * igcdex - it is not constant-time either.
+ * STARKPERP_SIGN_MASKED=1 (read by sp_init) removes the address dependence: the signers and sp_public_key_batch then
+ * walk a second EC_GEN table of 63 unsigned 4-bit windows (63 KiB), reading ALL 16 entries of every window - the
+ * same addresses on every lane whatever the scalar is - and keeping one by a mask; 62 mixed additions for every k.
+ * Same keys and signatures bit for bit (tests/test_gpu_ecdsa.py::test_masked_signer_...); 2^16 signatures 0.86 ->
+ * 1.27 ms (7.7 -> 5.2 x 10^7 /s), d * G four times slower (profiles/r05_masked_signer.txt).  What stays data
+ * dependent under the mask: the number of rejected RFC 6979 candidates (timing of the nonce phase) and the 2^-55
+ * exceptional branches.  A deployment that must sign third-party keys on a shared device should still keep its HSM
+ * / constant-time CPU signer and use this library for hashing and verification (which handle public data only).
  *
  * One signing attempt per item with caller-supplied nonce k (host RFC 6979, signature.py:117-134):
  * the body of the loop at signature.py:146-173. */

@@ -476,6 +476,14 @@ static int init_locked(Context& c, int device, int window_bits) {
   if (rc != SP_OK) return rc;
   rc = build_gen_table(c.gen, gen_bits, bases[0], 0x5350474E54424C45ull, c.wbits, c.nwin);
   if (rc != SP_OK) return rc;
+  if (const char* masked = getenv("STARKPERP_SIGN_MASKED")) {
+    if (masked[0] == '1') {  // the small table of the masked signer: same builder, 4-bit windows, its own offsets
+      SP_HIP(hipMalloc(&c.gen_masked, (size_t)63 * 16 * sizeof(aff_packed)));
+      rc = build_gen_table(c.gen_masked, gen_bits, bases[0], 0x4D41534B45444745ull, 4, 63);
+      if (rc != SP_OK) return rc;
+      c.table_bytes += (size_t)63 * 16 * sizeof(aff_packed);
+    }
+  }
   c.ready = true;
   return SP_OK;
 }
@@ -489,8 +497,9 @@ extern "C" {
 static void free_tables(Context& c) {
   if (c.ped) (void)hipFree(c.ped);
   if (c.gen) (void)hipFree(c.gen);
+  if (c.gen_masked) (void)hipFree(c.gen_masked);
   if (c.d_plan) (void)hipFree(c.d_plan);
-  c.ped = c.gen = nullptr;
+  c.ped = c.gen = c.gen_masked = nullptr;
   c.d_plan = nullptr;
   c.io.release();
   c.io2.release();

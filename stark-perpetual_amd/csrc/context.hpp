@@ -67,6 +67,14 @@ struct Context {
   int nwin = 16;         // EC_GEN table: windows per 252-bit scalar = ceil(252 / wbits)
   aff_packed* ped = nullptr;   // Pedersen window tables, laid out by `plan`
   aff_packed* gen = nullptr;   // [nwin][1 << wbits]     fixed-base EC_GEN
+  // STARKPERP_SIGN_MASKED=1: a second EC_GEN table of 63 unsigned 4-bit windows (63 x 16 entries = 63 KiB) for the
+  // signers and the key derivation: every window reads all 16 of its entries and keeps one by a mask, so no address
+  // depends on the nonce or the private key (ecdsa.hip gen_mul_masked; include/starkperp.h "threat model")
+  aff_packed* gen_masked = nullptr;
+  // the fixed-base table the SECRET-scalar kernels are handed: wbits < 0 selects the masked walk
+  const aff_packed* secret_gen() const { return gen_masked ? gen_masked : gen; }
+  int secret_wbits() const { return gen_masked ? -4 : wbits; }
+  int secret_nwin() const { return gen_masked ? 63 : nwin; }
   PedPlan plan;                // host copy
   PedPlan* d_plan = nullptr;   // device copy the kernels read (uniform loads)
   size_t table_bytes = 0;

@@ -43,8 +43,51 @@ namespace sp {
 #endif
 constexpr int VERIFY_TPB = SP_VERIFY_TPB;
 
+// k * EC_GEN with addresses and control flow that do not depend on k (STARKPERP_SIGN_MASKED=1; the signer's threat
+// model in include/starkperp.h): `gen` is the table of 63 unsigned 4-bit windows (context.hpp gen_masked).  Window i
+// reads ALL 16 of its entries - the same 16 addresses on every lane, whatever the scalar is - and keeps the one its
+// nibble names with a mask built from a comparison of VALUES; the walk is the same 62 mixed additions for every k.
+// About six times the work of the gathered walk below (12 additions at 21-bit windows), which is why it is opt-in.
+__device__ __forceinline__ xyzz gen_mul_masked(u256 k, const aff_packed* __restrict__ gen, int nwin) {
+  auto select = [&](int i) {
+    const uint32_t v = k.w[0] & 15u;
+#pragma unroll
+    for (int w = 0; w < 7; ++w) k.w[w] = (k.w[w] >> 4) | (k.w[w + 1] << 28);
+    k.w[7] >>= 4;
+    uint32_t sel[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) sel[w] = 0;
+    const uint4* row = reinterpret_cast<const uint4*>(gen + (size_t)i * 16);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; ++j) {
+      const uint32_t m = 0u - (uint32_t)(v == j);  // all ones for the wanted entry, zero otherwise
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 t = row[4 * j + q];
+        sel[4 * q + 0] |= t.x & m;
+        sel[4 * q + 1] |= t.y & m;
+        sel[4 * q + 2] |= t.z & m;
+        sel[4 * q + 3] |= t.w & m;
+      }
+    }
+    u256 x, y;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { x.w[w] = sel[w]; y.w[w] = sel[8 + w]; }
+    aff a;
+    a.x = fe_unpack(x);
+    a.y = fe_unpack(y);
+    return a;
+  };
+  xyzz acc = xyzz_from_aff(select(0));
+#pragma unroll 1
+  for (int i = 1; i < nwin; ++i) acc = xyzz_madd(acc, select(i));
+  return acc;
+}
+
 // k * EC_GEN from the window table; k < 2^252.  Infinity (only for k == 0 mod N) shows as ZZ == 0.
+// wbits < 0: the masked walk above (the signers and the key derivation under STARKPERP_SIGN_MASKED=1).
 __device__ __forceinline__ xyzz gen_mul(u256 k, const aff_packed* __restrict__ gen, int wbits, int nwin) {
+  if (wbits < 0) return gen_mul_masked(k, gen, nwin);
   const size_t per = (size_t)1 << wbits;
   const uint32_t mask = (1u << wbits) - 1u;
   auto pop = [&](void) {
@@ -1459,7 +1502,7 @@ static int enqueue_sign_rfc6979(Context& c, const uint64_t* z, const uint64_t* d
   auto one_kernel = [&](const uint64_t* z_, const uint64_t* d_, const uint64_t* seeds_, uint64_t* r_, uint64_t* s_,
                         uint8_t* status_, size_t n_) {
     hipLaunchKernelGGL(ecdsa_sign_rfc6979_kernel, dim3(nblocks(n_, 128)), dim3(128), 0, st, z_, d_, seeds_, r_, s_,
-                       status_, n_, c.gen, c.wbits, c.nwin);
+                       status_, n_, c.secret_gen(), c.secret_wbits(), c.secret_nwin());
   };
   if (min_n == 0 || n < min_n) {
     one_kernel(z, d, seeds, r, s, status, n);
@@ -1498,10 +1541,10 @@ static int enqueue_sign_rfc6979(Context& c, const uint64_t* z, const uint64_t* d
     hipLaunchKernelGGL(sign_nonce_retry_kernel, dim3(nblocks((m >> (ROUNDS + 1)) + 8192, 128)), dim3(128), 0, st,
                        idx[ROUNDS & 1], state[ROUNDS & 1], counters + ROUNDS, m, 64, kbuf, (uint32_t*)nullptr,
                        (uint32_t*)nullptr, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(m, 128)), dim3(128), 0, st, zc, dc, kbuf, rc_, sc_, stc, m, c.gen,
-                       c.wbits, c.nwin);
+    hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(m, 128)), dim3(128), 0, st, zc, dc, kbuf, rc_, sc_, stc, m, c.secret_gen(),
+                       c.secret_wbits(), c.secret_nwin());
     hipLaunchKernelGGL(ecdsa_sign_rfc6979_redo_kernel, dim3(nblocks(m, 128)), dim3(128), 0, st, zc, dc, sc, rc_, sc_, stc,
-                       m, c.gen, c.wbits, c.nwin);
+                       m, c.secret_gen(), c.secret_wbits(), c.secret_nwin());
     // Secret material does not outlive the chunk in HBM: kbuf holds every nonce of the chunk - one
     // leaked k gives that item's private key away - and the state planes the HMAC K, V derived from d.  The
     // one-kernel signer keeps all of it in registers; here it is scrubbed on the same stream, behind its last reader.
@@ -1530,7 +1573,7 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
   uint8_t* dst = (uint8_t*)(extra + 2 * fb);
   SP_HIP(hipMemsetAsync(dr, 0, 2 * fb, L.stream));
   hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(n, 128)), dim3(128), 0, L.stream, dev[0], dev[1], dev[2],
-                     dr, ds, dst, n, c.gen, c.wbits, c.nwin);
+                     dr, ds, dst, n, c.secret_gen(), c.secret_wbits(), c.secret_nwin());
   SP_HIP(hipGetLastError());
   SP_HIP(hipMemcpyAsync(r, dr, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(s, ds, fb, hipMemcpyDeviceToHost, L.stream));
@@ -1590,7 +1633,7 @@ int sp_ecdsa_sign_batch_dev(const uint64_t* z, const uint64_t* d, const uint64_t
   Context& c = ctx();
   ctx_lock lk(c.mu);
   hipLaunchKernelGGL(ecdsa_sign_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, z, d, k, r, s, status,
-                     n, c.gen, c.wbits, c.nwin);
+                     n, c.secret_gen(), c.secret_wbits(), c.secret_nwin());
   SP_HIP(hipGetLastError());
   return SP_OK;
 }
@@ -1615,7 +1658,7 @@ int sp_public_key_batch_dev(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8
   Context& c = ctx();
   ctx_lock lk(c.mu);
   hipLaunchKernelGGL(public_key_kernel, dim3(nblocks(n, 128)), dim3(128), 0, (hipStream_t)stream, d, qx, qy, status, n,
-                     c.gen, c.wbits, c.nwin);
+                     c.secret_gen(), c.secret_wbits(), c.secret_nwin());
   SP_HIP(hipGetLastError());
   return SP_OK;
 }
@@ -1638,7 +1681,7 @@ int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* 
   uint8_t* dst = (uint8_t*)(extra + 2 * fb);
   SP_HIP(hipMemsetAsync(dx, 0, 2 * fb, L.stream));
   hipLaunchKernelGGL(public_key_kernel, dim3(nblocks(n, 128)), dim3(128), 0, L.stream, dev[0], dx, dy, dst, n,
-                     c.gen, c.wbits, c.nwin);
+                     c.secret_gen(), c.secret_wbits(), c.secret_nwin());
   SP_HIP(hipGetLastError());
   SP_HIP(hipMemcpyAsync(qx, dx, fb, hipMemcpyDeviceToHost, L.stream));
   if (qy) SP_HIP(hipMemcpyAsync(qy, dy, fb, hipMemcpyDeviceToHost, L.stream));

@@ -530,3 +530,45 @@ def test_verify_extreme_limb_patterns_differential(batch):
     assert batch.verify_codes(zs, rs, ss, xonly, key_tables=False) == batch.verify_codes(zs, rs, ss, xonly, key_tables=True)
     got_x = batch.verify_codes(zs, rs, ss, xonly, key_tables=False)
     assert [g for g, e in zip(got_x, exp) if e == 1] == [1] * exp.count(1)
+
+
+_MASKED_WORKER = r"""
+import json, os, random, sys
+sys.path.insert(0, os.path.join(%(root)r, "stark-perpetual_amd")); sys.path.insert(0, %(root)r)
+from starkperp import _lib, batch
+lib = _lib.ensure_init(0, 16)
+h = lambda v: int(v, 16)
+g2 = json.load(open(os.path.join(%(root)r, "tests", "golden", "g2_keys.json")))["keys"]      # (d, x, y)
+g3 = json.load(open(os.path.join(%(root)r, "tests", "golden", "g3_sign.json")))["cases"]     # (z, d, seed, r, s)
+out = {"table_bytes": int(lib.sp_table_bytes())}
+out["keys_ok"] = batch.public_keys_many([h(d) for d, _, _ in g2]) == [(h(x), h(y)) for _, x, y in g2]
+sigs = batch.sign_many([h(c[0]) for c in g3], [h(c[1]) for c in g3], [None if c[2] is None else h(c[2]) for c in g3])
+out["sigs_ok"] = sigs == [(h(c[3]), h(c[4])) for c in g3]
+rng = random.Random(99)
+zs = [rng.randrange(2**251) for _ in range(6000)]   # above the compaction threshold: nonce rounds + ecdsa_sign_kernel
+ds = [rng.randrange(1, batch.EC_ORDER) for _ in range(6000)]
+big = batch.sign_many(zs, ds)
+import hashlib
+out["big_digest"] = hashlib.sha256(repr(big).encode()).hexdigest()
+print("MASKED " + json.dumps(out))
+"""
+
+
+def test_masked_signer_gives_the_same_keys_and_signatures():
+    """STARKPERP_SIGN_MASKED=1 (include/starkperp.h, the signer's threat model): k * G and d * G walk a table of 63
+    4-bit windows reading all 16 entries of every window - no address depends on the scalar.  Same public keys as
+    the reference (g2), same signatures as the reference (g3) and as the gathered walk on 6000 random items."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for masked in ("0", "1"):
+        env = dict(os.environ, STARKPERP_SIGN_MASKED=masked)
+        out = subprocess.run([sys.executable, "-c", _MASKED_WORKER % {"root": ROOT}], capture_output=True, text=True,
+                             timeout=600, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[masked] = json.loads([l for l in out.stdout.splitlines() if l.startswith("MASKED ")][0][7:])
+    assert res["1"]["table_bytes"] == res["0"]["table_bytes"] + 63 * 16 * 64  # the small table exists only when asked for
+    for r in res.values():
+        assert r["keys_ok"] and r["sigs_ok"]
+    assert res["0"]["big_digest"] == res["1"]["big_digest"]
