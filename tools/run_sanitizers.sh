@@ -66,10 +66,14 @@ TORCH_LIB="$(python -c 'import os, importlib.util as u; print(os.path.join(list(
 export LD_LIBRARY_PATH="$LD_LIBRARY_PATH:$TORCH_LIB"
 PYSAN="env LD_PRELOAD=$RT/libclang_rt.asan-x86_64.so ASAN_OPTIONS=$ASAN_PY STARKPERP_LIB=$LIBDIR/libstarkperp_asan.so"
 cd "$ROOT"
-run asan_pytest_cabi        $PYSAN python -m pytest -x -q -m gpu tests/test_gpu_cabi.py -k "not c_consumer and not native_threads" -p no:cacheprovider
-run asan_pytest_keyed       $PYSAN python -m pytest -x -q -m gpu tests/test_gpu_keyed_verify.py -p no:cacheprovider
-run asan_pytest_state       $PYSAN python -m pytest -x -q -m gpu tests/test_gpu_state.py -p no:cacheprovider
-run asan_pytest_multidevice $PYSAN python -m pytest -x -q -m gpu tests/test_gpu_multi_device.py -p no:cacheprovider
+# pytest.main + os._exit: the interpreter's exit would run the HSA runtime's static destructors under ASan, whose own
+# device allocator then calls back into the half-torn-down runtime (SEGV / CHECK inside libhsa-runtime64 <- operator
+# delete <- __cxa_finalize: no frame of this library; seen in two of three runs) and would bury the suite's verdict
+PYTEST_MAIN='import os, sys, pytest; rc = pytest.main(sys.argv[1:]); sys.stdout.flush(); sys.stderr.flush(); os._exit(int(rc))'
+run asan_pytest_cabi        $PYSAN python -c "$PYTEST_MAIN" -x -q -m gpu tests/test_gpu_cabi.py -k "not c_consumer and not native_threads" -p no:cacheprovider
+run asan_pytest_keyed       $PYSAN python -c "$PYTEST_MAIN" -x -q -m gpu tests/test_gpu_keyed_verify.py -p no:cacheprovider
+run asan_pytest_state       $PYSAN python -c "$PYTEST_MAIN" -x -q -m gpu tests/test_gpu_state.py -p no:cacheprovider
+run asan_pytest_multidevice $PYSAN python -c "$PYTEST_MAIN" -x -q -m gpu tests/test_gpu_multi_device.py -p no:cacheprovider
 
 # ---- TSan, native ---------------------------------------------------------------------------------------
 $CLANG -fsanitize=thread -shared-libsan -g -O1 -I"$ROOT/include" "$ROOT/tests/cabi/cabi_smoke.c" \
