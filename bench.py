@@ -300,6 +300,8 @@ def combine_check(slot, world, _lib):
 
 
 VALU_PEAK_SIMDS, VALU_NOMINAL_GHZ = 1024, 2.4
+# PMC passes of the airfri workload, newest first (no round-5 file: the prover kernels did not change)
+AIRFRI_PMC_FILES = ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")
 VALU_ISSUE_FILES = ("r04_valu_issue.json", "r03_valu_issue.json", "r02_valu_issue.json", "r01_valu_issue.json")
 
 
@@ -1185,8 +1187,8 @@ def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
                 peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value),
                 hashes_in_timed_launches=int(k_units.value), avg_launch_us=avg_launch_s * 1e6,
                 timing="HIP events around every ped_accumulate_kernel launch inside the timed region",
-                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
-                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
+                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES) or {}).get("bytes_per_launch"),
+                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES),
                 hbm={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS}),
             "telemetry": dict(TELEMETRY.describe(), timed=tel_window) if TELEMETRY else None,
@@ -1281,8 +1283,8 @@ def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, tr
                 or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None},
                 kernel="ped_accumulate_kernel (row chains and commit-tree levels above 65 536 hashes)",
                 peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value), avg_launch_us=avg_launch_s * 1e6,
-                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
-                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
+                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES) or {}).get("bytes_per_launch"),
+                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES),
                 hbm={"bound": "hbm", "achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}),
             "cpu_baseline": None,
@@ -1387,8 +1389,8 @@ def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None, min_
     roof.update({"kernel": "ped_accumulate_kernel (row chains and the tree levels above 65 536 hashes: %.0f %% of the "
                            "job's hashes)" % (100.0 * k_units.value / (3.0 * hashes)),
                  "launches": int(k_launches.value), "avg_launch_us": (k_ms.value / n_l) * 1e3,
-                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")) or {}).get("bytes_per_launch"),
-                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")),
+                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES) or {}).get("bytes_per_launch"),
+                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES),
                  "hbm": {"achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}})
     held = ((out["timed"]["telemetry"] or {}).get("sclk_mhz_median")) if out.get("timed") else None
@@ -1430,7 +1432,7 @@ def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None, min_
                          "algorithmic_bytes": algo[k], "hbm_gb_per_s": algo[k] / phase_s[k] / 1e9,
                          "hbm_frac_of_8_tb_per_s": algo[k] / phase_s[k] / 1e9 / HBM_PEAK_GBS,
                          "traffic_per_launch_of_dominant_kernel": pmc_traffic(
-                             "sp::" + dominant[k][0], "airfri", ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json"))} for k in phase_s}
+                             "sp::" + dominant[k][0], "airfri", AIRFRI_PMC_FILES)} for k in phase_s}
     out["roofline"] = roof
     stark.prove(xs, ys, n_queries=8, seed=0)
     torch.cuda.synchronize()
