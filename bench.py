@@ -1037,42 +1037,62 @@ def main():
         result["build"] = build_provenance(lib)
         # GPU legs and CPU legs alternate, so that the device's activity is spread over the run instead of sitting in
         # its first seconds (the driver samples gpu_busy every few seconds: round 4's run showed it 0 % eight times).
+        # A secondary leg that fails must not take the headline with it: it is reported under its key as
+        # {"error": ...} (traceback on stderr) and the line is still printed.
+        def leg(key, fn):
+            try:
+                result[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                result[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                result.setdefault("failed_legs", []).append(key)
+
         levels = leaf_ints = gpu_root = tnb = None
         with_cpu = world == 1 and not args.no_cpu_baseline
         if with_cpu:
-            n_sample = 1 << HEIGHT  # up to the whole first level (32768 hashes), bounded by budget_s
-            # tree 0 of the forest buffer the FIRST TIMED call wrote (its inner nodes were zeroed before the
-            # timed regions): the parity legs check the timed computation, not a warm-up forest
-            tsl, tnb = timed_targets[0]
-            levels = tsl["levels"][tnb]
-            leaf_ints = _lib.unpack_felts(
-                (ctypes.c_uint64 * (4 * n_sample)).from_buffer_copy(
-                    levels[:n_sample].cpu().numpy().astype("<i8").tobytes()), n_sample)
-            base, cpu_out = cpu_baseline(leaf_ints)
-            gpu_l1 = _lib.unpack_felts(
-                (ctypes.c_uint64 * (4 * len(cpu_out))).from_buffer_copy(
-                    levels[n_leaves * tnb : n_leaves * tnb + len(cpu_out)].cpu().numpy().astype("<i8").tobytes()),
-                len(cpu_out))
-            base["matches_gpu"] = gpu_l1 == cpu_out
-            base["compared_with"] = "level 1 of tree 0 in the %d-tree buffer written by the timed region" % tnb
-            result["cpu_baseline"] = base
-            gpu_root = _lib.unpack_felts(
-                (ctypes.c_uint64 * 4).from_buffer_copy(
-                    levels[levels.shape[0] - tnb : levels.shape[0] - tnb + 1].cpu().numpy().astype("<i8").tobytes()), 1)[0]
+            try:
+                n_sample = 1 << HEIGHT  # up to the whole first level (32768 hashes), bounded by budget_s
+                # tree 0 of the forest buffer the FIRST TIMED call wrote (its inner nodes were zeroed before the
+                # timed regions): the parity legs check the timed computation, not a warm-up forest
+                tsl, tnb = timed_targets[0]
+                levels = tsl["levels"][tnb]
+                leaf_ints = _lib.unpack_felts(
+                    (ctypes.c_uint64 * (4 * n_sample)).from_buffer_copy(
+                        levels[:n_sample].cpu().numpy().astype("<i8").tobytes()), n_sample)
+                base, cpu_out = cpu_baseline(leaf_ints)
+                gpu_l1 = _lib.unpack_felts(
+                    (ctypes.c_uint64 * (4 * len(cpu_out))).from_buffer_copy(
+                        levels[n_leaves * tnb : n_leaves * tnb + len(cpu_out)].cpu().numpy().astype("<i8").tobytes()),
+                    len(cpu_out))
+                base["matches_gpu"] = gpu_l1 == cpu_out
+                base["compared_with"] = "level 1 of tree 0 in the %d-tree buffer written by the timed region" % tnb
+                result["cpu_baseline"] = base
+                gpu_root = _lib.unpack_felts(
+                    (ctypes.c_uint64 * 4).from_buffer_copy(
+                        levels[levels.shape[0] - tnb : levels.shape[0] - tnb + 1].cpu().numpy().astype("<i8").tobytes()), 1)[0]
+            except Exception as e:  # noqa: BLE001 - reported, and the C legs that need its inputs are skipped
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                result["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                result.setdefault("failed_legs", []).append("cpu_baseline")
+                leaf_ints = None
         if not args.no_airfri:
-            result["airfri"] = (airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline, min_timed_s=args.min_timed_s,
-                                              preheat_s=0.7 * args.preheat_s) if world == 1
-                                else airfri_multi)
+            if world == 1:
+                leg("airfri", lambda: airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline,
+                                                    min_timed_s=args.min_timed_s, preheat_s=0.7 * args.preheat_s))
+            else:
+                result["airfri"] = airfri_multi
             if forced_dist and airfri_multi is not None:  # the N > 1 reduction of the job rates, rehearsed at N = 1
                 result["airfri_dist_rehearsal"] = {k: airfri_multi[k] for k in
                                                    ("commits_per_sec", "commits_per_sec_slowest_gpu", "n_gpus")}
-        if with_cpu:
-            result["cpu_baseline_c"] = cpu_baseline_c(leaf_ints, gpu_root)
-            result["cpu_baseline_opt"] = cpu_baseline_opt(leaf_ints, gpu_root)
+        if with_cpu and leaf_ints is not None and gpu_root is not None:
+            leg("cpu_baseline_c", lambda: cpu_baseline_c(leaf_ints, gpu_root))
+            leg("cpu_baseline_opt", lambda: cpu_baseline_opt(leaf_ints, gpu_root))
         if world == 1 and not args.no_extras:
-            result["extra"] = extras(torch, lib, _lib, dev, stream)
+            leg("extra", lambda: extras(torch, lib, _lib, dev, stream))
         if with_cpu:
-            result["cpu_baseline_ecdsa"] = cpu_baseline_ecdsa()
+            leg("cpu_baseline_ecdsa", cpu_baseline_ecdsa)
         result["summary"] = summary_object(result)  # LAST key: both halves of the metric survive a truncated tail
         print(json.dumps(result))
     if dist is not None:
