@@ -754,6 +754,86 @@ ped_finish_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, int
   }
 }
 
+// Kernel B with the prefix products (and, while they fit, the ZZ values) of a thread kept in LDS instead of the
+// sPre plane in HBM (round 5).  The finish launch of a big level is bound by its traffic, not by its arithmetic:
+// per hash it read ZZ twice, wrote and re-read the prefix product and read X - 212 B against 921 instructions,
+// 139 MB in 42 us for the 655 360 hashes of level 0 of the driver's forest (3.3 TB/s).  A block of 256 threads owns
+// the whole LDS of its CU here (the launch is one wave per SIMD by design, finish_threads), so K <= 16 prefix products
+// per thread fit (K x 9 KiB), and K <= 8 of prefix + ZZ: 104 B per hash are left (ZZ, X, out).  Dynamic indexing of
+// LDS keeps the loops rolled (the unrolled register-resident form overflows the instruction cache, see above).
+template <bool Z_IN_LDS>
+__global__ void __launch_bounds__(256)
+ped_finish_lds_kernel(const int32_t* __restrict__ sX, int32_t* __restrict__ sZZ, size_t n, size_t T,
+                      uint64_t* __restrict__ out, size_t ostride, uint8_t* __restrict__ status,
+                      unsigned* __restrict__ flag, int kmax) {
+  extern __shared__ int32_t fin_lds[];  // pre: [kmax][9][256], then (Z_IN_LDS) z: [kmax][9][256]
+  int32_t* lpre = fin_lds;
+  int32_t* lz = fin_lds + (size_t)kmax * NL * 256;
+  auto lds_put = [&](int32_t* base, size_t j, const fe& v) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) base[((j * NL + k) << 8) + threadIdx.x] = v.l[k];
+  };
+  auto lds_get = [&](const int32_t* base, size_t j) {
+    fe v;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) v.l[k] = base[((j * NL + k) << 8) + threadIdx.x];
+    return v;
+  };
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const size_t cnt = t < n ? (n - t + T - 1) / T : 0;  // number of elements owned (<= kmax: the host checked)
+  fe run = FE_ONE_M;
+  if (cnt > 0) {
+    fe znext = load_limbs(sZZ, n, t);
+#pragma unroll 1
+    for (size_t j = 0; j < cnt; ++j) {
+      const fe z = znext;
+      if (j + 1 < cnt) znext = load_limbs(sZZ, n, t + (j + 1) * T);
+      lds_put(lpre, j, run);
+      if (Z_IN_LDS) lds_put(lz, j, z);
+      run = fe_mul(run, z);
+    }
+  }
+  if (fe_is_zero(run)) {  // rare: find the zero factors, flag them, and redo the products without them
+    run = FE_ONE_M;
+    size_t j = 0;
+#pragma unroll 1
+    for (size_t e = t; e < n; e += T, ++j) {
+      fe z = load_limbs(sZZ, n, e);
+      if (fe_is_zero(z)) {
+        z = FE_ONE_M;
+        store_limbs(sZZ, n, e, z);
+        if (status) status[e] = SP_HASH_UNHASHABLE;
+        if (flag) atomicOr(flag, (unsigned)SP_HASH_UNHASHABLE);
+      }
+      lds_put(lpre, j, run);
+      if (Z_IN_LDS) lds_put(lz, j, z);
+      run = fe_mul(run, z);
+    }
+  }
+  size_t e = cnt > 0 ? t + (cnt - 1) * T : 0;
+  fe zn = run, xn = run;
+  if (cnt > 0) {
+    if (!Z_IN_LDS) zn = load_limbs(sZZ, n, e);
+    xn = load_limbs(sX, n, e);
+  }
+  fe inv = fe_inv_shared_quad<2, true>(run, (int)(threadIdx.x & 3));
+#pragma unroll 1
+  for (size_t j = cnt; j-- > 0;) {
+    const fe z = Z_IN_LDS ? lds_get(lz, j) : zn, xv = xn;
+    const fe pre = lds_get(lpre, j);
+    const size_t cur = t + j * T;
+    if (j > 0) {
+      if (!Z_IN_LDS) zn = load_limbs(sZZ, n, cur - T);
+      xn = load_limbs(sX, n, cur - T);
+    }
+    const fe zinv = fe_mul(inv, pre);
+    inv = fe_mul(inv, z);
+    const fe xa = fe_mul(xv, zinv);
+    st_u256(out + 4 * cur * ostride, fe_pack(fe_canon(xa)));
+  }
+}
+
 // Full affine point (x, y) per item - pedersen_hash_as_point (signature.py:300-318), a testing
 // helper in the reference; one thread does its own inversion.
 __global__ void __launch_bounds__(128)
@@ -873,6 +953,24 @@ static size_t parse_split_lanes() {
   return ((size_t)v + 255) & ~(size_t)255;
 }
 static size_t g_split_lanes = parse_split_lanes();
+static bool g_finish_lds = getenv("STARKPERP_NO_FINISH_LDS") == nullptr;  // A/B switch
+// The LDS form of the finish kernel takes up to 144 KiB of dynamic LDS: the limit is a per-function, per-DEVICE
+// attribute, raised once for every device a context runs on (the caller holds the context lock).
+static int finish_lds_ready() {
+  static std::map<int, int> done;  // device -> SP_OK / SP_ERR_HIP
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return SP_ERR_HIP;
+  auto it = done.find(dev);
+  if (it != done.end()) return it->second;
+  const int want = 16 * NL * 256 * (int)sizeof(int32_t);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ped_finish_lds_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, want);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ped_finish_lds_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return done[dev] = (e == hipSuccess ? SP_OK : SP_ERR_HIP);
+}
 static size_t finish_threads(size_t n) {
   // K hashes share one inversion (Montgomery's trick, 3 multiplications per extra hash).  The
   // inversion is a ~14 k-instruction dependent chain of mostly 32-bit ops, and a SIMD is already
@@ -1130,8 +1228,18 @@ static int enqueue_pedersen_impl(const uint64_t* x, size_t xs, const uint64_t* y
     const size_t T = finish_threads(n);
     const unsigned tpb = T >= 256 ? 256 : 64;
     const unsigned blocksB = (unsigned)((T + tpb - 1) / tpb);
-    hipLaunchKernelGGL(ped_finish_kernel, dim3(blocksB), dim3(tpb), 0, st, s.X, s.ZZ, s.Pre, n, T, out,
-                       os, status, flag);
+    const size_t kmax = (n + T - 1) / T;  // elements per thread
+    if (g_finish_lds && tpb == 256 && kmax >= 2 && kmax <= 16 && finish_lds_ready() == SP_OK) {
+      const bool z_too = kmax <= 8;
+      const size_t lds_bytes = kmax * NL * 256 * sizeof(int32_t) * (z_too ? 2 : 1);
+      if (z_too) hipLaunchKernelGGL((ped_finish_lds_kernel<true>), dim3(blocksB), dim3(256), lds_bytes, st, s.X, s.ZZ, n, T,
+                                    out, os, status, flag, (int)kmax);
+      else hipLaunchKernelGGL((ped_finish_lds_kernel<false>), dim3(blocksB), dim3(256), lds_bytes, st, s.X, s.ZZ, n, T,
+                              out, os, status, flag, (int)kmax);
+    } else {
+      hipLaunchKernelGGL(ped_finish_kernel, dim3(blocksB), dim3(tpb), 0, st, s.X, s.ZZ, s.Pre, n, T, out,
+                         os, status, flag);
+    }
   }
   SP_HIP(hipGetLastError());
   return SP_OK;
