@@ -14,25 +14,27 @@ chip idle.  With N > 1 ranks every step is a tree of N * 2^16 leaves: each rank 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `value` = Pedersen hashes/s over the whole job.
+Rank 0 prints ONE JSON line of at most 8 KB on stdout (benchlib/line.py holds it to that: round 5's
+20 KB line could not be parsed by the driver) and writes everything else it measured - telemetry
+windows, burst, region percentiles, per-phase tables, configs[2] timings, provenance - to
+bench_detail.json beside this script and to stderr.  `value` = Pedersen hashes/s over the whole job.
   roofline      the dominant kernel (ped_accumulate_kernel, the one-lane-per-hash bulk launches) against
                 the roofline that binds it - VALU issue - from HIP events around those launches inside
-                the timed region; the HBM fraction the contract names is the secondary `hbm` field;
-                `traffic` = HBM bytes per launch from rocprofv3 PMC passes, with the configuration
-                they were collected on.
+                the timed region; the HBM fraction the contract names is the `hbm` field; `traffic` = HBM
+                bytes per launch from rocprofv3 PMC passes (profiles/, named in `sources`).
   airfri        the second half of BASELINE.json's metric: 2^20-row AIR+FRI commit jobs per second
-                (configs[3]), per-phase times with each phase's dominant kernel and HBM fraction, its own
-                roofline and a CPU baseline (oracle/stark_ref.py, build-defined, parity unpinned).  With
-                N > 1 ranks: independent 2^20-row jobs on every GPU started together (no data-path
-                collective), commits_per_sec = N x the slowest rank's rate; ONE trace sharded over the
-                ranks is `--workload airfri`.
+                (configs[3]) with its own roofline fraction and CPU leg.  With N > 1 ranks: independent
+                jobs on every GPU, commits_per_sec = N x the slowest rank's rate; ONE trace sharded over
+                the ranks is `--workload airfri`.
   cpu_baseline  the oracle (pure-Python restatement of the reference algorithm) on the host cores, a
-                bounded sample of the same tree; cpu_baseline_c the same algorithm in C on the whole tree;
-                cpu_baseline_opt an optimised CPU comparator (windowed tables + batched affine additions).
+                bounded sample of the same tree; the C port and the optimised CPU comparator are in the
+                detail file and in `summary`.
+
+This file keeps the argument parsing, the timed region, the CPU-baseline legs (the only code outside tests/ and
+smoke() that touches oracle/) and the print; the plumbing lives in benchlib/ (unit-tested on CPU).
 """
 import argparse
 import ctypes
-import json
 import os
 import sys
 import time
@@ -45,18 +47,16 @@ sys.path.insert(0, os.path.join(ROOT, "stark-perpetual_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, ROOT)
 
-HEIGHT = 16
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-ALGO_BYTES_PER_HASH = 96  # two 32-byte felts in, one out
+from benchlib import telemetry as _telemetry  # noqa: E402  (no torch import, no GPU touched at import time)
+from benchlib.common import HEIGHT, median, seeded_felts  # noqa: E402
+from benchlib.launch import dist_report, init_library_one_plan, open_process_group, reduce_scalar, self_spawn  # noqa: E402
+from benchlib.line import emit, main_line  # noqa: E402
+from benchlib.merkle import combine_check, merkle_detail, plan  # noqa: E402
+from benchlib.provenance import build_provenance  # noqa: E402
+from benchlib.telemetry import Telemetry  # noqa: E402,F401  (re-exported: tests and tools read bench.Telemetry)
 
 
-def seeded_felts(torch, n, seed, device):
-    """n felts < 2^250 as an int64 [n, 4] tensor (little-endian limbs)."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    t = torch.randint(-(2**63), 2**63 - 1, (n, 4), dtype=torch.int64, generator=g)
-    t[:, 3] &= (1 << 58) - 1
-    return t.to(device)
-
+# ---- CPU-baseline legs: the oracle as the checker / the comparator, never the thing measured or shipped ----------
 
 def _cpu_hash_chunk(pairs):
     from oracle import ref_py
@@ -230,449 +230,35 @@ def cpu_baseline_ecdsa(budget_s=1.5):
             "sign_matches_gpu": bool(gpu_sigs == sigs), "verify_matches_gpu": bool(list(gpu_ok) == verdicts),
             "all_verified": bool(all(verdicts))}
 
-
-def summary_object(result):
-    """Compact digest, appended as the LAST key of the line so that a reader who keeps only the tail of the
-    line still sees both halves of BASELINE.json's metric and the figures the verdicts ask about."""
-    def g(d, *path):
-        for k in path:
-            if not isinstance(d, dict) or k not in d:
-                return None
-            d = d[k]
-        return d
-    np_c3 = g(result, "extra", "c3_4096_orders_numpy_entry_points_seconds", "total")
-    s = {
-        "pedersen_hashes_per_sec": result.get("value"),
-        "ms_per_step": result.get("ms_per_step"),
-        "roofline_frac_bulk_launches": g(result, "roofline", "frac"),
-        "roofline_frac_whole_region": g(result, "roofline", "whole_region", "frac"),
-        "roofline_frac_at_held_clock": g(result, "roofline", "frac_at_held_clock"),
-        "sclk_mhz_median": g(result, "telemetry", "sclk_mhz_median"),
-        "power_w_median": g(result, "telemetry", "power_w_median"),
-        "timed_total_s": g(result, "timed_regions", "total_s"),
-        "burst_pedersen_hashes_per_sec": g(result, "burst", "value"),
-        "sustained_over_burst": result.get("sustained_over_burst"),
-        "lib_sha256_16": (g(result, "build", "lib_sha256") or "")[:16],
-        "airfri_commits_per_sec": g(result, "airfri", "commits_per_sec"),
-        "airfri_seconds_per_job": g(result, "airfri", "seconds_per_job_one_stream"),
-        "airfri_roofline_frac": g(result, "airfri", "roofline", "frac"),
-        "airfri_cpu_baseline_commits_per_sec": g(result, "airfri", "cpu_baseline", "scaled_to_2p20_rows", "commits_per_sec"),
-        "single_tree_ms": g(result, "extra", "single_tree_rebuild_ms_one_stream"),
-        "bulk_pedersen_hashes_per_sec": g(result, "extra", "bulk_pedersen_hashes_per_sec"),
-        "c3_total_ms": None if np_c3 is None else 1e3 * np_c3,
-        "c3_one_call_ms": (lambda v: None if v is None else 1e3 * v)(
-            g(result, "extra", "c3_4096_orders_one_call_seconds", "best_of_3")),
-        "c3_tree_update_ms": (lambda v: None if v is None else 1e3 * v)(
-            g(result, "extra", "c3_4096_orders_numpy_entry_points_seconds", "orders_tree_height64_update_on_existing_state")),
-        "ecdsa_verifies_per_sec_ladder": g(result, "extra", "ecdsa_verifies_per_sec_x_only_2p16"),
-        "ecdsa_verifies_per_sec_key_tables": g(result, "extra", "ecdsa_verifies_per_sec_key_tables_2p16"),
-        "ecdsa_signs_per_sec": g(result, "extra", "ecdsa_signs_per_sec_2p16"),
-        "ecdsa_signs_per_sec_list_api_host_inclusive": g(result, "extra", "ecdsa_signs_per_sec_2p16_host_inclusive"),
-        "cpu_hashes_per_sec_python_port": g(result, "cpu_baseline", "value"),
-        "cpu_hashes_per_sec_c_port": g(result, "cpu_baseline_c", "value"),
-        "cpu_hashes_per_sec_optimised": g(result, "cpu_baseline_opt", "value"),
-        "cpu_sign_per_sec_all_cores": g(result, "cpu_baseline_ecdsa", "sign_per_sec_all_cores"),
-        "cpu_verify_per_sec_all_cores": g(result, "cpu_baseline_ecdsa", "verify_per_sec_all_cores"),
-        "cpu_cores": g(result, "cpu_baseline", "cores"),
-        "parity_in_run": {"level1_matches_gpu": g(result, "cpu_baseline", "matches_gpu"),
-                          "root_matches_c_oracle": g(result, "cpu_baseline_c", "root_matches_gpu"),
-                          "root_matches_optimised_cpu": g(result, "cpu_baseline_opt", "root_matches_gpu"),
-                          "sign_matches_gpu": g(result, "cpu_baseline_ecdsa", "sign_matches_gpu"),
-                          "verify_matches_gpu": g(result, "cpu_baseline_ecdsa", "verify_matches_gpu")},
-    }
-    return s
-
-
-def combine_check(slot, world, _lib):
-    """N > 1: the job root of tree 0 of the last call issued on stream 0, recomputed from the gathered
-    sub-roots (rank order) through the library's host-pointer tree entry point - a check of the
-    exchange and of the tree-major transposition, independent of the lockstep device path."""
-    try:
-        from starkperp import batch
-        nb = slot["last_nb"]
-        top = slot["top"][: nb * (2 * world - 1)].cpu().numpy().astype("<i8")
-        felts = _lib.unpack_felts((ctypes.c_uint64 * (4 * top.shape[0])).from_buffer_copy(top.tobytes()), top.shape[0])
-        leaves, root = felts[:world], felts[nb * (2 * world - 1) - nb]
-        return batch.merkle_root(leaves) == root
-    except Exception as e:  # noqa: BLE001 - a failed self-check must not void the measurement
-        sys.stderr.write("bench: combine check skipped (%s)\n" % e)
-        return None
-
-
-VALU_PEAK_SIMDS, VALU_NOMINAL_GHZ = 1024, 2.4
-# PMC passes of the airfri workload, newest first (no round-5 file: the prover kernels did not change)
-AIRFRI_PMC_FILES = ("r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json", "r02_pmc_traffic_airfri.json")
-VALU_ISSUE_FILES = ("r04_valu_issue.json", "r03_valu_issue.json", "r02_valu_issue.json", "r01_valu_issue.json")
-
-
-def _valu_issue_file():
-    for name in VALU_ISSUE_FILES:
-        try:
-            return json.load(open(os.path.join(ROOT, "profiles", name))), name
-        except Exception:
-            continue
-    return {}, None
-
-
-def valu_cycles_per_instr():
-    """Issue interval of the bulk hash kernel's instruction MIX in shader cycles per wave64 instruction per SIMD:
-    every opcode of the kernel priced at the best interval tools/ubench/valu_rate.hip measured for it at any
-    occupancy (profiles/r04_valu_rate_ubench.txt), weighted by the kernel's static histogram (tools/valu_mix.py).
-    4.04 for ped_accumulate_kernel; rounds 1 - 3 used a flat 4."""
-    m, _ = _valu_issue_file()
-    return float(m.get("cycles_per_wave64_valu_instr", 4.0))
-
-
-def _valu_counts(window_bits):
-    """SQ_INSTS_VALU per hash of the bulk kernels (rocprofv3 --pmc, profiles/r0N_valu_issue.json, newest
-    first); None when there is no measurement for this window width."""
-    for name in VALU_ISSUE_FILES:
-        try:
-            m = json.load(open(os.path.join(ROOT, "profiles", name)))
-            w = m["window_bits"][str(window_bits)]
-            return w["accumulate_instr_per_hash"], w["finish_instr_per_hash"], name
-        except Exception:
-            continue
-    return None
-
-
-def valu_peak():
-    return VALU_PEAK_SIMDS * VALU_NOMINAL_GHZ * 1e9 / valu_cycles_per_instr()
-
-
-VALU_PEAK_NOTE = ("peak = 1024 SIMDs x 2.4 GHz / c_mix, c_mix = the issue interval of THIS kernel's instruction mix. "
-                  "Round 4 settled the interval per opcode in real shader cycles (tools/ubench/valu_rate.hip: waves per "
-                  "SIMD 1 - 8, 16 independent chains, clock from s_memtime / s_memrealtime inside every wave; "
-                  "profiles/r04_valu_rate_ubench.txt): v_add / v_sub / v_and / v_xor / v_mov / v_ashrrev_i32 / v_fma_f32 "
-                  "issue every 2.3 - 2.6 cycles - the guide's SIMD-32 figure - but every multiply (v_mad_i64_i32 4.5 - 5.0, "
-                  "v_mul_lo 4.2), every 64-bit shift or add, v_alignbit, v_bfe, every three-operand or carry-writing "
-                  "instruction, every DPP move and all of FP64 issue every 4.1 - 4.8 cycles, and nothing improves past 4 "
-                  "waves per SIMD (v_mad_i64_i32: 4.8 - 4.9 at 2 waves, 4.5 - 4.8 at 4 - 6, 5.0 at 8).  The bulk kernel is 52 % "
-                  "multiply-adds and 81 % four-cycle opcodes: c_mix = 4.04 with every opcode at its best interval "
-                  "(tools/valu_mix.py, profiles/r04_valu_issue.json), 4.34 at the kernel's own 2 waves per SIMD.  "
-                  "frac_at_2_cycle_peak prices the same rate against MI355X_MICROARCH.md's 2-cycle figure, which only "
-                  "the simple 32-bit opcodes reach.  Under this kernel the package runs at its power limit and holds "
-                  "2.08 - 2.10 GHz of the nominal 2.4 (profiles/r03_power_clock_bulk.txt): frac is against the NOMINAL clock")
-
-
-def valu_issue(hashes_per_sec, window_bits, workload, include_finish=True):
-    """The roofline that binds the hash kernels: wave64 VALU instructions issued per
-    second against the chip's issue peak."""
-    c = _valu_counts(window_bits)
-    if c is None:
-        return None
-    per_hash = c[0] + (c[1] if include_finish else 0)
-    achieved = hashes_per_sec * per_hash / 64.0
-    peak = valu_peak()
-    return {"bound": "valu_issue", "workload": workload, "instr_per_hash": per_hash,
-            "instr_source": "profiles/" + c[2], "achieved": achieved, "peak": peak,
-            "unit": "wave64 VALU instr/s", "frac": achieved / peak,
-            "cycles_per_instr_of_the_mix": valu_cycles_per_instr(),
-            "frac_at_2_cycle_peak": achieved / (VALU_PEAK_SIMDS * VALU_NOMINAL_GHZ * 1e9 / 2.0),
-            "frac_at_flat_4_cycle_peak": achieved / (VALU_PEAK_SIMDS * VALU_NOMINAL_GHZ * 1e9 / 4.0)}
-
-
-def pmc_traffic(kernel, this_config, files=("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE
-    and --pmc WRITE_SIZE runs, tools/pmc_traffic.py; units and gfx950 calibration in its docstring), and
-    the configuration those passes ran - traffic is only comparable with this run when they agree."""
-    for name in files:
-        try:
-            m = json.load(open(os.path.join(ROOT, "profiles", name)))
-            k = m["kernels"][kernel]
-            cfg = m.get("config", "bench.py r01 default: --steps 128 --warmup 16, 64 trees per call, 2 streams, "
-                                  "26-bit windows (NOT this run's configuration)")
-            return {"bytes_per_launch": k.get("hbm_bytes_per_launch_fetch_doubled", k["hbm_bytes_per_launch"]),
-                    "fetch_size_doubled_for_coalesced_reads": "hbm_bytes_per_launch_fetch_doubled" in k,
-                    "fetch_bytes_per_launch": k["fetch_bytes_per_launch"],
-                    "write_bytes_per_launch": k["write_bytes_per_launch"], "launches_profiled": k["launches"],
-                    "source": "profiles/" + name, "collected_on": cfg,
-                    "same_configuration_as_this_run": m.get("config_key") == this_config}
-        except Exception:
-            continue
-    return None
-
-
-def self_spawn(n):
-    """bench.py --gpus N started without torch.distributed.run: launch N ranks on this node through it (one process
-    per GPU, rendezvous on 127.0.0.1 at a free port), same arguments, stdout / stderr passed through."""
-    import socket
-    import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stderr.write("bench: --gpus %d without RANK/WORLD_SIZE: launching %s\n" % (n, " ".join(cmd[1:8])))
-    rc = subprocess.call(cmd, env=env)
-    if rc != 0:
-        raise SystemExit(rc)
-
-
-class Telemetry:
-    """Shader clock, package power and junction temperature of ONE device, sampled from a side thread while the
-    timed regions run (the 50 ms window of rounds 1 - 4 sat inside the power controller's ramp,
-    profiles/r03_power_clock_bulk.txt).  Source: the amdgpu hwmon files of the PCI function HIP reports for the
-    device (freq1_input = sclk in Hz, power1_input = socket power in uW, temp2_input = junction in mC); a box whose
-    sysfs does not show them falls back to `rocm-smi --json`.  Reading costs well under a millisecond and the
-    timed loop spends its time inside ctypes calls that release the GIL."""
-
-    def __init__(self, dev_index, period_s=0.02):
-        import threading
-        self.period = period_s
-        self.samples = []  # (t, sclk_mhz, power_w, temp_c)
-        self._stop = threading.Event()
-        self._thread = None
-        self.source = None
-        self._files = self._find_hwmon(dev_index)
-        if self._files:
-            self.source = "sysfs hwmon " + self._files["dir"]
-        else:
-            import shutil
-            if shutil.which("rocm-smi"):
-                self.source = "rocm-smi --showpower --showclocks --json (card0)"
-                self.period = max(period_s, 0.25)
-
-    @staticmethod
-    def _find_hwmon(dev_index):
-        import glob
-        try:
-            # the HIP runtime this process already runs on (torch's, loaded RTLD_GLOBAL by starkperp._lib): never
-            # dlopen a second libamdhip64 by name
-            bus = None
-            try:
-                buf = ctypes.create_string_buffer(64)
-                if ctypes.CDLL(None).hipDeviceGetPCIBusId(buf, 64, int(dev_index)) == 0:
-                    bus = buf.value.decode().lower()
-            except (AttributeError, OSError):
-                bus = None
-            if not bus:
-                import torch
-                pr = torch.cuda.get_device_properties(int(dev_index))
-                bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-            for d in glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bus):
-                if os.path.exists(os.path.join(d, "freq1_input")) and (
-                        os.path.exists(os.path.join(d, "power1_input")) or os.path.exists(os.path.join(d, "power1_average"))):
-                    return {"dir": d, "bus": bus, "sclk": os.path.join(d, "freq1_input"),
-                            "power": os.path.join(d, "power1_input") if os.path.exists(os.path.join(d, "power1_input"))
-                            else os.path.join(d, "power1_average"),
-                            "temp": os.path.join(d, "temp2_input"), "cap": os.path.join(d, "power1_cap")}
-        except Exception:  # noqa: BLE001 - telemetry never breaks the measurement
-            return None
-        return None
-
-    @staticmethod
-    def _read_num(path):
-        try:
-            with open(path) as f:
-                return float(f.read().strip())
-        except Exception:  # noqa: BLE001
-            return None
-
-    def sample(self):
-        t = time.perf_counter()
-        if self._files:
-            sclk, pw, tc = (self._read_num(self._files[k]) for k in ("sclk", "power", "temp"))
-            self.samples.append((t, None if sclk is None else sclk / 1e6, None if pw is None else pw / 1e6,
-                                 None if tc is None else tc / 1e3))
-        elif self.source:
-            import subprocess
-            try:
-                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True,
-                                     text=True, timeout=10).stdout
-                card = next(iter(json.loads(out).values()))
-                sclk = pw = None
-                for k, v in card.items():
-                    if k.lower().startswith("sclk clock speed"):
-                        sclk = float("".join(ch for ch in v if ch.isdigit() or ch == "."))
-                    if "power (w)" in k.lower():
-                        pw = float(v)
-                self.samples.append((t, sclk, pw, None))
-            except Exception:  # noqa: BLE001
-                pass
-
-    def start(self):
-        import threading
-        if not self.source or self._thread is not None:
-            return self
-
-        def run():
-            while not self._stop.is_set():
-                self.sample()
-                self._stop.wait(self.period)
-        self._thread = threading.Thread(target=run, daemon=True)
-        self._thread.start()
-        return self
-
-    def stop(self):
-        if self._thread is not None:
-            self._stop.set()
-            self._thread.join()
-            self._thread = None
-
-    def window(self, t0, t1):
-        """Median / min / max of the samples taken between the perf_counter times t0 and t1."""
-        rows = [s for s in self.samples if t0 <= s[0] <= t1]
-
-        def stat(i):
-            v = sorted(x[i] for x in rows if x[i] is not None)
-            if not v:
-                return None
-            return {"median": v[len(v) // 2], "min": v[0], "max": v[-1]}
-        sclk, pw, tc = stat(1), stat(2), stat(3)
-        return {"samples": len(rows), "seconds": t1 - t0,
-                "sclk_mhz_median": sclk and sclk["median"], "sclk_mhz_min": sclk and sclk["min"],
-                "sclk_mhz_max": sclk and sclk["max"],
-                "power_w_median": pw and pw["median"], "power_w_min": pw and pw["min"], "power_w_max": pw and pw["max"],
-                "junction_c_median": tc and tc["median"]}
-
-    def describe(self):
-        cap = self._read_num(self._files["cap"]) if self._files else None
-        return {"source": self.source, "period_s": self.period, "pci_bus": self._files and self._files["bus"],
-                "power_cap_w": None if cap is None else cap / 1e6}
-
-
-def build_provenance(lib):
-    """Which binary produced this line: sha256 of the loaded libstarkperp.so, what the
-    library says it was compiled with (sp_build_info: compiler, HIP version, offload arch, compile date) and the
-    toolchain found on THIS box."""
-    import hashlib
-    import subprocess
-    from starkperp import _lib
-    out = {"lib": os.path.relpath(_lib.LIB_PATH, ROOT)}
-    try:
-        h = hashlib.sha256()
-        with open(_lib.LIB_PATH, "rb") as f:
-            for blk in iter(lambda: f.read(1 << 20), b""):
-                h.update(blk)
-        out["lib_sha256"] = h.hexdigest()
-        out["lib_bytes"] = os.path.getsize(_lib.LIB_PATH)
-        out["lib_mtime_utc"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(_lib.LIB_PATH)))
-    except OSError as e:
-        out["lib_sha256"] = "unreadable: %s" % e
-    try:
-        lib.sp_build_info.restype = ctypes.c_char_p
-        out["compiled_with"] = lib.sp_build_info().decode()
-    except Exception as e:  # noqa: BLE001
-        out["compiled_with"] = "sp_build_info unavailable: %s" % e
-    try:
-        v = subprocess.run(["hipcc", "--version"], capture_output=True, text=True, timeout=20).stdout.splitlines()
-        out["hipcc_on_this_box"] = "; ".join(l.strip() for l in v[:2])
-    except Exception as e:  # noqa: BLE001
-        out["hipcc_on_this_box"] = "not found (%s)" % type(e).__name__
-    try:
-        out["bench_py_sha16"] = hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16]
-    except OSError:
-        pass
-    return out
-
-
-TELEMETRY = None
-
-
-def dist_report(torch, dist, dev, dev_index, world, rank, forced, value, lib):
-    """What the process group looked like - collective: every rank calls it.  Rank 0 gets
-    {backend, world_size, rccl_version, per-rank device name / PCI bus / free HBM / window bits, the N x N
-    hipDeviceCanAccessPeer matrix, the link types rocm-smi reports}; nothing here may break the line."""
-    info = {"backend": dist.get_backend(), "world_size": world, "forced_at_one_gpu": forced}
-    try:
-        free_b, total_b = torch.cuda.mem_get_info(dev)
-        pr = torch.cuda.get_device_properties(dev)
-        mine = {"rank": rank, "device_index": dev_index, "name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None),
-                "pci": "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
-                                             getattr(pr, "pci_device_id", 0)),
-                "free_hbm_gib": free_b / 2**30, "total_hbm_gib": total_b / 2**30,
-                "window_bits": int(lib.sp_window_bits()), "table_gib": lib.sp_table_bytes() / 2**30,
-                "pid": os.getpid(), "cpus_allowed": len(os.sched_getaffinity(0)),
-                "local_hashes_per_sec": value}
-    except Exception as e:  # noqa: BLE001
-        mine = {"rank": rank, "error": repr(e)}
-    try:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        info["ranks"] = gathered
-    except Exception as e:  # noqa: BLE001
-        info["ranks"] = [mine]
-        info["ranks_error"] = repr(e)
-    if rank != 0:
-        return info
-    lv = [r.get("local_hashes_per_sec") for r in info["ranks"] if isinstance(r, dict) and r.get("local_hashes_per_sec")]
-    if lv:
-        info["per_rank_value"] = {"min": min(lv), "max": max(lv), "unit": "hashes/s on a rank's own clock (its 2^16-leaf "
-                                  "subtrees per step; the job's value uses the slowest rank's region)"}
-    try:
-        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
-    except Exception as e:  # noqa: BLE001
-        info["rccl_version"] = "unknown (%s)" % type(e).__name__
-    info["env"] = {k: os.environ[k] for k in ("NCCL_DEBUG", "NCCL_P2P_DISABLE", "NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE",
-                                               "HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
-                                               "GPU_MAX_HW_QUEUES") if k in os.environ}
-    try:  # peer access between the devices the ranks run on, from this process (it sees all of them under torchrun)
-        devs = [r.get("device_index", i) for i, r in enumerate(info["ranks"])]
-        n_vis = torch.cuda.device_count()
-        info["visible_devices"] = n_vis
-        info["peer_access"] = [[(1 if a == b else int(torch.cuda.can_device_access_peer(a, b)))
-                                if a < n_vis and b < n_vis else None for b in devs] for a in devs]
-    except Exception as e:  # noqa: BLE001
-        info["peer_access"] = "unavailable (%s)" % type(e).__name__
-    if world > 1:
-        try:
-            import subprocess
-            t = subprocess.run(["rocm-smi", "--showtopotype", "--json"], capture_output=True, text=True, timeout=30).stdout
-            info["link_types"] = json.loads(t)
-        except Exception as e:  # noqa: BLE001
-            info["link_types"] = "unavailable (%s)" % type(e).__name__
-    return info
-
-
-def median(v):
-    s = sorted(v)
-    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--trees-per-call", type=int, default=64,
-                    help="independent 2^16-leaf rebuilds advanced in lockstep by one library call "
-                         "(sp_merkle_forest_dev: one launch pair per level serves all of them; the upper "
-                         "levels of a single rebuild are latency-bound and leave most of the chip idle); "
-                         "1 = strictly one tree per call")
+                    help="cap on the independent 2^16-leaf rebuilds advanced in lockstep by one library call "
+                         "(sp_merkle_forest_dev); 1 = strictly one tree per call")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the lockstep calls / independent jobs are issued on round-robin "
                          "(0 = 2 for the merkle workload, 3 for airfri)")
     ap.add_argument("--workload", choices=["merkle", "airfri"], default="merkle",
-                    help="merkle = BASELINE.json configs[1] (default, the headline line); airfri = one "
-                         "2^20-row AIR+FRI commit job per GPU per step (configs[3]; with N GPUs the "
-                         "N * 2^20-row trace of configs[4] as disjoint row ranges, roots combined over RCCL)")
+                    help="merkle = BASELINE.json configs[1] (default, the headline line); airfri = one 2^20-row AIR+FRI "
+                         "commit job per GPU per step (configs[3]; N GPUs: the N * 2^20-row trace of configs[4] sharded)")
     ap.add_argument("--plan", default="",
-                    help="comma-separated call sizes (trees per lockstep call, issued round-robin over the "
-                         "streams) for the TIMED steps; must sum to --steps.  Default: see plan()")
+                    help="comma-separated call sizes (trees per lockstep call, round-robin over the streams) for the "
+                         "TIMED steps; must sum to --steps.  Default: benchlib.merkle.plan")
     ap.add_argument("--window-bits", type=int, default=26,
-                    help="log2 of the entries per signed window of the Pedersen tables: 26 = 75 GiB of the "
-                         "288 GB HBM as tables, 19 table entries per hash (0.12 - 0.13 s to build, outside the timed "
-                         "region; 27 = 155 GiB / 18 entries is no faster: its gathers stop hiding behind the "
-                         "arithmetic); 0 = the library default 21 = 4.3 GiB, 23 entries per hash.  If the "
-                         "wide tables cannot be allocated the bench falls back to the library default and "
-                         "says so in config")
-    ap.add_argument("--log-rows", type=int, default=20,
-                    help="airfri workload: log2 of the trace rows per GPU (20 = configs[3]; 24 = the whole "
-                         "configs[4] trace on ONE GPU, 14 GiB of columns and trees)")
+                    help="log2 of the entries per signed window of the Pedersen tables: 26 = 75 GiB of the 288 GB HBM, "
+                         "19 table entries per hash; 0 = the library default 21 = 4.3 GiB, 23 entries per hash.  If the "
+                         "wide tables cannot be allocated the bench falls back to the library default and says so")
+    ap.add_argument("--log-rows", type=int, default=20, help="airfri workload: log2 of the trace rows per GPU")
     ap.add_argument("--with-witness", action="store_true",
-                    help="airfri workload: generate the 2^k-row trace (witness) inside every job instead of "
-                         "treating it as input preparation")
+                    help="airfri workload: generate the trace (witness) inside every job instead of as input preparation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--force-dist", action="store_true",
-                    default=os.environ.get("STARKPERP_BENCH_FORCE_DIST") == "1",
-                    help="--gpus 1 only: create a world-size-1 RCCL process group anyway and take every branch the "
-                         "N > 1 runs take (sub-root all_gather + top forest, max / min reductions of the timings, the "
-                         "sharded AIR+FRI path with --workload airfri) - the one-GPU rehearsal of the multi-GPU launch")
+    ap.add_argument("--force-dist", action="store_true", default=os.environ.get("STARKPERP_BENCH_FORCE_DIST") == "1",
+                    help="--gpus 1 only: create a world-size-1 RCCL process group anyway and take every branch the N > 1 "
+                         "runs take - the one-GPU rehearsal of the multi-GPU launch")
     ap.add_argument("--min-timed-s", type=float, default=float(os.environ.get("STARKPERP_BENCH_MIN_TIMED_S", "3.0")),
                     help="the timed regions (each EXACTLY --steps steps between fences) are repeated until this many "
                          "seconds have been timed; value = the median region of that sustained window")
@@ -681,11 +267,12 @@ def main():
                          "the power controller has settled (profiles/r03_power_clock_bulk.txt: ~0.7 s)")
     ap.add_argument("--burst-s", type=float, default=0.05,
                     help="the 50 ms window of rounds 1 - 4, taken first, straight out of idle: reported as `burst`")
-    ap.add_argument("--no-airfri", action="store_true",
-                    help="merkle workload: skip the `airfri` object (the 2^20-row AIR+FRI half of the metric; at N > 1 "
-                         "independent jobs on every GPU)")
-    args = ap.parse_args()
+    ap.add_argument("--no-airfri", action="store_true", help="merkle workload: skip the `airfri` object")
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -693,8 +280,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
-            # `python bench.py --gpus N` without a launcher: start the N ranks ourselves,
-            # exactly as the driver would, and hand their single JSON line through
+            # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver
+            # would, and hand their single JSON line through
             return self_spawn(args.gpus)
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
@@ -705,96 +292,34 @@ def main():
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    dist = None
     forced_dist = bool(args.force_dist and world == 1)
-    if world > 1 or forced_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if forced_dist:
-            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        if share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-            # RCCL writes a version banner ("RCCL version : ...", five lines) to the C stdout when its first
-            # communicator comes up; through a pipe it would sit in the stdio buffer and land AFTER the JSON line at
-            # exit.  Bring the communicator up now with fd 1 pointed at stderr and flush: stdout carries ONE line.
-            sys.stdout.flush()
-            saved_fd = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                t0 = torch.zeros(1, device=dev)
-                dist.all_reduce(t0)
-                torch.cuda.synchronize()
-                ctypes.CDLL(None).fflush(None)
-            finally:
-                os.dup2(saved_fd, 1)
-                os.close(saved_fd)
+    dist = open_process_group(torch, dev, world, forced_dist, share_gpu) if (world > 1 or forced_dist) else None
 
     from starkperp import _lib
     from starkperp.distributed import combine_forest_dev
-
-    wide_error = None
-    try:
-        lib = _lib.ensure_init(dev_index, args.window_bits or None)
-    except _lib.StarkPerpError as e:
-        if not args.window_bits:
-            raise
-        wide_error = str(e)
-        lib = None
-    if dist is not None and args.window_bits:
-        # ONE table plan for the job: a single rank that cannot allocate the wide tables (a GPU
-        # with less free HBM) takes every rank to the library default - ranks on different plans would still agree on
-        # every hash, but the weak-scaling figure would mix two kernels' rates
-        okt = torch.tensor([0 if lib is None else 1], dtype=torch.int32, device=dev)
-        if dist.get_backend() == "gloo":
-            okt = okt.cpu()
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        if int(okt.item()) == 0 and lib is not None:
-            wide_error = "another rank could not allocate the %d-bit tables" % args.window_bits
-            _lib.load().sp_shutdown()
-            lib = None
-    if lib is None:
-        sys.stderr.write("bench: %d-bit tables unavailable (%s); using the library default\n" % (args.window_bits, wide_error))
-        lib = _lib.ensure_init(dev_index, None)
-    global TELEMETRY
-    TELEMETRY = Telemetry(dev_index).start() if rank == 0 else None
+    lib, wide_error = init_library_one_plan(torch, dist, dev, dev_index, args.window_bits)
+    tel = _telemetry.ACTIVE = Telemetry(dev_index).start() if rank == 0 else None
     if args.workload == "airfri":
-        return run_airfri(args, torch, dist, lib, _lib, dev, rank, world)
+        from benchlib.airfri import run_airfri
+        return run_airfri(args, torch, dist, lib, _lib, dev, rank, world, cpu_leg=cpu_airfri_baseline)
+
     n_leaves = 1 << HEIGHT
     n_streams = args.streams if args.streams > 0 else 2
     B = max(1, min(1024, int(args.trees_per_call)))  # independent rebuilds advanced in lockstep per call
-
-    def forest_felts(nb):
-        return nb * (2 * n_leaves - 1)
-
-    def plan(k):
-        """K steps (trees) as the fewest lockstep calls of <= B trees each, evenly sized.  Measured
-        (tools/plan_sweep*.sh): the larger the forest the better - one call of 64 beats two of 32 on
-        two streams (6.5 vs 6.1 x 10^8 hashes/s), and two calls of 64 on two streams overlap their
-        latency-bound tops (7.5 x 10^8)."""
-        if k <= 0:
-            return []
-        calls = (k + B - 1) // B
-        base, rem = divmod(k, calls)
-        return [base + (1 if i < rem else 0) for i in range(calls)]
-
     if args.plan:
         timed_plan = [int(v) for v in args.plan.split(",")]
         if sum(timed_plan) != args.steps or min(timed_plan) < 1 or max(timed_plan) > 1024:
             raise SystemExit("--plan must be positive call sizes <= 1024 summing to --steps")
     else:
-        timed_plan = plan(args.steps)
-    sizes = sorted(set([B] + plan(args.warmup) + timed_plan))
+        timed_plan = plan(args.steps, B)
+    sizes = sorted(set([B] + plan(args.warmup, B) + timed_plan))
     max_b = sizes[-1]
     leaves = seeded_felts(torch, n_leaves * max_b, 1000 + rank, dev)  # distinct leaves for every tree
     slots = []
-    for si in range(n_streams):
+    for _ in range(n_streams):
         bufs = {}
         for nb in sizes:  # one forest buffer per call size; tree t always gets the same seeded leaves
-            lv = torch.zeros((forest_felts(nb), 4), dtype=torch.int64, device=dev)
+            lv = torch.zeros((nb * (2 * n_leaves - 1), 4), dtype=torch.int64, device=dev)
             lv[: n_leaves * nb] = leaves[: n_leaves * nb]
             bufs[nb] = lv
         slots.append({
@@ -816,7 +341,7 @@ def main():
             buf = sl["levels"][nb]
             _lib.check(lib.sp_merkle_forest_dev(buf.data_ptr(), nb, HEIGHT, None, h), "forest")
             if dist is not None:
-                combine_forest_dev(lib, dist, buf[buf.shape[0] - nb :], sl["gathered"], sl["top"], nb, h)
+                combine_forest_dev(lib, dist, buf[buf.shape[0] - nb:], sl["gathered"], sl["top"], nb, h)
 
     def fence():
         torch.cuda.synchronize()
@@ -824,12 +349,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for sl in slots:  # size every stream's scratch before the timed region
+    for _ in slots:  # size every stream's scratch before the timed region
         issue(max_b)
-    for nb in plan(args.warmup):
+    for nb in plan(args.warmup, B):
         issue(nb)
     fence()
-    launches_per_call = HEIGHT + 8
     # The inner nodes of the buffers the TIMED calls write are zeroed first, so that the parity legs below
     # (cpu_baseline*, matches_gpu / root_matches_gpu) check what the timed region itself computed.
     first_timed = call_counter[0]
@@ -842,17 +366,17 @@ def main():
     fence()
     # One region = EXACTLY --steps steps between two fences (barrier + synchronize on both sides); a region of 20
     # lockstep trees lasts ~1.7 ms.  Three windows of such regions, one after the other:
-    #   burst      --burst-s (50 ms) straight after the CPU-only set-up: what rounds 1 - 4 reported.  The power
-    #              controller is still ramping (clock above its steady state), so this is NOT the headline any more;
-    #   pre-heat   --preheat-s (1 s) of the same call, untimed;
+    #   burst      --burst-s (50 ms) straight after the CPU-only set-up: what rounds 1 - 4 reported;
+    #   pre-heat   --preheat-s (1 s) of the same call, untimed: the power controller settles;
     #   sustained  regions repeated until --min-timed-s (3 s) have been timed: `value` = the MEDIAN region of this
     #              window, with the shader clock and package power sampled beside it (Telemetry).
     # Every rank takes the same decisions: a region's time is MAX-reduced over the ranks before it is used.
     MAX_REGIONS = 1 << 15
+    local_regions = []  # this rank's own clock for every region (the MAX over ranks is what `value` uses)
 
     def run_regions(min_s, max_regions):
         regs = []
-        w0_ = time.perf_counter()
+        w0 = time.perf_counter()
         while True:
             t0 = time.perf_counter()
             for nb in timed_plan:
@@ -860,185 +384,59 @@ def main():
             fence()
             dt = time.perf_counter() - t0
             local_regions.append(dt)
-            if dist is not None:
-                t = torch.tensor([dt], dtype=torch.float64, device=dev)
-                if dist.get_backend() == "gloo":
-                    t = t.cpu()
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t.item())
-            regs.append(dt)
+            regs.append(reduce_scalar(torch, dist, dev, dt, "MAX"))
             if sum(regs) >= min_s or len(regs) >= max_regions:
-                break
-        return regs, w0_, time.perf_counter()
-
-    local_regions = []  # this rank's own clock for every region (the MAX over ranks is what `value` uses)
+                return regs, (w0, time.perf_counter())
 
     def profiled(min_s, max_regions, est_regions):
         """run_regions with HIP events around every ped_accumulate_kernel launch of the window."""
         # levels of more than 65 536 hashes per call: at most log2(trees) of them
-        slots = min(int(est_regions) * sum(nb.bit_length() + 1 for nb in timed_plan) + 64, 100000)
-        _lib.check(lib.sp_profile_begin(slots), "profile_begin")
-        regs, a, b = run_regions(min_s, max_regions)
+        n_events = min(int(est_regions) * sum(nb.bit_length() + 1 for nb in timed_plan) + 64, 100000)
+        _lib.check(lib.sp_profile_begin(n_events), "profile_begin")
+        regs, window = run_regions(min_s, max_regions)
         k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
         _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)),
                    "profile_end")
-        return regs, a, b, (k_ms.value, int(k_launches.value), int(k_units.value))
+        return regs, window, (k_ms.value, int(k_launches.value), int(k_units.value))
 
-    idle_tel = TELEMETRY.window(time.perf_counter() - 0.5, time.perf_counter()) if TELEMETRY else None
-    burst_regions, burst_t0, burst_t1, burst_prof = profiled(args.burst_s, 64, 64)
-    burst_med = median(burst_regions)
-    preheat_regions, _, _ = run_regions(args.preheat_s, MAX_REGIONS) if args.preheat_s > 0 else ([], 0, 0)
-    est = args.min_timed_s / max(burst_med, 1e-5) * 1.25 + 16
+    m = {"timed_plan": timed_plan, "n_streams": n_streams, "trees_per_call_cap": B,
+         "idle_tel": tel.window(time.perf_counter() - 0.5, time.perf_counter()) if tel else None}
+    m["burst_regions"], m["burst_window"], m["burst_prof"] = profiled(args.burst_s, 64, 64)
+    m["preheat_regions"] = run_regions(args.preheat_s, MAX_REGIONS)[0] if args.preheat_s > 0 else []
+    est = args.min_timed_s / max(median(m["burst_regions"]), 1e-5) * 1.25 + 16
     del local_regions[:]
-    regions, sus_t0, sus_t1, (k_ms_v, k_launches_v, k_units_v) = profiled(args.min_timed_s, MAX_REGIONS, est)
+    m["regions"], m["sustained_window"], m["prof"] = profiled(args.min_timed_s, MAX_REGIONS, est)
     local_value = (n_leaves - 1) * args.steps / median(local_regions)  # this rank's own subtrees over its own clock
-
-    class _V:  # the names the roofline code below reads
-        def __init__(self, v):
-            self.value = v
-    k_ms, k_launches, k_units = _V(k_ms_v), _V(k_launches_v), _V(k_units_v)
-    srt = sorted(regions)
-    elapsed = median(regions)
-
-    hashes_per_step = world * (n_leaves - 1) + (world - 1)
-    value = hashes_per_step * args.steps / elapsed
 
     # The AIR + FRI half of the metric at N > 1: independent 2^20-row jobs on every GPU (BASELINE north_star:
     # "independent order batches ... shard across the 8 GPUs"), no data-path collective; the ranks start their
     # timed jobs together and the job rate of the node is n_gpus x the slowest rank's rate.
     airfri_multi = None
     if dist is not None and not args.no_airfri:
-        loc = airfri_object(torch, lib, _lib, dev, False, brief=True, fence=fence, min_timed_s=args.min_timed_s,
+        from benchlib.airfri import airfri_object
+        loc = airfri_object(torch, lib, _lib, dev, brief=True, fence=fence, min_timed_s=args.min_timed_s,
                             preheat_s=0.7 * args.preheat_s)
-        t = torch.tensor([loc["commits_per_sec"], 1.0 / loc["seconds_per_job_one_stream"]], dtype=torch.float64, device=dev)
-        if dist.get_backend() == "gloo":
-            t = t.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        loc["commits_per_sec_slowest_gpu"] = float(t[0])
-        loc["commits_per_sec"] = world * float(t[0])
-        loc["seconds_per_job_one_stream"] = 1.0 / float(t[1])
-        loc["n_gpus"] = world
-        loc["scaling"] = "weak"
-        loc["sharding"] = ("independent 2^20-row jobs on every GPU, no data-path collective: commits_per_sec = n_gpus x "
-                           "the slowest rank's rate (seconds_per_job_one_stream = the slowest rank's); ONE trace over "
-                           "all ranks is `--workload airfri`")
+        slowest = reduce_scalar(torch, dist, dev, loc["commits_per_sec"], "MIN")
+        loc.update({"commits_per_sec_slowest_gpu": slowest, "commits_per_sec": world * slowest,
+                    "seconds_per_job_one_stream": 1.0 / reduce_scalar(torch, dist, dev, 1.0 / loc["seconds_per_job_one_stream"], "MIN"),
+                    "n_gpus": world, "scaling": "weak",
+                    "sharding": "independent 2^20-row jobs on every GPU, no data-path collective: commits_per_sec = "
+                                "n_gpus x the slowest rank's rate; ONE trace over all ranks is `--workload airfri`"})
         airfri_multi = loc
-
     dist_info = dist_report(torch, dist, dev, dev_index, world, rank, forced_dist, local_value, lib) if dist is not None else None
 
     if rank == 0:
-        wbits = int(lib.sp_window_bits())
-        n_l = max(int(k_launches.value), 1)
-        avg_launch_s = (k_ms.value / 1e3) / n_l
-        hashes_per_launch = k_units.value / n_l
-        kernel_rate = hashes_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0  # hashes/s inside the bulk launches
-        hbm_gbs = ALGO_BYTES_PER_HASH * kernel_rate / 1e9
-        config_key = "merkle:steps=%d:calls=%s:streams=%d:w=%d" % (args.steps, ",".join(map(str, timed_plan)),
-                                                                  n_streams, wbits)
-        roof = valu_issue(kernel_rate, wbits, "inside the ped_accumulate_kernel launches of the timed region "
-                                              "(HIP events around each of them)", include_finish=False) or {
-            "bound": "valu_issue", "achieved": None, "peak": valu_peak(), "unit": "wave64 VALU instr/s", "frac": None}
-        roof.update({
-            "kernel": "ped_accumulate_kernel (one lane per hash: every level of more than 65 536 hashes; %.0f %% of "
-                      "the hashes of this run)" % (100.0 * k_units.value / max(len(regions) * hashes_per_step * args.steps / max(world, 1), 1)),
-            "peak_basis": VALU_PEAK_NOTE,
-            "launches": int(k_launches.value), "hashes_per_launch": hashes_per_launch,
-            "avg_launch_us": avg_launch_s * 1e6,
-            "timing": "HIP events around every ped_accumulate_kernel launch inside the timed region, on the "
-                      "stream it is launched on (sp_profile_begin/_end)",
-            "traffic": (pmc_traffic("sp::ped_accumulate_kernel", config_key) or {}).get("bytes_per_launch"),
-            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE + WRITE_SIZE); algorithmic: %d" % int(
-                ALGO_BYTES_PER_HASH * hashes_per_launch),
-            "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", config_key),
-            "hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": hbm_gbs / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_hash": ALGO_BYTES_PER_HASH,
-                    "note": "the roofline the contract names; this kernel is integer-ALU bound (about 28 k VALU "
-                            "instructions per 96 algorithmic bytes), so the HBM fraction says nothing about it"},
-            "whole_region": valu_issue(value / max(world, 1), wbits,
-                                       "every kernel of the timed region: hashes/s per GPU over the wall time "
-                                       "(latency-bound upper levels included)"),
-            "frac_basis": "peak at the NOMINAL 2.4 GHz with c_mix = %.2f cycles per wave64 instruction (the basis since "
-                          "round 4; rounds 1 - 3 printed what is now frac_at_flat_4_cycle_peak)" % valu_cycles_per_instr(),
-        })
-        tel_sus = TELEMETRY.window(sus_t0, sus_t1) if TELEMETRY else None
-        tel_burst = TELEMETRY.window(burst_t0, burst_t1) if TELEMETRY else None
-        held_mhz = tel_sus and tel_sus.get("sclk_mhz_median")
-        if held_mhz and roof.get("achieved"):
-            # the same issue rate against the clock the chip HELD while it was measured (the package sits at its
-            # power limit under this kernel): what the kernel reaches of the attainable issue rate
-            held_peak = VALU_PEAK_SIMDS * held_mhz * 1e6 / valu_cycles_per_instr()
-            roof["held_clock_mhz"] = held_mhz
-            roof["frac_at_held_clock"] = roof["achieved"] / held_peak
-            if roof.get("whole_region"):
-                roof["whole_region"]["frac_at_held_clock"] = roof["whole_region"]["achieved"] / held_peak
-        b_ms, b_l, b_u = burst_prof
-        burst_value = hashes_per_step * args.steps / burst_med
-        burst = {"value": burst_value, "unit": "hashes/s", "median_s": burst_med, "count": len(burst_regions),
-                 "total_s": sum(burst_regions),
-                 "bulk_kernel_hashes_per_sec": (b_u / (b_ms / 1e3)) if b_ms > 0 else None,
-                 "telemetry": tel_burst,
-                 "note": "the %.0f ms window rounds 1 - 4 reported as `value`, taken first, straight after the CPU-only "
-                         "set-up: the power controller has not settled yet" % (1e3 * args.burst_s)}
-        telemetry = dict(TELEMETRY.describe(), sustained=tel_sus, burst=tel_burst, idle_before=idle_tel,
-                         sclk_mhz_median=held_mhz, power_w_median=tel_sus and tel_sus.get("power_w_median"),
-                         note="rank 0's device, sampled every %.0f ms from a side thread while the regions run; "
-                              "`sustained` covers exactly the window `value` comes from"
-                              % (1e3 * TELEMETRY.period)) if TELEMETRY else None
-        result = {
-            "metric": "pedersen_hashes_per_sec",
-            "value": value,
-            "unit": "hashes/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "timed_regions": {"count": len(regions), "median_s": elapsed, "mean_s": sum(regions) / len(regions),
-                              "min_s": srt[0], "max_s": srt[-1], "p10_s": srt[len(srt) // 10],
-                              "p90_s": srt[(9 * len(srt)) // 10], "total_s": sum(regions),
-                              "preheat_s": sum(preheat_regions), "preheat_regions": len(preheat_regions),
-                              "value_from_mean_region": hashes_per_step * args.steps * len(regions) / sum(regions),
-                              "note": "SUSTAINED: after %.2f s of the same call as pre-heat, the region (exactly "
-                                      "--steps steps between barrier + synchronize fences) is repeated until %.1f s "
-                                      "have been timed; value and ms_per_step come from the MEDIAN region of that "
-                                      "window" % (sum(preheat_regions), args.min_timed_s)},
-            "burst": burst,
-            "sustained_over_burst": value / burst_value if burst_value else None,
-            "telemetry": telemetry,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32x9 (29-bit limbs, 64-bit accumulators) mod p=2^251+17*2^192+1",
-            "data": "synthetic",
-            "config": {
-                "workload": "2^16-leaf Pedersen Merkle rebuild per GPU (BASELINE.json configs[1])",
-                "tree_height": HEIGHT,
-                "leaves_per_gpu": n_leaves,
-                "hashes_per_step": hashes_per_step,
-                "trees_in_timed_call": timed_plan[0] if len(set(timed_plan)) == 1 else max(timed_plan),
-                "calls_per_region": len(timed_plan),
-                "trees_per_call_cap": B,
-                "streams": n_streams,
-                "timed_calls": timed_plan,
-                "ms_per_step_note": "steps advance in lockstep: ms_per_step is wall time / steps, not the latency "
-                                    "of one rebuild (extra.single_tree_rebuild_ms_one_stream has that)",
-                "window_bits": wbits,
-                "table_mib": lib.sp_table_bytes() / 2**20,
-                "combine": "none" if world == 1 else "all_gather of %d sub-roots (RCCL) + %d top hashes" % (
-                    world, world - 1),
-            },
-            "roofline": roof,
-        }
+        result = merkle_detail(args, world, lib, tel, m)
         if dist is not None:
             result["combine_matches_recomputed"] = combine_check(slots[0], world, _lib)
             result["dist"] = dist_info
             if wide_error:
                 result["dist"]["window_plan_fallback"] = wide_error
         result["build"] = build_provenance(lib)
-        # GPU legs and CPU legs alternate, so that the device's activity is spread over the run instead of sitting in
-        # its first seconds (the driver samples gpu_busy every few seconds: round 4's run showed it 0 % eight times).
-        # A secondary leg that fails must not take the headline with it: it is reported under its key as
-        # {"error": ...} (traceback on stderr) and the line is still printed.
+
+        # GPU legs and CPU legs alternate, so that the device's activity is spread over the run.  A secondary leg that
+        # fails must not take the headline with it: it is reported under its key as {"error": ...} (traceback on
+        # stderr) and the line is still printed.
         def leg(key, fn):
             try:
                 result[key] = fn()
@@ -1048,38 +446,33 @@ def main():
                 result[key] = {"error": "%s: %s" % (type(e).__name__, e)}
                 result.setdefault("failed_legs", []).append(key)
 
-        levels = leaf_ints = gpu_root = tnb = None
+        def felts_of(t):
+            return _lib.unpack_felts((ctypes.c_uint64 * (4 * t.shape[0])).from_buffer_copy(
+                t.cpu().numpy().astype("<i8").tobytes()), t.shape[0])
+
+        leaf_ints = gpu_root = None
         with_cpu = world == 1 and not args.no_cpu_baseline
         if with_cpu:
-            try:
-                n_sample = 1 << HEIGHT  # up to the whole first level (32768 hashes), bounded by budget_s
-                # tree 0 of the forest buffer the FIRST TIMED call wrote (its inner nodes were zeroed before the
-                # timed regions): the parity legs check the timed computation, not a warm-up forest
+            def first_leg():
+                # tree 0 of the forest buffer the FIRST TIMED call wrote (its inner nodes were zeroed before the timed
+                # regions): the parity legs check the timed computation, not a warm-up forest
+                nonlocal leaf_ints, gpu_root
                 tsl, tnb = timed_targets[0]
                 levels = tsl["levels"][tnb]
-                leaf_ints = _lib.unpack_felts(
-                    (ctypes.c_uint64 * (4 * n_sample)).from_buffer_copy(
-                        levels[:n_sample].cpu().numpy().astype("<i8").tobytes()), n_sample)
+                leaf_ints = felts_of(levels[:n_leaves])
                 base, cpu_out = cpu_baseline(leaf_ints)
-                gpu_l1 = _lib.unpack_felts(
-                    (ctypes.c_uint64 * (4 * len(cpu_out))).from_buffer_copy(
-                        levels[n_leaves * tnb : n_leaves * tnb + len(cpu_out)].cpu().numpy().astype("<i8").tobytes()),
-                    len(cpu_out))
-                base["matches_gpu"] = gpu_l1 == cpu_out
+                base["matches_gpu"] = felts_of(levels[n_leaves * tnb: n_leaves * tnb + len(cpu_out)]) == cpu_out
                 base["compared_with"] = "level 1 of tree 0 in the %d-tree buffer written by the timed region" % tnb
-                result["cpu_baseline"] = base
-                gpu_root = _lib.unpack_felts(
-                    (ctypes.c_uint64 * 4).from_buffer_copy(
-                        levels[levels.shape[0] - tnb : levels.shape[0] - tnb + 1].cpu().numpy().astype("<i8").tobytes()), 1)[0]
-            except Exception as e:  # noqa: BLE001 - reported, and the C legs that need its inputs are skipped
-                import traceback
-                traceback.print_exc(file=sys.stderr)
-                result["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-                result.setdefault("failed_legs", []).append("cpu_baseline")
-                leaf_ints = None
+                gpu_root = felts_of(levels[levels.shape[0] - tnb: levels.shape[0] - tnb + 1])[0]
+                return base
+            leg("cpu_baseline", first_leg)
+        else:
+            result["cpu_baseline"] = None
         if not args.no_airfri:
             if world == 1:
-                leg("airfri", lambda: airfri_object(torch, lib, _lib, dev, not args.no_cpu_baseline,
+                from benchlib.airfri import airfri_object
+                leg("airfri", lambda: airfri_object(torch, lib, _lib, dev,
+                                                    cpu_leg=None if args.no_cpu_baseline else cpu_airfri_baseline,
                                                     min_timed_s=args.min_timed_s, preheat_s=0.7 * args.preheat_s))
             else:
                 result["airfri"] = airfri_multi
@@ -1090,635 +483,16 @@ def main():
             leg("cpu_baseline_c", lambda: cpu_baseline_c(leaf_ints, gpu_root))
             leg("cpu_baseline_opt", lambda: cpu_baseline_opt(leaf_ints, gpu_root))
         if world == 1 and not args.no_extras:
+            from benchlib.extras import extras
             leg("extra", lambda: extras(torch, lib, _lib, dev, stream))
         if with_cpu:
             leg("cpu_baseline_ecdsa", cpu_baseline_ecdsa)
-        result["summary"] = summary_object(result)  # LAST key: both halves of the metric survive a truncated tail
-        print(json.dumps(result))
+        emit(main_line(result), detail=result)
+    if tel:
+        tel.stop()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def run_airfri(args, torch, dist, lib, _lib, dev, rank, world):
-    """configs[3] (N = 1: independent 2^k-row jobs alternating over streams) and configs[4] (N > 1: ONE
-    trace of N * 2^k rows sharded over the ranks by starkperp.sharded_prover - LDE units spread over the
-    ranks, ONE bulk all-to-all into block-cyclic LDE-row shards with halos, per-block subtrees + all_gather
-    of block roots, shard-local folds; every root equals the single-GPU root of the same trace)."""
-    import random
-    from starkperp import stark
-    if not 10 <= args.log_rows <= 24:
-        raise SystemExit("--log-rows must be in 10..24")
-    total_log_rows = args.log_rows + (world.bit_length() - 1)
-    if world > 1 and (world & (world - 1) or total_log_rows > 25):
-        raise SystemExit("the sharded job needs a power-of-two world and at most 2^25 rows in all")
-    m = 1 << (total_log_rows - 9)  # 512 trace rows per hash; N > 1: the WHOLE trace (every rank holds its inputs)
-    log_lde = total_log_rows + 2
-    P = stark.FIELD_PRIME
-    xs, ys = seeded_felts(torch, m, 11, dev), seeded_felts(torch, m, 12, dev)
-    rng = random.Random(13)
-    alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
-    betas = [rng.randrange(P) for _ in range(log_lde - 6)]
-    trace = stark.pedersen_trace(xs, ys)  # witness generation is input preparation
-    if dist is not None:  # N > 1, or --force-dist at N = 1: the sharded path on a process group
-        return run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, trace, alphas, betas,
-                                  total_log_rows)
-    per = stark.periodic_lde(512 * m, stark.FIELD_GEN, dev)
-    n_roots = 2 + (log_lde - 7)  # trace, composition, every FRI layer above 64 points
-    # Independent jobs alternate over the streams: the latency-bound tree tops of one job overlap
-    # the throughput-bound row hashing of the next (inside one job every phase depends on the last).
-    n_streams = args.streams if args.streams > 0 else 3
-    slots = []
-    for si in range(n_streams):
-        slots.append({
-            "stream": torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream(device=dev),
-            "roots": torch.zeros((n_roots, 4), dtype=torch.int64, device=dev),
-        })
-    job_counter = [0]
-
-    def step():
-        sl = slots[job_counter[0] % n_streams]
-        job_counter[0] += 1
-        with torch.cuda.stream(sl["stream"]):
-            roots_dev = sl["roots"]
-            k = 0
-            job_trace = stark.pedersen_trace(xs, ys) if args.with_witness else trace
-            t_lde = stark.lde(job_trace)
-            roots_dev[k] = stark.commit_rows(t_lde)[-1]; k += 1
-            comp = stark.air_eval(t_lde, per, 512 * m, alphas)
-            roots_dev[k] = stark.commit_rows(comp.unsqueeze(0))[-1]; k += 1
-            layer, sh, j = comp, stark.FIELD_GEN, 0
-            while layer.shape[0] > 64:
-                layer = stark.fri_fold(layer, betas[j], sh)
-                sh = sh * sh % P
-                j += 1
-                if layer.shape[0] > 64:
-                    roots_dev[k] = stark.commit_rows(layer.unsqueeze(0))[-1]; k += 1
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # the hash kernels dominate this job too (about 3/4 of its GPU time): same roofline leg as the
-    # headline workload - HIP events around every accumulate launch of the timed region
-    launches_per_step = 40 * (n_roots + 4)
-    _lib.check(lib.sp_profile_begin(args.steps * launches_per_step), "profile_begin")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
-    _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)),
-               "profile_end")
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tel_window = TELEMETRY.window(t0, t1) if TELEMETRY else None
-    if rank == 0:
-        avg_launch_s = (k_ms.value / 1e3) / max(k_launches.value, 1)
-        achieved = (ALGO_BYTES_PER_HASH * k_units.value / max(k_launches.value, 1)) / avg_launch_s / 1e9 \
-            if avg_launch_s > 0 else 0.0
-        # trace rows: 3 chain hashes + 1 tree node per LDE row; then one tree per committed column
-        hashes = 4 * (1 << log_lde) + (1 << log_lde) + sum((1 << k) for k in range(7, log_lde))
-        print(json.dumps({
-            "metric": "air_fri_commits_per_sec", "value": world * args.steps / elapsed, "unit": "commits/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x9 (29-bit limbs) mod p", "data": "synthetic",
-            "config": {"workload": "2^%d-row Pedersen-step trace per GPU: LDE x4 -> commit -> AIR -> commit -> "
-                                   "%d FRI folds with %d layer commits (BASELINE.json configs[3] at 2^20; N GPUs "
-                                   "= configs[4] as N disjoint row ranges; --log-rows 24 = configs[4] on one "
-                                   "GPU)" % (args.log_rows, log_lde - 6, log_lde - 7),
-                       "rows_per_gpu": 512 * m, "pedersen_hashes_per_job": hashes, "streams": n_streams,
-                       "combine": "none" if world == 1 else "all_gather of 17 roots per rank + top hashes"},
-            "roofline": dict(
-                valu_issue((k_units.value / max(k_launches.value, 1)) / avg_launch_s if avg_launch_s > 0 else 0.0,
-                           int(lib.sp_window_bits()), "inside the ped_accumulate_kernel launches of the timed region",
-                           include_finish=False) or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None},
-                kernel="ped_accumulate_kernel (row chains and commit-tree levels above 65 536 hashes)",
-                peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value),
-                hashes_in_timed_launches=int(k_units.value), avg_launch_us=avg_launch_s * 1e6,
-                timing="HIP events around every ped_accumulate_kernel launch inside the timed region",
-                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES) or {}).get("bytes_per_launch"),
-                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES),
-                hbm={"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS}),
-            "telemetry": dict(TELEMETRY.describe(), timed=tel_window) if TELEMETRY else None,
-            "build": build_provenance(lib),
-            "cpu_baseline": (cpu_airfri_baseline(10) if (world == 1 and not args.no_cpu_baseline) else None),
-        }))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def run_airfri_sharded(args, torch, dist, lib, _lib, dev, rank, world, stark, trace, alphas, betas, total_log_rows):
-    from starkperp import sharded_prover
-    ops = sharded_prover.GpuOps(dev)
-    log_lde = total_log_rows + 2
-    n_roots = 2 + (log_lde - 7)
-    out = {}
-    stats = {}
-
-    def step():
-        out["roots"], out["final"] = sharded_prover.commit_job(ops, dist, trace, alphas, betas, stats=stats)
-
-    def fence():
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    _lib.check(lib.sp_profile_begin(args.steps * 40 * (n_roots + 4)), "profile_begin")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
-    _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)), "profile_end")
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist.get_backend() == "gloo":
-        t = t.cpu()
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    same = None
-    if rank == 0 and total_log_rows <= 24:
-        # the whole trace once more on this GPU alone (outside the timed region): the sharded roots must be
-        # the single-GPU roots
-        n = trace.shape[1]
-        t_lde = stark.lde(trace)
-        ref = [stark.root_of(stark.commit_rows(t_lde))]
-        comp = stark.air_eval(t_lde, stark.periodic_lde(n, stark.FIELD_GEN, dev), n, alphas)
-        del t_lde
-        ref.append(stark.root_of(stark.commit_rows(comp.unsqueeze(0))))
-        layer, sh, k = comp, stark.FIELD_GEN, 0
-        while layer.shape[0] > 64:
-            layer = stark.fri_fold(layer, betas[k], sh)
-            sh = sh * sh % stark.FIELD_PRIME
-            k += 1
-            if layer.shape[0] > 64:
-                ref.append(stark.root_of(stark.commit_rows(layer.unsqueeze(0))))
-        same = bool(ref == out["roots"] and stark.tensor_to_felts(layer) == out["final"])
-    if rank == 0:
-        n_l = max(int(k_launches.value), 1)
-        avg_launch_s = (k_ms.value / 1e3) / n_l
-        rate = (k_units.value / n_l) / avg_launch_s if avg_launch_s > 0 else 0.0
-        lde_bytes = 4 * (4 << total_log_rows) * 32
-        print(json.dumps({
-            "metric": "air_fri_commits_per_sec", "value": world * args.steps / elapsed,
-            "unit": "2^%d-row commits/s (one step = ONE proof of %d x 2^%d rows)" % (args.log_rows, world, args.log_rows),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x9 (29-bit limbs) mod p", "data": "synthetic",
-            "config": {"workload": "ONE 2^%d-row Pedersen-step trace sharded over %d GPUs (BASELINE.json configs[4] "
-                                   "shape; 2^24 rows = --log-rows 21 on 8 GPUs): 16 LDE units of 4 interpolations spread over "
-                                   "the ranks, ONE all-to-all into block-cyclic LDE-row shards with halos, per-block subtrees "
-                                   "+ all_gather of block roots, shard-local folds"
-                                   % (total_log_rows, world),
-                       "rows_total": 1 << total_log_rows, "rows_per_gpu": 1 << args.log_rows,
-                       "exchange": {"lde_all_to_all_bytes_total": lde_bytes,
-                                    "per_commit": "all_gather of the block roots (32 B per block of 2^%d rows) + the top "
-                                                  "levels on every rank" % stats.get("log_block", 0),
-                                    "per_fold": "none: block-cyclic row shards keep both members of every fold pair on one "
-                                                "rank; one all_gather of 2^%d felts per rank before the replicated tail"
-                                                % stats.get("log_block", 0),
-                                    "bytes_sent_by_rank0_per_job": stats.get("bytes_sent_by_this_rank"),
-                                    "interpolations_on_rank0": stats.get("interpolations"),
-                                    "backend": dist.get_backend()}},
-            "sharded_roots_match_single_gpu": same,
-            "roofline": dict(
-                valu_issue(rate, int(lib.sp_window_bits()), "inside the ped_accumulate_kernel launches of the timed "
-                           "region on rank 0", include_finish=False)
-                or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None},
-                kernel="ped_accumulate_kernel (row chains and commit-tree levels above 65 536 hashes)",
-                peak_basis=VALU_PEAK_NOTE, launches=int(k_launches.value), avg_launch_us=avg_launch_s * 1e6,
-                traffic=(pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES) or {}).get("bytes_per_launch"),
-                traffic_detail=pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES),
-                hbm={"bound": "hbm", "achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}),
-            "cpu_baseline": None,
-        }))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def airfri_object(torch, lib, _lib, dev, with_cpu, brief=False, fence=None, min_timed_s=2.0, preheat_s=0.7):
-    """BASELINE.json configs[3], the second half of the metric: one 2^20-row Pedersen-step trace ->
-    4-column LDE to 2^22 -> commit -> composition -> commit -> 16 folds with 15 layer commits (25.2 M
-    Pedersen hashes).  Inputs (the witness) resident in HBM.  commits_per_sec times independent jobs
-    alternating over three streams, exactly what `--workload airfri` times per GPU.
-    brief (the N > 1 form of the default line): every rank runs its own jobs - `fence` (barrier + synchronize)
-    lines the ranks up in front of the timed jobs - and the object stops after the rates and the hash roofline."""
-    import random
-    from starkperp import stark
-    m = 2048
-    n_rows, n_lde, cols = 512 * m, 4 * 512 * m, 4
-    xs, ys = seeded_felts(torch, m, 11, dev), seeded_felts(torch, m, 12, dev)
-    rng = random.Random(13)
-    P = stark.FIELD_PRIME
-    alphas = [rng.randrange(P) for _ in range(stark.N_CONSTRAINTS)]
-    betas = [rng.randrange(P) for _ in range(16)]
-    trace = stark.pedersen_trace(xs, ys)  # witness generation is input preparation
-    per = stark.periodic_lde(n_rows, stark.FIELD_GEN, dev)
-    torch.cuda.synchronize()
-
-    def timed(fn, iters):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters
-
-    def job():
-        t_lde = stark.lde(trace)
-        stark.commit_rows(t_lde)
-        comp = stark.air_eval(t_lde, per, n_rows, alphas)
-        stark.commit_rows(comp.unsqueeze(0))
-        layer, sh, k = comp, stark.FIELD_GEN, 0
-        while layer.shape[0] > 64:
-            layer = stark.fri_fold(layer, betas[k], sh)
-            sh = sh * sh % P
-            k += 1
-            if layer.shape[0] > 64:
-                stark.commit_rows(layer.unsqueeze(0))
-
-    hashes = 4 * n_lde + n_lde + sum((1 << k) for k in range(7, 22))
-    out = {"workload": "2^20-row trace, blowup 4, 11 constraints, folds down to 64 points (BASELINE.json configs[3])",
-           "pedersen_hashes_per_job": hashes, "data": "synthetic", "dtype": "u32x9 (29-bit limbs) mod p"}
-    job()
-    torch.cuda.synchronize()
-    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
-
-    def pipelined(njobs):
-        for i in range(njobs):
-            with torch.cuda.stream(streams[i % 3]):
-                job()
-        torch.cuda.synchronize()
-
-    # Three windows, like the headline (VERDICT r4 item 1): a burst of 9 jobs straight away (what rounds 1 - 4
-    # reported), pre-heat, then batches of 9 jobs until `min_timed_s` seconds have been timed: commits_per_sec is the
-    # rate over that whole sustained window, with the clock and power the chip held in it.
-    pipelined(3)
-    if fence is not None:
-        fence()
-    t0 = time.perf_counter()
-    pipelined(9)
-    burst_rate = 9 / (time.perf_counter() - t0)
-    heat_t0 = time.perf_counter()
-    while time.perf_counter() - heat_t0 < preheat_s:
-        pipelined(9)
-    if fence is not None:
-        fence()
-    n_batches = max(1, int(min_timed_s * burst_rate / 9 + 0.999))  # fixed in advance: ranks stay in step
-    sus_t0 = time.perf_counter()
-    for _ in range(n_batches):
-        pipelined(9)
-    sus_t1 = time.perf_counter()
-    out["commits_per_sec"] = 9 * n_batches / (sus_t1 - sus_t0)
-    out["commits_per_sec_burst"] = burst_rate
-    out["timed"] = {"jobs": 9 * n_batches, "seconds": sus_t1 - sus_t0, "preheat_s": sus_t0 - heat_t0,
-                    "telemetry": TELEMETRY.window(sus_t0, sus_t1) if TELEMETRY else None}
-    # one job after the other on one stream (the chip is hot now), with HIP events around the bulk hash launches
-    _lib.check(lib.sp_profile_begin(3 * 64), "profile_begin")
-    t_seq = timed(job, 2)
-    k_ms, k_launches, k_units = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
-    _lib.check(lib.sp_profile_end(ctypes.byref(k_ms), ctypes.byref(k_launches), ctypes.byref(k_units)), "profile_end")
-    out["seconds_per_job_one_stream"] = t_seq
-    out["commits_per_sec_note"] = "%d independent jobs alternating over 3 streams (tree tops of one job beside the row " \
-                                  "hashing of the next) in %.2f s after %.2f s of pre-heat; the first 9 jobs out of idle " \
-                                  "ran at %.1f commits/s; one job at a time: %.1f commits/s" % (
-                                      9 * n_batches, sus_t1 - sus_t0, sus_t0 - heat_t0, burst_rate, 1.0 / t_seq)
-    n_l = max(int(k_launches.value), 1)
-    rate = (k_units.value / n_l) / ((k_ms.value / 1e3) / n_l) if k_ms.value > 0 else 0.0
-    roof = valu_issue(rate, int(lib.sp_window_bits()),
-                      "inside the ped_accumulate_kernel launches of three sequential jobs (HIP events)",
-                      include_finish=False) or {"bound": "valu_issue", "achieved": None, "peak": valu_peak(), "frac": None}
-    roof.update({"kernel": "ped_accumulate_kernel (row chains and the tree levels above 65 536 hashes: %.0f %% of the "
-                           "job's hashes)" % (100.0 * k_units.value / (3.0 * hashes)),
-                 "launches": int(k_launches.value), "avg_launch_us": (k_ms.value / n_l) * 1e3,
-                 "traffic": (pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES) or {}).get("bytes_per_launch"),
-                 "traffic_detail": pmc_traffic("sp::ped_accumulate_kernel", "airfri", AIRFRI_PMC_FILES),
-                 "hbm": {"achieved": ALGO_BYTES_PER_HASH * rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ALGO_BYTES_PER_HASH * rate / 1e9 / HBM_PEAK_GBS}})
-    held = ((out["timed"]["telemetry"] or {}).get("sclk_mhz_median")) if out.get("timed") else None
-    if held and roof.get("achieved"):
-        roof["held_clock_mhz"] = held
-        roof["frac_at_held_clock"] = roof["achieved"] / (VALU_PEAK_SIMDS * held * 1e6 / valu_cycles_per_instr())
-    if brief:
-        out["roofline"] = roof
-        return out
-    out["witness_generation_seconds"] = timed(lambda: stark.pedersen_trace(xs, ys), 2)
-    t_lde = stark.lde(trace)
-    comp = stark.air_eval(t_lde, per, n_rows, alphas)
-    phase_s = {
-        "lde_4cols_2p20_to_2p22": timed(lambda: stark.lde(trace), 3),
-        "commit_trace_lde_4cols_2p22_rows": timed(lambda: stark.commit_rows(t_lde), 2),
-        "air_eval_2p22_points": timed(lambda: stark.air_eval(t_lde, per, n_rows, alphas), 3),
-        "commit_composition_2p22_rows": timed(lambda: stark.commit_rows(comp.unsqueeze(0)), 2),
-        "fri_fold_first_layer_2p22": timed(lambda: stark.fri_fold(comp, betas[0], stark.FIELD_GEN), 5),
-    }
-    # algorithmic bytes (SURVEY 8(d)): an NTT pass reads and writes each felt once; the 2^20-point inverse
-    # transform takes 2 passes, the 2^22-point forward one 3, the first of which reads the 2^20 coefficients
-    # (coset scaling and zero padding happen in LDS) and writes 2^22 points; composition: 7 trace + 6
-    # periodic reads and one write of 32 B per point; fold: 32 B read, 16 B written per input point; commit
-    # of M rows of W felts: 32 W M read, 32 (2 M) written
-    algo = {
-        "lde_4cols_2p20_to_2p22": cols * (2 * 64 * n_rows + 32 * n_rows + 32 * n_lde + 2 * 64 * n_lde),
-        "commit_trace_lde_4cols_2p22_rows": 32 * cols * n_lde + 64 * n_lde,
-        "air_eval_2p22_points": (7 + 6 + 1) * 32 * n_lde,
-        "commit_composition_2p22_rows": 32 * n_lde + 64 * n_lde,
-        "fri_fold_first_layer_2p22": (32 + 16) * n_lde,
-    }
-    dominant = {"lde_4cols_2p20_to_2p22": ("ntt_tile_kernel", "valu (one 156-instruction multiplication per butterfly "
-                                           "and 64 B; 0.30 of 8 TB/s would be 100 % VALU issue)"),
-                "commit_trace_lde_4cols_2p22_rows": ("ped_accumulate_kernel", "valu_issue"),
-                "air_eval_2p22_points": ("air_eval_kernel", "valu"),
-                "commit_composition_2p22_rows": ("ped_accumulate_kernel", "valu_issue"),
-                "fri_fold_first_layer_2p22": ("fri_fold_kernel", "valu / hbm")}
-    out["phases"] = {k: {"seconds": phase_s[k], "dominant_kernel": dominant[k][0], "bound": dominant[k][1],
-                         "algorithmic_bytes": algo[k], "hbm_gb_per_s": algo[k] / phase_s[k] / 1e9,
-                         "hbm_frac_of_8_tb_per_s": algo[k] / phase_s[k] / 1e9 / HBM_PEAK_GBS,
-                         "traffic_per_launch_of_dominant_kernel": pmc_traffic(
-                             "sp::" + dominant[k][0], "airfri", AIRFRI_PMC_FILES)} for k in phase_s}
-    out["roofline"] = roof
-    stark.prove(xs, ys, n_queries=8, seed=0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    stark.prove(xs, ys, n_queries=8, seed=1)
-    torch.cuda.synchronize()
-    out["prove_seconds_own_witness_8_queries"] = time.perf_counter() - t0
-    out["cpu_baseline"] = cpu_airfri_baseline(10) if with_cpu else None
-    return out
-
-
-def extras(torch, lib, _lib, dev, stream):
-    """Secondary throughput numbers (outside the timed region): bulk independent hashes and a
-    batch of ECDSA verifications, both device-resident."""
-    out = {}
-
-    def timed(fn, iters):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters / 1e3
-
-    lv = torch.zeros((2 * (1 << HEIGHT) - 1, 4), dtype=torch.int64, device=dev)
-    lv[: 1 << HEIGHT] = seeded_felts(torch, 1 << HEIGHT, 5, dev)
-    # best of three averages of ten: one host hiccup inside a 7 ms window once printed 8.5 ms here
-    s1 = min(timed(lambda: _lib.check(lib.sp_merkle_build_dev(lv.data_ptr(), HEIGHT, None, stream), "merkle"), 10)
-             for _ in range(3))
-    out["single_tree_rebuild_ms_one_stream"] = s1 * 1e3
-    out["single_tree_hashes_per_sec_one_stream"] = ((1 << HEIGHT) - 1) / s1
-
-    n = 1 << 22
-    x, y = seeded_felts(torch, n, 7, dev), seeded_felts(torch, n, 8, dev)
-    o = torch.empty_like(x)
-    bulk = lambda: _lib.check(lib.sp_pedersen_batch_dev(x.data_ptr(), y.data_ptr(), o.data_ptr(), None,  # noqa: E731
-                                                        n, stream), "ped")
-    s_burst = timed(bulk, 3)
-    timed(bulk, max(3, int(0.5 / s_burst)))  # pre-heat
-    b_t0 = time.perf_counter()
-    s = timed(bulk, max(3, int(1.0 / s_burst)))  # sustained: about one second of back-to-back 2^22-hash batches
-    b_t1 = time.perf_counter()
-    out["bulk_pedersen_hashes_per_sec"] = n / s
-    out["bulk_pedersen_hashes_per_sec_burst"] = n / s_burst
-    out["bulk_pedersen_batch"] = n
-    out["bulk_pedersen_telemetry"] = TELEMETRY.window(b_t0, b_t1) if TELEMETRY else None
-    del x, y, o
-    out["valu_issue"] = valu_issue(n / s, int(lib.sp_window_bits()),
-                                   "2^22 independent hashes, accumulate + finish kernels (bulk_pedersen_hashes_per_sec)")
-    _held = (out["bulk_pedersen_telemetry"] or {}).get("sclk_mhz_median")
-    if _held and out["valu_issue"]:
-        out["valu_issue"]["held_clock_mhz"] = _held
-        out["valu_issue"]["frac_at_held_clock"] = out["valu_issue"]["achieved"] / (
-            VALU_PEAK_SIMDS * _held * 1e6 / valu_cycles_per_instr())
-
-    # BASELINE.json configs[0]: the reference's scalar API, one call at a time through the import overlay
-    # (host-inclusive latency per call; the reference itself: 11 ms / 16 ms / 60 ms per hash / sign / verify)
-    from starkware.crypto.signature import signature as _sig
-    def _latency(fn, reps=20):
-        fn()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        return (time.perf_counter() - t0) / reps * 1e3
-    _d, _z = 0x3C1E9550E66958296D11B60F8E8E7A7AD990D07FA65D5F7652C4A6C87D4E3CC, 0x1234567
-    _pub = _sig.private_to_stark_key(_d)
-    _r, _s = _sig.sign(_z, _d)
-    out["c1_scalar_call_latency_ms"] = {
-        "pedersen_hash": _latency(lambda: _sig.pedersen_hash(_z, _d)),
-        "private_to_stark_key": _latency(lambda: _sig.private_to_stark_key(_d)),
-        "sign": _latency(lambda: _sig.sign(_z, _d)),
-        "verify_x_only_key": _latency(lambda: _sig.verify(_z, _r, _s, _pub)),
-        "verify_all_true": bool(_sig.verify(_z, _r, _s, _pub)),
-    }
-    # the same scalar calls from eight host threads: the stateless entry points run on host lanes
-    # (include/starkperp.h "Threading"), so the calls overlap on the device; aggregate ms per call
-    import threading as _threading
-    from starkperp import batch as _b0
-
-    def _threaded(fn, threads=8, reps=20):
-        fn()
-        ts = [_threading.Thread(target=lambda: [fn() for _ in range(reps)]) for _ in range(threads)]
-        t0 = time.perf_counter()
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        return (time.perf_counter() - t0) / (threads * reps) * 1e3
-
-    _b0.set_verify_policy(_b0.VERIFY_POLICY_LADDER)
-    try:
-        out["c1_scalar_call_ms_aggregate_8_threads"] = {
-            "pedersen_hash": _threaded(lambda: _sig.pedersen_hash(_z, _d)),
-            "sign": _threaded(lambda: _sig.sign(_z, _d)),
-            "verify_x_only_key_ladder": _threaded(lambda: _sig.verify(_z, _r, _s, _pub)),
-            "verify_x_only_key_ladder_one_thread": _latency(lambda: _sig.verify(_z, _r, _s, _pub)),
-        }
-    finally:
-        _b0.set_verify_policy(_b0.VERIFY_POLICY_AUTO)
-
-    # BASELINE.json configs[2]: 4096 limit orders - message hashes, ECDSA verify, orders-tree update
-    import random as _random
-    from starkperp import batch as _batch, perpetual_messages as _pm, state as _state
-    import workloads as wl
-    orders = wl.limit_orders(4096, seed=2)
-    keys = wl.private_keys(1024, seed=12)
-    t0 = time.perf_counter()
-    zs = _pm.limit_order_msgs_many([wl.order_args(o) for o in orders])
-    t_msgs = time.perf_counter() - t0
-    pubs = _batch.public_keys_many(keys)
-    zsig = [z % 2**251 for z in zs]
-    sigs = _batch.sign_many(zsig, [keys[o["key_index"]] for o in orders])
-    t0 = time.perf_counter()
-    ok = _batch.verify_many(zsig, [r for r, _ in sigs], [s_ for _, s_ in sigs],
-                            [pubs[o["key_index"]][0] for o in orders])
-    t_verify = time.perf_counter() - t0  # first sight of the 1024 keys: includes building their tables
-    t0 = time.perf_counter()
-    ok2 = _batch.verify_many(zsig, [r for r, _ in sigs], [s_ for _, s_ in sigs],
-                             [pubs[o["key_index"]][0] for o in orders])
-    t_verify_warm = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ok3 = _batch.verify_codes(zsig, [r for r, _ in sigs], [s_ for _, s_ in sigs],
-                              [pubs[o["key_index"]][0] for o in orders], key_tables=False)
-    t_verify_ladder = time.perf_counter() - t0
-    _state.orders_tree_root({1: 1}, 64)  # warm the per-leaf cache of empty-subtree roots
-    t0 = time.perf_counter()
-    _state.orders_tree_root({_state.order_id_of(z): o["amount_synthetic"] for z, o in zip(zs, orders)}, 64)
-    t_tree = time.perf_counter() - t0
-    # the same update on a tree that already holds state (the library keeps the tree: sp_tree_*)
-    _tree = _state.LibrarySparseTree(64, 0)
-    _tree.update({_state.order_id_of(z): o["amount_synthetic"] for z, o in zip(zs, orders)})
-    _rng2 = _random.Random(77)
-    _second = {_rng2.randrange(2**64): _rng2.randrange(1, 2**64) for _ in range(4096)}
-    t0 = time.perf_counter()
-    _tree.update(_second)
-    t_tree_state = time.perf_counter() - t0
-    _tree.close()
-    # a whole state update (state/state.cairo:135-186): 2048 positions changed + 4096 order fills on
-    # trees that already hold 2048 positions and 4096 orders - squash, previous and new position
-    # hashes, previous-leaf checks, both height-64 trees (state.SharedState)
-    _shared = _state.SharedState(64, 64)
-    _empty_pos = (0, 0, ())
-    _poss = [(p[0], p[1], tuple(p[2])) for p in wl.positions(2048, seed=3)]
-    _pkeys = [_rng2.randrange(2**64) for _ in range(2048)]
-    _okeys = [_rng2.randrange(2**64) for _ in range(4096)]
-    _shared.apply_state_updates([(k, _empty_pos, p) for k, p in zip(_pkeys, _poss)],
-                                [(k, 0, 1 + i) for i, k in enumerate(_okeys)])
-    _poss2 = [(p[0], p[1] + 1, p[2]) for p in _poss]
-    t0 = time.perf_counter()
-    _roots = _shared.apply_state_updates([(k, p, q) for k, p, q in zip(_pkeys, _poss, _poss2)],
-                                         [(k, 1 + i, 2 + i) for i, k in enumerate(_okeys)])
-    t_state = time.perf_counter() - t0
-    out["state_update_2048_positions_4096_orders_seconds"] = t_state
-    out["c3_4096_orders_host_inclusive_seconds"] = {
-        "message_hashes": t_msgs, "verify_x_only": t_verify, "orders_tree_height64_update": t_tree,
-        "orders_tree_height64_update_on_existing_state": t_tree_state,
-        "verify_x_only_keys_already_tabulated": t_verify_warm,
-        "verify_x_only_per_signature_ladder": t_verify_ladder,
-        "all_verified": bool(all(ok) and all(ok2) and all(c == 1 for c in ok3))}
-    out["c3_orders_per_sec_host_inclusive"] = 4096 / (t_msgs + t_verify + t_tree)
-    # the same batch through the NumPy entry points (starkperp.batch_np: felts as uint64[n, 4], no per-int
-    # packing) on trees that already hold state: message hashes -> verification (keys tabulated by the
-    # earlier sighting, the steady state of an exchange) -> orders-tree update of the 4096 order ids
-    import numpy as _np2
-    from starkperp import batch_np as _bn
-    _arr = {"sell": [], "buy": [], "fee": [], "a_sell": [], "a_buy": []}
-    for o in orders:
-        syn, col, buying, f, a_syn, a_col, a_fee, nonce, pos, exp = wl.order_args(o)
-        sd, bd, ns, nb = (col, syn, a_col, a_syn) if buying else (syn, col, a_syn, a_col)
-        _arr["sell"].append(sd); _arr["buy"].append(bd); _arr["fee"].append(f)
-        _arr["a_sell"].append(ns); _arr["a_buy"].append(nb)
-    _oa = [wl.order_args(o) for o in orders]
-    _u = lambda i: _np2.array([a[i] for a in _oa], dtype=_np2.uint64)
-    _np_args = (_bn.felts_from_ints(_arr["sell"]), _bn.felts_from_ints(_arr["buy"]), _bn.felts_from_ints(_arr["fee"]),
-                _np2.array(_arr["a_sell"], dtype=_np2.uint64), _np2.array(_arr["a_buy"], dtype=_np2.uint64),
-                _u(6), _u(7), _u(8), _u(9))
-    _r_np, _s_np = _bn.felts_from_ints([r for r, _ in sigs]), _bn.felts_from_ints([s_ for _, s_ in sigs])
-    _q_np = _bn.felts_from_ints([pubs[o["key_index"]][0] for o in orders])
-    _amounts = _bn.pack_fields(4096, [(_np2.array([o["amount_synthetic"] for o in orders], dtype=_np2.uint64), 0)])
-    _tree2 = _state.LibrarySparseTree(64, 0)
-    _tree2.update(_second)  # existing state
-    _np_t = {}
-    for _rep in range(2):  # second pass = warm caches
-        t0 = time.perf_counter()
-        _z_np = _bn.limit_order_msgs(*_np_args)
-        _np_t["message_hashes"] = time.perf_counter() - t0
-        _z_np[:, 3] &= _np2.uint64((1 << 59) - 1)  # z mod 2^251, as the list path signs it
-        t0 = time.perf_counter()
-        _ok_np = _bn.verify_many(_z_np, _r_np, _s_np, _q_np)
-        _np_t["verify_x_only_keys_tabulated"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        _tree2.update_arrays(_bn.order_ids(_z_np), _amounts)
-        _np_t["orders_tree_height64_update_on_existing_state"] = time.perf_counter() - t0
-    _tree2.close()
-    _np_t["total"] = sum(_np_t.values())
-    _np_t["all_verified"] = bool(_ok_np.all())
-    _np_t["message_hashes_match_list_api"] = bool(_bn.ints_from_felts(_bn.limit_order_msgs(*_np_args)) == zs)
-    out["c3_4096_orders_numpy_entry_points_seconds"] = _np_t
-    # ... and as ONE library call (sp_order_batch: chains -> keyed verification -> order ids -> tree update, the
-    # verification overlapping the tree's level hashing, committed only when every signature verified)
-    _tree3 = _state.LibrarySparseTree(64, 0)
-    _tree3.update(_second)  # existing state
-    _one = []
-    for _rep in range(3):
-        t0 = time.perf_counter()
-        _w = _bn.limit_order_words(*_np_args)
-        _z1, _v1, _o1, _n1, _ok1 = _bn.order_batch(_w, _r_np, _s_np, _q_np, _tree3, _amounts)
-        _one.append(time.perf_counter() - t0)
-    out["c3_4096_orders_one_call_seconds"] = {
-        "best_of_3": min(_one), "all": _one, "committed": bool(_ok1), "all_verified": bool((_v1 == 1).all()),
-        "message_hashes_match_list_api": bool(_bn.ints_from_felts(_z1) == zs),
-        "entry_point": "sp_order_batch (word packing in NumPy included; tree on existing state)"}
-    _tree3.close()
-    # device-resident verification rate
-    nv = 1 << 16
-    rng = _random.Random(21)
-    dsk = [rng.randrange(1, _batch.EC_ORDER) for _ in range(nv)]
-    zv = [rng.randrange(2**251) for _ in range(nv)]
-    kv = [rng.randrange(1, _batch.EC_ORDER) for _ in range(nv)]
-    pv = _batch.public_keys_many(dsk)
-    rv, sv, stv = _batch.sign_attempt_many(zv, dsk, kv)
-    from starkperp import stark as _st
-    dz, dr, dsig, dq = (_st.felts_to_tensor(v, dev) for v in (zv, rv, sv, [q[0] for q in pv]))
-    res = torch.zeros(nv, dtype=torch.uint8, device=dev)
-    sv_t = timed(lambda: _lib.check(lib.sp_ecdsa_verify_batch_dev(
-        dz.data_ptr(), dr.data_ptr(), dsig.data_ptr(), dq.data_ptr(), None, res.data_ptr(), nv, stream), "verify"), 3)
-    out["ecdsa_verifies_per_sec_x_only_2p16"] = nv / sv_t
-    out["ecdsa_verify_all_true"] = bool(int((res == 1).sum()) == stv.count(0))
-    # the same signatures through per-key comb tables (csrc/ecdsa.hip "Key tables")
-    import numpy as _np
-    _batch.key_cache_reset()
-    t0 = time.perf_counter()
-    slots = _batch.register_keys([q[0] for q in pv])
-    out["ecdsa_key_registrations_per_sec_host_inclusive"] = nv / (time.perf_counter() - t0)
-    dslots = torch.from_numpy(_np.asarray(slots, dtype=_np.uint32).view(_np.int32)).to(dev)
-    kv_t = timed(lambda: _lib.check(lib.sp_ecdsa_verify_keyed_dev(
-        dz.data_ptr(), dr.data_ptr(), dsig.data_ptr(), dslots.data_ptr(), res.data_ptr(), nv, stream), "keyed"), 3)
-    out["ecdsa_verifies_per_sec_key_tables_2p16"] = nv / kv_t
-    out["ecdsa_verify_key_tables_all_true"] = bool(int((res == 1).sum()) == stv.count(0))
-    # full deterministic signing (RFC 6979 nonce + attempt on the device), Python ints in and out
-    t0 = time.perf_counter()
-    signed = _batch.sign_many(zv, dsk)
-    out["ecdsa_signs_per_sec_2p16_host_inclusive"] = nv / (time.perf_counter() - t0)
-    out["ecdsa_sign_sample_matches_host_nonces"] = bool(
-        signed[:64] == _batch._sign_many_host_nonces(zv[:64], dsk[:64], [None] * 64))
-    # the same signer with the inputs resident in HBM (sp_ecdsa_sign_rfc6979_batch_dev: one launch, nothing staged)
-    # and through the NumPy entry point (host pointers, no Python int per field element)
-    dd = _st.felts_to_tensor(dsk, dev)
-    sr, ss = torch.zeros_like(dz), torch.zeros_like(dz)
-    sst = torch.zeros(nv, dtype=torch.uint8, device=dev)
-    sg_t = timed(lambda: _lib.check(lib.sp_ecdsa_sign_rfc6979_batch_dev(
-        dz.data_ptr(), dd.data_ptr(), None, sr.data_ptr(), ss.data_ptr(), sst.data_ptr(), nv, stream), "sign_dev"), 3)
-    out["ecdsa_signs_per_sec_2p16"] = nv / sg_t
-    out["ecdsa_sign_dev_matches_list_api"] = bool(
-        int((sst == 0).sum()) == nv and list(zip(_st.tensor_to_felts(sr), _st.tensor_to_felts(ss))) == signed)
-    _zn, _dn = _bn.felts_from_ints(zv), _bn.felts_from_ints(dsk)
-    t0 = time.perf_counter()
-    _rn, _sn = _bn.sign_many(_zn, _dn)
-    out["ecdsa_signs_per_sec_2p16_numpy_host_inclusive"] = nv / (time.perf_counter() - t0)
-    out["ecdsa_sign_numpy_matches_list_api"] = bool(
-        list(zip(_bn.ints_from_felts(_rn), _bn.ints_from_felts(_sn))) == signed)
-
-    return out
 
 
 if __name__ == "__main__":

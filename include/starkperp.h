@@ -263,6 +263,10 @@ int sp_ecdsa_key_cache_reset(void);
  * STARKPERP_SIGN_MASKED=1 (read by sp_init) removes the address dependence: the signers and sp_public_key_batch then
  * walk a second EC_GEN table of 63 unsigned 4-bit windows (63 KiB), reading ALL 16 entries of every window - the
  * same addresses on every lane whatever the scalar is - and keeping one by a mask; 62 mixed additions for every k.
+ * Checked on the ISA, not only at source level: tests/test_masked_walk_isa.py compiles the walk (csrc/masked_walk.hpp)
+ * for gfx950 and asserts that every table entry is fetched by wave-uniform scalar loads, that EXEC is never written
+ * and that the only branch is the uniform loop counter's; inside the signer kernels the mask passes an opaque-value
+ * barrier so that the compiler cannot re-derive a branch from it.
  * Same keys and signatures bit for bit (tests/test_gpu_ecdsa.py::test_masked_signer_...); 2^16 signatures 0.86 ->
  * 1.27 ms (7.7 -> 5.2 x 10^7 /s), d * G four times slower (profiles/r05_masked_signer.txt).  What stays data
  * dependent under the mask: the number of rejected RFC 6979 candidates (timing of the nonce phase) and the 2^-55

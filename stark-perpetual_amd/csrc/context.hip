@@ -478,9 +478,14 @@ static int init_locked(Context& c, int device, int window_bits) {
   if (rc != SP_OK) return rc;
   if (const char* masked = getenv("STARKPERP_SIGN_MASKED")) {
     if (masked[0] == '1') {  // the small table of the masked signer: same builder, 4-bit windows, its own offsets
+      c.gen_masked = nullptr;
       SP_HIP(hipMalloc(&c.gen_masked, (size_t)63 * 16 * sizeof(aff_packed)));
       rc = build_gen_table(c.gen_masked, gen_bits, bases[0], 0x4D41534B45444745ull, 4, 63);
-      if (rc != SP_OK) return rc;
+      if (rc != SP_OK) {  // never leave a half-built masked table behind, whoever the caller is
+        (void)hipFree(c.gen_masked);
+        c.gen_masked = nullptr;
+        return rc;
+      }
       c.table_bytes += (size_t)63 * 16 * sizeof(aff_packed);
     }
   }
@@ -591,6 +596,9 @@ size_t sp_table_bytes(void) {  // all contexts
   return total;
 }
 
+#ifndef SP_OFFLOAD_ARCH
+#error "SP_OFFLOAD_ARCH must come from the Makefile (-DSP_OFFLOAD_ARCH='\"$(ARCH)\"'): sp_build_info reports what was compiled"
+#endif
 #ifndef SP_SANITIZER
 #define SP_SANITIZER "none"
 #endif
@@ -598,7 +606,7 @@ size_t sp_table_bytes(void) {  // all contexts
 #define SP_STR(x) SP_STR2(x)
 const char* sp_build_info(void) {
   return "libstarkperp; compiler: clang " __clang_version__ "; HIP " SP_STR(HIP_VERSION_MAJOR) "." SP_STR(HIP_VERSION_MINOR) "." SP_STR(
-      HIP_VERSION_PATCH) "; offload-arch: gfx950; compiled: " __DATE__ " " __TIME__ "; sanitizer: " SP_SANITIZER;
+      HIP_VERSION_PATCH) "; offload-arch: " SP_OFFLOAD_ARCH "; compiled: " __DATE__ " " __TIME__ "; sanitizer: " SP_SANITIZER;
 }
 
 int sp_synchronize(void* stream) {

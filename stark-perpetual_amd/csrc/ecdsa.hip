@@ -31,6 +31,7 @@
 
 #include "context.hpp"
 #include "curve_consts.hpp"
+#include "masked_walk.hpp"
 #include "rfc6979.hpp"
 
 namespace sp {
@@ -42,47 +43,6 @@ namespace sp {
 #define SP_VERIFY_TPB 256
 #endif
 constexpr int VERIFY_TPB = SP_VERIFY_TPB;
-
-// k * EC_GEN with addresses and control flow that do not depend on k (STARKPERP_SIGN_MASKED=1; the signer's threat
-// model in include/starkperp.h): `gen` is the table of 63 unsigned 4-bit windows (context.hpp gen_masked).  Window i
-// reads ALL 16 of its entries - the same 16 addresses on every lane, whatever the scalar is - and keeps the one its
-// nibble names with a mask built from a comparison of VALUES; the walk is the same 62 mixed additions for every k.
-// About six times the work of the gathered walk below (12 additions at 21-bit windows), which is why it is opt-in.
-__device__ __forceinline__ xyzz gen_mul_masked(u256 k, const aff_packed* __restrict__ gen, int nwin) {
-  auto select = [&](int i) {
-    const uint32_t v = k.w[0] & 15u;
-#pragma unroll
-    for (int w = 0; w < 7; ++w) k.w[w] = (k.w[w] >> 4) | (k.w[w + 1] << 28);
-    k.w[7] >>= 4;
-    uint32_t sel[16];
-#pragma unroll
-    for (int w = 0; w < 16; ++w) sel[w] = 0;
-    const uint4* row = reinterpret_cast<const uint4*>(gen + (size_t)i * 16);
-#pragma unroll
-    for (uint32_t j = 0; j < 16; ++j) {
-      const uint32_t m = 0u - (uint32_t)(v == j);  // all ones for the wanted entry, zero otherwise
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint4 t = row[4 * j + q];
-        sel[4 * q + 0] |= t.x & m;
-        sel[4 * q + 1] |= t.y & m;
-        sel[4 * q + 2] |= t.z & m;
-        sel[4 * q + 3] |= t.w & m;
-      }
-    }
-    u256 x, y;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) { x.w[w] = sel[w]; y.w[w] = sel[8 + w]; }
-    aff a;
-    a.x = fe_unpack(x);
-    a.y = fe_unpack(y);
-    return a;
-  };
-  xyzz acc = xyzz_from_aff(select(0));
-#pragma unroll 1
-  for (int i = 1; i < nwin; ++i) acc = xyzz_madd(acc, select(i));
-  return acc;
-}
 
 // k * EC_GEN from the window table; k < 2^252.  Infinity (only for k == 0 mod N) shows as ZZ == 0.
 // wbits < 0: the masked walk above (the signers and the key derivation under STARKPERP_SIGN_MASKED=1).
@@ -997,8 +957,14 @@ namespace sp {
 void release_ecdsa_state() {
   for (auto& kv : g_verify_tab) kv.second.release();
   g_verify_tab.clear();
-  for (auto& kv : g_sign_scratch) {  // scrubbed behind every call already; once more before the memory goes back
-    if (kv.second.ptr) (void)hipMemset(kv.second.ptr, 0, kv.second.bytes);
+  for (auto& kv : g_sign_scratch) {  // scrubbed behind every call already; once more before the memory goes back,
+    if (kv.second.ptr) {             // on the device of the context that owns the scratch
+      DeviceScope on(ctx_at(kv.first.first).device);
+      if (hipMemset(kv.second.ptr, 0, kv.second.bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        fprintf(stderr, "libstarkperp: could not wipe %zu bytes of signer scratch at shutdown\n", kv.second.bytes);
+      }
+    }
     kv.second.release();
   }
   g_sign_scratch.clear();
@@ -1352,10 +1318,11 @@ static bool use_key_tables(const uint64_t* qx, const uint64_t* qy, size_t n) {
   if (!keyed) return false;
   if (fresh.size() + registered + FIRST_KEY_SLOT > g_keys.limit) return false;  // more keys in one batch than the cache holds
   if (g_keys.used - g_keys.free_slots.size() + fresh.size() > g_keys.limit) {
-    // full: evict everything (new generation) rather than leave the tables to the keys that came first -
-    // unless a caller holds handles of this generation (sp_ecdsa_register_keys): then the ladder serves the batch
+    // full: the batch will need a new generation (everything evicted) rather than leave the tables to the keys
+    // that came first - unless a caller holds handles of this generation (sp_ecdsa_register_keys): then the
+    // ladder serves the batch.  The eviction itself is NOT done here: this function only decides;
+    // verify_batch_keyed_impl evicts in the hold that registers, when registration really finds the cache full.
     if (g_keys.external_handles) return false;
-    if (sp_ecdsa_key_cache_reset() != SP_OK) return false;
   }
   return true;
 }
@@ -1377,11 +1344,15 @@ int sp_ecdsa_get_verify_policy(void) {
 }
 
 // Host-pointer verification through the key tables: registers the keys it has not seen, then runs
-// the comb kernel.  `policy`: the call comes from sp_ecdsa_verify_batch - the policy decision, the registration
-// and the launch happen under ONE hold of the context lock (round 3 dropped it between the decision and the
-// registration: another host thread could fill the cache or start a new generation in between and the batch
-// failed with SP_ERR_CACHE_FULL instead of running on the ladder); *fell_back is set when the policy chose the
-// ladder or the cache could not take the batch's keys after all, and nothing has been enqueued then.
+// the comb kernel.  `policy`: the call comes from sp_ecdsa_verify_batch.  Two holds of the context lock:
+//   1. the DECISION (use_key_tables: reads the cache, remembers first sightings, evicts nothing), before a lane is
+//      taken, so that a batch that ends on the ladder costs the primary device no lane and no stream;
+//   2. EVICTION (only when registration finds the cache full, no caller holds handles and the batch fits an empty
+//      cache), REGISTRATION and the LAUNCH against the tables, in one hold - a cache that another thread filled or
+//      re-generated between the two holds is handled here, and one that still cannot take the batch sends it to the
+//      ladder.  If no lane opens between the holds nothing has been evicted.
+// *fell_back is set when the policy chose the ladder or the cache could not take the batch's keys after all, and
+// nothing has been enqueued then.
 static int verify_batch_keyed_impl(const uint64_t* z, const uint64_t* r, const uint64_t* s, const uint64_t* qx,
                                    const uint64_t* qy, uint8_t* result, size_t n, bool policy, bool* fell_back) {
   // The key cache lives on the primary context: take a host lane of that context.  The lock covers the
@@ -1409,7 +1380,12 @@ static int verify_batch_keyed_impl(const uint64_t* z, const uint64_t* r, const u
     // the handles never leave this call, so this is not an `external_handles` registration (sp_order_batch comes
     // through here on every batch: it must not switch the policy's eviction off)
     int rc = register_keys_locked(qx, qy, n, slots.data());
-    if (policy && rc == SP_ERR_CACHE_FULL) { *fell_back = true; return SP_OK; }  // filled by another thread since the decision
+    if (policy && rc == SP_ERR_CACHE_FULL && !g_keys.external_handles) {
+      // full (register_keys_locked rolled its partial work back): start a new generation and register once more.
+      // use_key_tables has checked that the batch's distinct keys fit an empty cache.
+      if (sp_ecdsa_key_cache_reset() == SP_OK) rc = register_keys_locked(qx, qy, n, slots.data());
+    }
+    if (policy && rc == SP_ERR_CACHE_FULL) { *fell_back = true; return SP_OK; }  // still no room: the ladder
     if (rc != SP_OK) return rc;
     const uint64_t* host[3] = {z, r, s};
     uint64_t* dev[3];
@@ -1496,6 +1472,34 @@ static size_t sign_chunk_items() {
   }();
   return v;
 }
+// Secret material staged in HBM (private keys, nonces, the HMAC state derived from them) is wiped when the scope
+// that staged it ends - on EVERY path out of it (round 5 scrubbed on the success path only, and an
+// early return after a failed launch or copy left the secrets in the lane's buffer).  finish() is the success
+// path: the wipe is enqueued behind the last reader and the caller's own synchronize covers it.  The destructor
+// is the error path: wipe, then wait for it.  A null range is skipped.
+struct SecretScrub {
+  void* ptr;
+  size_t bytes;
+  hipStream_t st;
+  SecretScrub(void* p, size_t n, hipStream_t s) : ptr(p), bytes(n), st(s) {}
+  hipError_t finish() {
+    if (!ptr || !bytes) return hipSuccess;
+    void* p = ptr;
+    ptr = nullptr;
+    return hipMemsetAsync(p, 0, bytes, st);
+  }
+  ~SecretScrub() {
+    if (!ptr || !bytes) return;
+    if (hipMemsetAsync(ptr, 0, bytes, st) != hipSuccess) {  // a stream in error: try the blocking form as well
+      (void)hipGetLastError();
+      (void)hipMemset(ptr, 0, bytes);
+    }
+    (void)hipStreamSynchronize(st);
+  }
+  SecretScrub(const SecretScrub&) = delete;
+  SecretScrub& operator=(const SecretScrub&) = delete;
+};
+
 static int enqueue_sign_rfc6979(Context& c, const uint64_t* z, const uint64_t* d, const uint64_t* seeds, uint64_t* r,
                                 uint64_t* s, uint8_t* status, size_t n, hipStream_t st) {
   const size_t min_n = sign_compact_min();
@@ -1525,6 +1529,7 @@ static int enqueue_sign_rfc6979(Context& c, const uint64_t* z, const uint64_t* d
   uint32_t* idx[2] = {(uint32_t*)(b + kb), (uint32_t*)(b + kb + ib)};
   uint32_t* state[2] = {(uint32_t*)(b + kb + 2 * ib), (uint32_t*)(b + kb + 2 * ib + sb)};
   uint32_t* counters = (uint32_t*)(b + kb + 2 * ib + 2 * sb);  // one per list: counters[j] = items that enter round j
+  SecretScrub wipe(b, kb + 2 * ib + 2 * sb, st);  // error paths; every chunk also wipes behind itself below
   for (size_t off = 0; off < n; off += chunk) {
     const size_t m = n - off < chunk ? n - off : chunk;
     const uint64_t *zc = z + 4 * off, *dc = d + 4 * off, *sc = seeds ? seeds + off : nullptr;
@@ -1551,6 +1556,7 @@ static int enqueue_sign_rfc6979(Context& c, const uint64_t* z, const uint64_t* d
     SP_HIP(hipMemsetAsync(b, 0, kb + 2 * ib + 2 * sb, st));
   }
   SP_HIP(hipGetLastError());
+  wipe.ptr = nullptr;  // every chunk has been wiped on the stream already
   return SP_OK;
 }
 
@@ -1559,6 +1565,7 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
   LaneScope ls;
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
+  if (!z || !d || !k || !r || !s || !status) { set_error("sp_ecdsa_sign_batch: null pointer"); return SP_ERR_BAD_ARGUMENT; }
   if (ls.open() != SP_OK) return SP_ERR_HIP;
   Context& c = ctx();
   HostLane& L = *ls.lane;
@@ -1568,6 +1575,7 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
   const size_t fb = n * 32;
   int rc = stage_in_lane(L, host, 3, n, dev, 2 * fb + n, &extra);
   if (rc != SP_OK) return rc;
+  SecretScrub wipe(dev[1], 2 * fb, L.stream);  // the staged private keys and nonces (dev[1], dev[2] are adjacent)
   uint64_t* dr = (uint64_t*)extra;
   uint64_t* ds = (uint64_t*)(extra + fb);
   uint8_t* dst = (uint8_t*)(extra + 2 * fb);
@@ -1578,7 +1586,7 @@ int sp_ecdsa_sign_batch(const uint64_t* z, const uint64_t* d, const uint64_t* k,
   SP_HIP(hipMemcpyAsync(r, dr, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(s, ds, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
-  SP_HIP(hipMemsetAsync(dev[1], 0, 2 * fb, L.stream));  // the staged private keys and nonces (dev[1], dev[2] are adjacent)
+  SP_HIP(wipe.finish());
   SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }
@@ -1588,6 +1596,7 @@ int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint
   LaneScope ls;
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
+  if (!z || !d || !r || !s || !status) { set_error("sp_ecdsa_sign_rfc6979_batch: null pointer"); return SP_ERR_BAD_ARGUMENT; }
   if (ls.open() != SP_OK) return SP_ERR_HIP;
   Context& c = ctx();
   HostLane& L = *ls.lane;
@@ -1597,6 +1606,7 @@ int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint
   const size_t fb = n * 32;
   int rc = stage_in_lane(L, host, 2, n, dev, 2 * fb + n * 8 + n + 64, &extra);
   if (rc != SP_OK) return rc;
+  SecretScrub wipe(dev[1], fb, L.stream);  // the staged private keys do not stay in the lane's buffer
   uint64_t* dr = (uint64_t*)extra;
   uint64_t* ds = (uint64_t*)(extra + fb);
   uint64_t* dseed = (uint64_t*)(extra + 2 * fb);
@@ -1611,7 +1621,7 @@ int sp_ecdsa_sign_rfc6979_batch(const uint64_t* z, const uint64_t* d, const uint
   SP_HIP(hipMemcpyAsync(r, dr, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(s, ds, fb, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
-  SP_HIP(hipMemsetAsync(dev[1], 0, fb, L.stream));  // the staged private keys do not stay in the lane's buffer
+  SP_HIP(wipe.finish());
   SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }
@@ -1667,6 +1677,7 @@ int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* 
   LaneScope ls;
   SP_REQUIRE_READY();
   if (n == 0) return SP_OK;
+  if (!d || !qx) { set_error("sp_public_key_batch: null pointer"); return SP_ERR_BAD_ARGUMENT; }
   if (ls.open() != SP_OK) return SP_ERR_HIP;
   Context& c = ctx();
   HostLane& L = *ls.lane;
@@ -1676,6 +1687,7 @@ int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* 
   const size_t fb = n * 32;
   int rc = stage_in_lane(L, host, 1, n, dev, 2 * fb + n, &extra);
   if (rc != SP_OK) return rc;
+  SecretScrub wipe(dev[0], fb, L.stream);  // the staged private keys do not stay in the lane's buffer
   uint64_t* dx = (uint64_t*)extra;
   uint64_t* dy = (uint64_t*)(extra + fb);
   uint8_t* dst = (uint8_t*)(extra + 2 * fb);
@@ -1686,7 +1698,7 @@ int sp_public_key_batch(const uint64_t* d, uint64_t* qx, uint64_t* qy, uint8_t* 
   SP_HIP(hipMemcpyAsync(qx, dx, fb, hipMemcpyDeviceToHost, L.stream));
   if (qy) SP_HIP(hipMemcpyAsync(qy, dy, fb, hipMemcpyDeviceToHost, L.stream));
   if (status) SP_HIP(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, L.stream));
-  SP_HIP(hipMemsetAsync(dev[0], 0, fb, L.stream));  // the staged private keys do not stay in the lane's buffer
+  SP_HIP(wipe.finish());
   SP_HIP(hipStreamSynchronize(L.stream));
   return SP_OK;
 }

@@ -16,6 +16,7 @@
 // contiguous 2048-point tile in LDS).
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "context.hpp"
@@ -1076,15 +1077,21 @@ static int coset_table(int log_n, int log_blowup, const uint64_t* shift_host, co
 // pad_log_b > 0 (dit only) `in` is the bit-reversed coefficient array of 2^(log_n - pad_log_b) felts per
 // column and the zero-padded, coset-scaled input of the transform exists only in LDS.
 static const bool g_ntt_lazy_store = getenv("STARKPERP_NTT_CANON_ALL") == nullptr;  // A/B switch
-// The tile needs more dynamic LDS than a kernel gets by default: raised once per process (per device: the attribute
-// is per function and device, and the prover's entry points run on the primary context only).
+// The tile needs more dynamic LDS than a kernel gets by default.  The attribute is per function AND per device, and
+// sp_shutdown followed by sp_init on another device keeps this process's statics: the result is cached per device
+// (as pedersen.hip's finish_lds_ready does), under its own mutex because the prover's entry points may be entered
+// from several host threads.
 static int ntt_lds_ready() {
-  static int rc = [] {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES);
-    return e == hipSuccess ? SP_OK : hip_fail(e, "hipFuncSetAttribute(ntt_tile_kernel, MaxDynamicSharedMemorySize)");
-  }();
-  return rc;
+  static std::mutex mu;
+  static std::map<int, int> done;  // device -> SP_OK / SP_ERR_HIP
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return SP_ERR_HIP;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = done.find(dev);
+  if (it != done.end()) return it->second;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES);
+  return done[dev] = (e == hipSuccess ? SP_OK : hip_fail(e, "hipFuncSetAttribute(ntt_tile_kernel, MaxDynamicSharedMemorySize)"));
 }
 static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse, int dit, int use_scale,
                       fe scale, hipStream_t st, unsigned ncols = 1, size_t in_col_stride = 0,

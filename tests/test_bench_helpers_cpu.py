@@ -1,5 +1,6 @@
-"""CPU-side checks of bench.py's measurement plumbing (round 5): the telemetry windows, the median, the
-self-spawn command line and the process-group report over gloo - none of it needs a GPU."""
+"""CPU-side checks of bench.py's measurement plumbing (benchlib/): the ONE line's size and completeness, the telemetry
+windows, the median, the self-spawn command line, the roofline file lists and the process-group report over gloo - none of
+it needs a GPU."""
 import json
 import os
 import subprocess
@@ -11,6 +12,136 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (no torch import, no GPU touched at import time)
+from benchlib import common, launch, line, roofline, telemetry  # noqa: E402
+
+
+def _canned_detail():
+    """A full-size result of the default run: round 5's 20 KB line (the one the driver could not parse), which is
+    exactly the `detail` dict bench.py now hands to benchlib.line.main_line."""
+    return json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+
+
+def test_line_is_small_and_complete():
+    """the printed line is one strictly valid JSON object of less than 8 KB with every key of the
+    contract, a numbers-only roofline, cpu_baseline, a small airfri and `summary` last."""
+    detail = _canned_detail()
+    assert len(json.dumps(detail)) > 16000  # the canned input really is the oversized one
+    out = line.main_line(detail)
+    text = line.check_line(out)
+    assert len(text.encode()) < 8192 and "\n" not in text
+    back = json.loads(text, parse_constant=lambda c: pytest.fail("non-finite constant %s in the line" % c))
+    for k in line.REQUIRED_KEYS:
+        assert k in back, k
+    assert back["metric"] == "pedersen_hashes_per_sec" and back["unit"] == "hashes/s" and back["dtype"] == "u32x9"
+    assert back["value"] == pytest.approx(detail["value"], rel=1e-8)
+    assert back["ms_per_step"] == pytest.approx(detail["ms_per_step"], rel=1e-8)
+    assert back["value"] == pytest.approx(back["config"]["hashes_per_step"] * back["steps"] / back["timed"]["median_s"], rel=1e-6)
+    assert back["config"]["workload"].startswith("2^16-leaf") and "model" not in back["config"]
+    r = back["roofline"]
+    for k in line.ROOFLINE_KEYS + ("kernel", "instr_per_hash", "avg_launch_us", "frac_at_held_clock", "frac_at_2_cycle_peak",
+                                   "algorithmic_bytes_per_launch", "hbm", "whole_region", "sources"):
+        assert k in r, k
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-6)
+    assert r["hbm"]["bound"] == "hbm" and r["hbm"]["frac"] == pytest.approx(r["hbm"]["achieved"] / r["hbm"]["peak"], rel=1e-6)
+    assert r["algorithmic_bytes_per_launch"] == 96 * int(r["hashes_per_launch"])
+    assert all(isinstance(v, (int, float, bool, type(None))) or k in ("bound", "kernel", "unit", "traffic_unit", "hbm",
+                                                                      "whole_region", "sources")
+               for k, v in r.items()), "prose crept back into the roofline"
+    assert all(src.startswith("profiles/") for src in r["sources"])
+    cb = back["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and len(cb["sample"]) <= 200
+    assert len(json.dumps(back["airfri"])) <= 1200 and back["airfri"]["commits_per_sec"] > 0
+    assert back["airfri"]["cpu_baseline"]["commits_per_sec_scaled_to_2p20"] > 0
+    assert list(back)[-1] == "summary"
+    assert back["summary"]["pedersen_hashes_per_sec"] == back["value"]
+    assert back["summary"]["airfri_commits_per_sec"] == back["airfri"]["commits_per_sec"]
+    assert back["detail"] == line.DETAIL_FILE
+
+
+def test_line_with_a_process_group_keeps_the_rccl_proof(tmp_path):
+    """at N > 1 the main line still says what RCCL saw (world size, version, per-rank value, the
+    combine check) - and stays under the bound with an 8-rank report attached."""
+    detail = _canned_detail()
+    detail["n_gpus"] = 8
+    detail["combine_matches_recomputed"] = True
+    detail["dist"] = {"backend": "nccl", "world_size": 8, "rccl_version": "2.26.6", "forced_at_one_gpu": False,
+                      "visible_devices": 8, "per_rank_value": {"min": 7.7e8, "max": 7.9e8, "unit": "hashes/s ..."},
+                      "ranks": [{"rank": i, "device_index": i, "name": "AMD Instinct MI355X", "pci": "0000:%02x:00.0" % (16 * i + 5),
+                                 "free_hbm_gib": 190.0, "total_hbm_gib": 287.9, "window_bits": 26, "table_gib": 75.0,
+                                 "pid": 1000 + i, "cpus_allowed": 128, "local_hashes_per_sec": 7.8e8} for i in range(8)],
+                      "peer_access": [[1] * 8 for _ in range(8)], "env": {"HSA_ENABLE_IPC_MODE_LEGACY": "0"},
+                      "link_types": {"system": {"(Topology) Link type between DRM devices %d and %d" % (a, b): "XGMI"
+                                                for a in range(8) for b in range(a + 1, 8)}}}
+    out = line.main_line(detail)
+    text = line.check_line(out)
+    assert len(text.encode()) < 8192
+    d = json.loads(text)["dist"]
+    assert d["world_size"] == 8 and d["rccl_version"] == "2.26.6" and d["backend"] == "nccl"
+    assert d["per_rank_value"] == {"min": 7.7e8, "max": 7.9e8} and d["ranks_reported"] == 8 and len(d["devices"]) == 8
+    assert d["peer_access_all"] is True and json.loads(text)["combine_matches_recomputed"] is True
+    # emit(): the line on stdout, the detail in its file
+    import io
+    buf = io.StringIO()
+    os.environ["STARKPERP_BENCH_DETAIL"] = str(tmp_path / "detail.json")
+    try:
+        printed = line.emit(out, detail=detail, stream=buf)
+    finally:
+        del os.environ["STARKPERP_BENCH_DETAIL"]
+    assert buf.getvalue() == printed + "\n" and buf.getvalue().count("\n") == 1
+    assert json.load(open(tmp_path / "detail.json"))["dist"]["ranks"][7]["rank"] == 7
+
+
+def test_emit_never_prints_an_oversized_line(capsys):
+    """A line that breaks the bound (somebody adds prose again) is cut to the contract's keys rather than printed."""
+    import io
+    out = line.main_line(_canned_detail())
+    out["config"]["essay"] = "x" * 9000
+    with pytest.raises(ValueError):
+        line.check_line(out)
+    buf = io.StringIO()
+    printed = line.emit(out, stream=buf)
+    assert len(printed.encode()) < 8192
+    back = json.loads(printed)
+    assert back["value"] > 0 and back["roofline"]["frac"] > 0 and back["cpu_baseline"]["value"] > 0
+    assert "limit 8192" in capsys.readouterr().err
+
+
+def test_non_finite_numbers_become_null():
+    out = line._clean({"a": float("nan"), "b": [float("inf"), 1.0], "c": {"d": -float("inf")}, "e": 0.1234567891234})
+    assert out == {"a": None, "b": [None, 1.0], "c": {"d": None}, "e": 0.123456789}
+
+
+def test_roofline_files_put_this_round_first_and_stamp_nothing_stale():
+    """the r06 passes come first in every list, and an older file is never called "the same
+    configuration as this run" unless its recorded config_key equals this run's."""
+    for files in (roofline.PMC_FILES, roofline.AIRFRI_PMC_FILES, roofline.VALU_ISSUE_FILES):
+        assert files[0].startswith("r06_") and list(files) == sorted(files, reverse=True)
+    key = roofline.merkle_config_key(20, [20], 2, 26)
+    assert key == "merkle:steps=20:calls=20:streams=2:w=26"
+    t = roofline.pmc_traffic("sp::ped_accumulate_kernel", key)
+    assert t["source"].startswith("profiles/r0") and t["same_configuration_as_this_run"] is (t["config_key"] == key)
+    assert roofline.pmc_traffic("sp::ped_accumulate_kernel", "merkle:steps=7:calls=7:streams=1:w=21")[
+        "same_configuration_as_this_run"] is False
+    a = roofline.pmc_traffic("sp::ped_accumulate_kernel", roofline.airfri_config_key(26), roofline.AIRFRI_PMC_FILES)
+    assert a is None or a["same_configuration_as_this_run"] is (a["config_key"] == roofline.airfri_config_key(26))
+    r = roofline.valu_issue(1.0e9, 26, "test", include_finish=False)
+    assert r["instr_source"].startswith("profiles/r0") and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    held = roofline.add_held_clock(dict(r), 2000.0)
+    assert held["frac_at_held_clock"] == pytest.approx(r["frac"] * 2400.0 / 2000.0)
+
+
+def test_bench_py_stays_small_and_delegates():
+    """bench.py keeps argument parsing, the timed region, the CPU legs and the print."""
+    src = open(os.path.join(ROOT, "bench.py")).read().splitlines()
+    assert len(src) < 600
+    for name in ("Telemetry", "self_spawn", "dist_report", "median"):  # re-exported for tools that import bench
+        assert hasattr(bench, name)
+    assert bench.median is common.median and bench.Telemetry is telemetry.Telemetry and bench.self_spawn is launch.self_spawn
+    # only bench.py itself (its cpu_baseline legs) may import the oracle: nothing under benchlib/ does
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "benchlib", "*.py")):
+        text = open(f).read()
+        assert "from oracle" not in text and "import oracle" not in text, f
 
 
 def test_median_and_telemetry_windows():
@@ -66,7 +197,7 @@ _REPORT_WORKER = r"""
 import json, os, sys
 sys.path.insert(0, %(root)r)
 import torch, torch.distributed as dist
-import bench
+from benchlib import launch as bench
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 
