@@ -18,6 +18,8 @@
 // windows of different 2-adic weight - never.  The builder checks every entry against the curve.
 // The EC_GEN table (k*G for sign / public keys / the z*G leg of verify) is the plain unsigned
 // uniform-window table with offsets that are multiples of P0 and sum to the point at infinity.
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -174,6 +176,48 @@ void set_error(const std::string& s) {
 int hip_fail(hipError_t e, const char* what) {
   set_error(std::string(what) + ": " + hipGetErrorString(e));
   return SP_ERR_HIP;
+}
+
+struct HostTimeline {
+  const char* call;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  std::mutex mu;
+  std::vector<std::pair<std::string, double>> marks;
+};
+static std::atomic<HostTimeline*> g_timeline{nullptr};
+static const bool g_timeline_on = [] {
+  const char* e = getenv("STARKPERP_TIMELINE");
+  return e != nullptr && e[0] == '1';
+}();
+void tl_mark(const char* what) {
+  HostTimeline* t = g_timeline.load(std::memory_order_acquire);
+  if (!t) return;
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t->t0).count();
+  std::lock_guard<std::mutex> lk(t->mu);
+  char tid[32];
+  snprintf(tid, sizeof(tid), " [t%04x]", (unsigned)(std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xffff));
+  t->marks.emplace_back(std::string(what) + tid, us);
+}
+TimelineScope::TimelineScope(const char* call) {
+  if (!g_timeline_on) return;
+  HostTimeline* expected = nullptr;
+  HostTimeline* t = new HostTimeline{call};
+  if (g_timeline.compare_exchange_strong(expected, t)) mine = t;  // one traced call at a time; nested / concurrent calls are not traced
+  else delete t;
+}
+TimelineScope::~TimelineScope() {
+  if (!mine) return;
+  tl_mark("end");
+  g_timeline.store(nullptr, std::memory_order_release);
+  std::string line = std::string("libstarkperp timeline ") + mine->call + ":";
+  char buf[96];
+  for (const auto& m : mine->marks) {
+    snprintf(buf, sizeof(buf), " %.1f us ", m.second);
+    line += buf + m.first + ";";
+  }
+  fprintf(stderr, "%s\n", line.c_str());
+  // not deleted: a thread of ANOTHER call may still be inside tl_mark with this pointer (diagnostics mode only: a few
+  // hundred bytes per traced call)
 }
 
 // One thread per entry of ONE window: tab[v] = off + sum_{b < nb : bit b of v set} bits[b].

@@ -162,6 +162,19 @@ struct LaneScope {
 };
 
 void set_error(const std::string& s);
+
+// Host-side timeline of ONE traced API call (diagnostics, STARKPERP_TIMELINE=1; tools/c3_probe.py): marks from any
+// thread of the call - the caller's and sp_order_batch's verifier - printed to stderr as one line when the call
+// ends.  With the variable unset tl_mark is one relaxed load and a branch.
+struct HostTimeline;
+void tl_mark(const char* what);
+struct TimelineScope {  // opens the timeline for the duration of a call (no-op unless STARKPERP_TIMELINE=1)
+  HostTimeline* mine = nullptr;
+  explicit TimelineScope(const char* call);
+  ~TimelineScope();
+  TimelineScope(const TimelineScope&) = delete;
+  TimelineScope& operator=(const TimelineScope&) = delete;
+};
 int hip_fail(hipError_t e, const char* what);
 
 #define SP_HIP(call)                                   \

@@ -43,6 +43,30 @@ namespace sp {
 #define SP_VERIFY_TPB 256
 #endif
 constexpr int VERIFY_TPB = SP_VERIFY_TPB;
+// Waves per SIMD the register allocator must leave room for in the two verification kernels.
+// Left to itself (0) the allocator takes 256 VGPRs + 2 (ladder) / 11 (keyed) AGPRs - a handful of registers over the
+// 256 that two waves per SIMD may use - and a SIMD holds ONE wave.  With amdgpu_waves_per_eu(2, 2) it stays within 256
+// and spills 12 / 60 bytes per lane.  Measured (profiles/r06_verify_occupancy.txt, same box, alternating): nothing at
+// 2^16 signatures (1024 waves = one per SIMD either way), + 17 % / + 26 % at 2^18 (ladder 5.35 -> 6.27 x 10^7 /s,
+// keyed 2.77 -> 3.48 x 10^8 /s), + 22 % / + 29 % at 2^20.  2 is the default since round 6.
+#ifndef SP_VERIFY_WAVES
+#define SP_VERIFY_WAVES 2
+#endif
+// The same switch for the signers and the key derivation (183 - 212 VGPRs: two waves per SIMD by themselves; 3 would
+// need <= 168).  A/B build only so far (profiles/r06_verify_occupancy.txt): 0 = the allocator's choice.
+#ifndef SP_SIGN_WAVES
+#define SP_SIGN_WAVES 0
+#endif
+#if SP_SIGN_WAVES > 0
+#define SP_SIGN_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SP_SIGN_WAVES, SP_SIGN_WAVES)))
+#else
+#define SP_SIGN_OCCUPANCY
+#endif
+#if SP_VERIFY_WAVES > 0
+#define SP_VERIFY_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SP_VERIFY_WAVES, SP_VERIFY_WAVES)))
+#else
+#define SP_VERIFY_OCCUPANCY
+#endif
 
 // k * EC_GEN from the window table; k < 2^252.  Infinity (only for k == 0 mod N) shows as ZZ == 0.
 // wbits < 0: the masked walk above (the signers and the key derivation under STARKPERP_SIGN_MASKED=1).
@@ -363,7 +387,7 @@ __device__ __forceinline__ uint8_t key_model(const uint64_t* __restrict__ pqx, c
   return VERIFY_CONTINUE;
 }
 
-__global__ void __launch_bounds__(VERIFY_TPB)
+__global__ void __launch_bounds__(VERIFY_TPB) SP_VERIFY_OCCUPANCY
 ecdsa_verify_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr,
                     const uint64_t* __restrict__ ps, const uint64_t* __restrict__ pqx,
                     const uint64_t* __restrict__ pqy, uint8_t* __restrict__ result, size_t n,
@@ -638,7 +662,7 @@ __device__ __forceinline__ jac comb_mul(const u256& u2, const aff_packed* __rest
   return B;
 }
 
-__global__ void __launch_bounds__(VERIFY_TPB)
+__global__ void __launch_bounds__(VERIFY_TPB) SP_VERIFY_OCCUPANCY
 ecdsa_verify_keyed_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pr,
                           const uint64_t* __restrict__ ps, const uint32_t* __restrict__ slots,
                           uint8_t* __restrict__ result, size_t n, const aff_packed* __restrict__ gen,
@@ -671,7 +695,7 @@ ecdsa_verify_keyed_kernel(const uint64_t* __restrict__ pz, const uint64_t* __res
 }
 
 // (qx, qy) = d * G
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128) SP_SIGN_OCCUPANCY
 public_key_kernel(const uint64_t* __restrict__ pd, uint64_t* __restrict__ ox, uint64_t* __restrict__ oy,
                   uint8_t* __restrict__ status, size_t n, const aff_packed* __restrict__ gen, int wbits,
                   int nwin) {
@@ -722,7 +746,7 @@ __device__ __forceinline__ uint8_t sign_attempt(const u256& z, const u256& d, co
   return SP_SIGN_OK;
 }
 
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128) SP_SIGN_OCCUPANCY
 ecdsa_sign_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pd,
                   const uint64_t* __restrict__ pk, uint64_t* __restrict__ orr, uint64_t* __restrict__ os,
                   uint8_t* __restrict__ status, size_t n, const aff_packed* __restrict__ gen, int wbits,
@@ -743,7 +767,7 @@ ecdsa_sign_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ 
 // attempt, and - should the nonce be rejected, which takes a 2^-55 event - the reference's retry
 // with the next seed (None -> 1 -> 2 ...; a seed of 0 and "no seed" give the same entropy and the
 // same successor, so 0 stands for None).  After 8 rejected nonces the item is left to the caller.
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128) SP_SIGN_OCCUPANCY
 ecdsa_sign_rfc6979_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pd,
                           const uint64_t* __restrict__ pseed, uint64_t* __restrict__ orr,
                           uint64_t* __restrict__ os, uint8_t* __restrict__ status, size_t n,
@@ -859,7 +883,7 @@ sign_nonce_retry_kernel(const uint32_t* __restrict__ idx_in, const uint32_t* __r
 }
 
 // The one-kernel signer for exactly the items whose attempt asked for another seed (status SP_SIGN_RETRY).
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128) SP_SIGN_OCCUPANCY
 ecdsa_sign_rfc6979_redo_kernel(const uint64_t* __restrict__ pz, const uint64_t* __restrict__ pd,
                                const uint64_t* __restrict__ pseed, uint64_t* __restrict__ orr,
                                uint64_t* __restrict__ os, uint8_t* __restrict__ status, size_t n,
@@ -1375,8 +1399,10 @@ static int verify_batch_keyed_impl(const uint64_t* z, const uint64_t* r, const u
   HostLane& L = *ls.lane;
   std::vector<uint32_t> slots(n);
   uint8_t* d_res = nullptr;
+  tl_mark("keyed verify: lane open");
   {
     ctx_lock lk(ctx().mu);
+    tl_mark("keyed verify: context lock taken");
     // the handles never leave this call, so this is not an `external_handles` registration (sp_order_batch comes
     // through here on every batch: it must not switch the policy's eviction off)
     int rc = register_keys_locked(qx, qy, n, slots.data());
@@ -1387,6 +1413,7 @@ static int verify_batch_keyed_impl(const uint64_t* z, const uint64_t* r, const u
     }
     if (policy && rc == SP_ERR_CACHE_FULL) { *fell_back = true; return SP_OK; }  // still no room: the ladder
     if (rc != SP_OK) return rc;
+    tl_mark("keyed verify: keys registered");
     const uint64_t* host[3] = {z, r, s};
     uint64_t* dev[3];
     char* extra;
@@ -1398,6 +1425,7 @@ static int verify_batch_keyed_impl(const uint64_t* z, const uint64_t* r, const u
     rc = sp_ecdsa_verify_keyed_dev(dev[0], dev[1], dev[2], d_slots, d_res, n, L.stream);
     if (rc != SP_OK) return rc;
     SP_HIP(hipMemcpyAsync(result, d_res, n, hipMemcpyDeviceToHost, L.stream));
+    tl_mark("keyed verify: enqueued");
   }
   SP_HIP(hipStreamSynchronize(L.stream));  // `slots` stays alive until the copy that reads it has run
   return SP_OK;

@@ -393,6 +393,7 @@ struct SparseTree {
   uint64_t empty_leaf[4] = {0, 0, 0, 0};
   int ctx_index = 0;           // the context (device) the tree lives on
   TreeSlot* table = nullptr;   // HBM
+  TreeSlot* retired = nullptr; // the table before the last growth (tree_reserve), freed at the next growth / with the tree
   uint64_t slots = 0;          // power of two
   uint64_t entries = 0;        // used slots as of the last read of d_entries
   unsigned long long* d_entries = nullptr;  // device counter of claimed slots (insert kernels add to it)
@@ -423,12 +424,13 @@ static void tree_free(SparseTree& t) {
     (void)hipStreamDestroy(t.stream);
   }
   if (t.table) (void)hipFree(t.table);
+  if (t.retired) (void)hipFree(t.retired);
   if (t.d_entries) (void)hipFree(t.d_entries);
   t.buf.release();
   t.cpts.release();
   t.cpts_state = 0;
   t.stream = nullptr;
-  t.table = nullptr;
+  t.table = t.retired = nullptr;
   t.d_entries = nullptr;
   t.slots = 0;
 }
@@ -462,7 +464,22 @@ struct TreeScope {
   }
 };
 
-// room for `extra` more entries at a load factor of at most 1/2 (tree mutex held)
+// Room for `extra` more entries at a load factor of at most 1/2 (tree mutex held).
+// Growth policy (round 6): a table that has to grow is sized for FOUR times what is asked of it
+// (load factor 1/4 straight after a growth), so that the next updates of the same size fit without another one, and
+// the growth itself costs the caller no wait: allocation, clear and rehash are enqueued on the tree's stream and the
+// old table is retired, not freed - hipFree synchronises the whole device, which in sp_order_batch stalled the
+// verification running beside the update (calls 1 - 2 of a fresh tree cost 2.9 - 3.1 ms against 1.97 ms in round
+// 5).  The retired table goes back at the next growth (its rehash has long finished: the intervening update
+// synchronised the stream) or with the tree.  First allocation: 2^16 slots, or STARKPERP_TREE_INITIAL_SLOTS_LOG2.
+static uint64_t tree_initial_slots() {
+  static const uint64_t v = [] {
+    const char* e = getenv("STARKPERP_TREE_INITIAL_SLOTS_LOG2");
+    const int lg = e ? atoi(e) : 16;
+    return (uint64_t)1 << (lg < 10 ? 10 : (lg > 30 ? 30 : lg));
+  }();
+  return v;
+}
 static int tree_reserve(SparseTree& t, uint64_t extra) {
   if (!t.d_entries) {
     SP_HIP(hipMalloc(&t.d_entries, sizeof(unsigned long long)));
@@ -474,9 +491,15 @@ static int tree_reserve(SparseTree& t, uint64_t extra) {
     SP_HIP(hipStreamSynchronize(t.stream));
     t.entries = used;
   }
-  uint64_t want = t.slots ? t.slots : ((uint64_t)1 << 16);
-  while (2 * (t.entries + extra) > want) want <<= 1;
+  if (t.slots && 2 * (t.entries + extra) <= t.slots) return SP_OK;
+  uint64_t want = t.slots ? t.slots : tree_initial_slots();
+  while (4 * (t.entries + extra) > want) want <<= 1;
   if (want == t.slots) return SP_OK;
+  if (t.retired) {  // the table before the last one: nothing on the stream reads it any more
+    SP_HIP(hipStreamSynchronize(t.stream));
+    (void)hipFree(t.retired);
+    t.retired = nullptr;
+  }
   TreeSlot* fresh = nullptr;
   SP_HIP(hipMalloc(&fresh, want * sizeof(TreeSlot)));
   SP_HIP(hipMemsetAsync(fresh, 0, want * sizeof(TreeSlot), t.stream));
@@ -484,8 +507,7 @@ static int tree_reserve(SparseTree& t, uint64_t extra) {
     hipLaunchKernelGGL(tree_rehash_kernel, dim3((unsigned)((t.slots + 255) / 256)), dim3(256), 0, t.stream, t.table,
                        t.slots, fresh, want - 1);
     SP_HIP(hipGetLastError());
-    SP_HIP(hipStreamSynchronize(t.stream));
-    (void)hipFree(t.table);
+    t.retired = t.table;  // read by the rehash just enqueued; freed later, without a device-wide wait now
   }
   t.table = fresh;
   t.slots = want;
@@ -559,8 +581,10 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
     }
   }
   if (felts >= (size_t)INT_MAX || total > 0x7fffffffull) { set_error("update too large"); return SP_ERR_BAD_ARGUMENT; }
+  tl_mark("tree: level counts");
   rc = tree_reserve(t, total);
   if (rc != SP_OK) return rc;
+  tl_mark("tree: table reserved");
   const size_t emp_bytes = ((size_t)height + 1) * 32;
   const size_t felt_bytes = felts * 32, idx_bytes = idxs * 8, src_bytes = srcs * sizeof(int2);
   SP_HIP(t.buf.reserve(emp_bytes + felt_bytes + idx_bytes + src_bytes + 1024));
@@ -573,7 +597,9 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
   Scratch s;
   {
     // ---- enqueue under the library lock: scratch map, empty-root cache, launch bookkeeping ----
+    tl_mark("tree: work buffer ready");
     ctx_lock lk(global_mu());
+    tl_mark("tree: library lock taken");
     rc = get_scratch_public(n, s, st);
     if (rc != SP_OK) return rc;
     SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
@@ -620,6 +646,7 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
       ++l;
     }
   }
+  tl_mark("tree: levels enqueued");
   // ---- the device runs; nobody waits on the library lock for it ----
   // The status flag and the candidate root come back together: ONE wait per update.
   unsigned f = 0;
@@ -627,6 +654,7 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
   SP_HIP(hipMemcpyAsync(&f, s.flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   SP_HIP(hipMemcpyAsync(candidate, d_felts + 4 * (size_t)lv.val_base[height], 32, hipMemcpyDeviceToHost, st));
   SP_HIP(hipStreamSynchronize(st));
+  tl_mark("tree: levels hashed");
   if (status) *status = (uint8_t)f;
   if (f != 0) {  // an input out of range or an unhashable pair: nothing was written, the tree is as it was
     std::memcpy(new_root, old_root, 32);
@@ -764,9 +792,11 @@ int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t
                    uint64_t* z_out, uint8_t* verdicts, uint64_t* old_root, uint64_t* new_root, uint8_t* tree_status) {
   SP_REQUIRE_READY();
   if (depth < 1 || id_shift > 192) { set_error("sp_order_batch: bad chain depth or id shift"); return SP_ERR_BAD_ARGUMENT; }
+  TimelineScope timeline("sp_order_batch");
   uint8_t chain_status = 0;
   int rc = sp_pedersen_chains(words, n, depth, z_out, &chain_status);
   if (rc != SP_OK) return rc;
+  tl_mark("chains done");
   if (chain_status != 0) {  // a word out of range / an unhashable pair: nothing else runs
     if (tree_status) *tree_status = chain_status;
     for (size_t i = 0; i < n; ++i) verdicts[i] = 0;
@@ -805,8 +835,14 @@ int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t
     keys[j] = ids[j].first;
     std::memcpy(&sorted_leaves[4 * j], leaves + 4 * ids[j].second, 32);
   }
+  tl_mark("ids sorted");
   int vrc = SP_OK;
-  std::thread verifier([&] { vrc = sp_ecdsa_verify_batch_keyed(z_out, r, s, qx, qy, verdicts, n); });
+  std::thread verifier([&] {
+    tl_mark("verifier thread runs");
+    vrc = sp_ecdsa_verify_batch_keyed(z_out, r, s, qx, qy, verdicts, n);
+    tl_mark("verifier done");
+  });
+  tl_mark("verifier spawned");
   bool joined = false;
   const std::function<bool()> all_verified = [&]() {
     verifier.join();

@@ -66,6 +66,37 @@ __device__ __forceinline__ void lds_put(int32_t* lds, int e, const fe& v) {
   for (int l = 0; l < NL; ++l) lds[l * TILE + s] = v.l[l];
 }
 __device__ __forceinline__ fe ld_fe_packed(const uint64_t* p) { return fe_unpack(ld_u256(p)); }
+// The tile kernel streams: every felt of a pass is read once and written once, 1 GB per pass of a 4-column 2^22-point
+// transform against 4 MB of L2 per XCD.  SP_NTT_NT (build switch, A/B in profiles/r06_ntt_pass_ceiling.txt): bit 0 -
+// non-temporal stores of the tile, bit 1 - non-temporal loads.
+#ifndef SP_NTT_NT
+#define SP_NTT_NT 0
+#endif
+typedef uint32_t ntt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u256 ntt_ld(const uint64_t* p) {
+#if SP_NTT_NT & 2
+  const ntt_u32x4* q = reinterpret_cast<const ntt_u32x4*>(p);
+  const ntt_u32x4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+  u256 r;
+  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+  r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+  return r;
+#else
+  return ld_u256(p);
+#endif
+}
+__device__ __forceinline__ void ntt_st(uint64_t* p, const u256& v) {
+#if SP_NTT_NT & 1
+  ntt_u32x4* q = reinterpret_cast<ntt_u32x4*>(p);
+  ntt_u32x4 a, b;
+  a.x = v.w[0]; a.y = v.w[1]; a.z = v.w[2]; a.w = v.w[3];
+  b.x = v.w[4]; b.y = v.w[5]; b.z = v.w[6]; b.w = v.w[7];
+  __builtin_nontemporal_store(a, q);
+  __builtin_nontemporal_store(b, q + 1);
+#else
+  st_u256(p, v);
+#endif
+}
 
 // Where a tile sits in the transform and where its twiddles come from.
 struct ntt_geom {
@@ -217,7 +248,7 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
       for (int q = 0; q < PER; ++q) {
         const int e = threadIdx.x + q * NTT_THREADS;
         const int k = e >> log_c, c = e & (C - 1);
-        v[q] = ld_u256(in + 4 * (base | ((size_t)k << log_lo) | (size_t)c));
+        v[q] = ntt_ld(in + 4 * (base | ((size_t)k << log_lo) | (size_t)c));
       }
 #pragma unroll
       for (int q = 0; q < PER; ++q) lds_put(lds, threadIdx.x + q * NTT_THREADS, fe_unpack(v[q]));
@@ -225,7 +256,7 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
       for (int e = threadIdx.x; e < E; e += NTT_THREADS) {
         const int k = e >> log_c, c = e & (C - 1);
         const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
-        lds_put(lds, e, ld_fe_packed(in + 4 * idx));  // 256-bit input: limbs 0..7 normal, top limb < 2^24
+        lds_put(lds, e, fe_unpack(ntt_ld(in + 4 * idx)));  // 256-bit input: limbs 0..7 normal, top limb < 2^24
       }
     }
   }
@@ -267,9 +298,9 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
       v.l[0] -= q;
       v.l[6] -= q * P6;
       v.l[8] -= q * P8;
-      st_u256(out + 4 * idx, fe_pack(fe_carry(v)));
+      ntt_st(out + 4 * idx, fe_pack(fe_carry(v)));
     } else {
-      st_u256(out + 4 * idx, fe_pack(fe_canon(v)));
+      ntt_st(out + 4 * idx, fe_pack(fe_canon(v)));
     }
   }
 }
@@ -731,7 +762,18 @@ struct EcdsaAirParams {
 
 // Composition of the ECDSA-verification AIR (26 constraints, oracle/stark_ref.py ecdsa_constraint_values);
 // plain operands, Montgomery constants (see the file comment).  per: 12 tables of 4096 plain felts.
-__global__ void __launch_bounds__(256)
+// SP_AIR_ECDSA_WAVES: the same occupancy switch as ecdsa.hip's SP_VERIFY_WAVES.  0 = the allocator's choice (256 VGPRs +
+// 24 AGPRs, one wave per SIMD); 2 = stay within 256 registers: the composition of 4096 verifications (2^24 points)
+// 8.36 -> 5.52 ms (profiles/r06_verify_occupancy.txt; same output digest).  2 is the default since round 6.
+#ifndef SP_AIR_ECDSA_WAVES
+#define SP_AIR_ECDSA_WAVES 2
+#endif
+#if SP_AIR_ECDSA_WAVES > 0
+#define SP_AIR_ECDSA_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SP_AIR_ECDSA_WAVES, SP_AIR_ECDSA_WAVES)))
+#else
+#define SP_AIR_ECDSA_OCCUPANCY
+#endif
+__global__ void __launch_bounds__(256) SP_AIR_ECDSA_OCCUPANCY
 air_eval_ecdsa_kernel(const uint64_t* __restrict__ trace /* [10][M] plain */, const uint64_t* __restrict__ per,
                       size_t M, EcdsaAirParams prm, uint64_t* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -901,7 +943,17 @@ struct AirParams {
 // Block-cyclic row shards (log_block >= 0): the M local points are blocks of B = 2^log_block consecutive
 // LDE rows, local block t being global block t * blk_mul + blk_add (blk_mul = ranks, blk_add = this rank);
 // every block is stored with its own halo, B + 4 rows apart.
-__global__ void __launch_bounds__(256)
+// SP_AIR_WAVES: occupancy switch of the Pedersen-step composition (177 VGPRs: two waves per SIMD; 3 needs <= 168).
+// A/B build only (profiles/r06_verify_occupancy.txt): 0 = the allocator's choice.
+#ifndef SP_AIR_WAVES
+#define SP_AIR_WAVES 0
+#endif
+#if SP_AIR_WAVES > 0
+#define SP_AIR_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SP_AIR_WAVES, SP_AIR_WAVES)))
+#else
+#define SP_AIR_OCCUPANCY
+#endif
+__global__ void __launch_bounds__(256) SP_AIR_OCCUPANCY
 air_eval_kernel(const uint64_t* __restrict__ trace /* [4][col_stride] plain */, const uint64_t* __restrict__ per /* [6][2048] plain */,
                 size_t M, size_t col_stride, size_t row0, int wrap, AirParams prm, uint64_t* __restrict__ out /* [M] plain */,
                 int log_block, size_t blk_mul, size_t blk_add) {
@@ -1077,6 +1129,14 @@ static int coset_table(int log_n, int log_blowup, const uint64_t* shift_host, co
 // pad_log_b > 0 (dit only) `in` is the bit-reversed coefficient array of 2^(log_n - pad_log_b) felts per
 // column and the zero-padded, coset-scaled input of the transform exists only in LDS.
 static const bool g_ntt_lazy_store = getenv("STARKPERP_NTT_CANON_ALL") == nullptr;  // A/B switch
+// MEASUREMENT switch, never set in production: STARKPERP_NTT_PROBE=copy launches every pass with
+// ZERO stages - load, unpack, LDS tile, barrier, pack, store, nothing else - so that a trace shows what the kernel's
+// own data path costs per pass (its HBM ceiling).  The results are NOT a transform (tools/ntt_pass_ceiling.py only
+// times them; profiles/r06_ntt_pass_ceiling.txt).
+static const bool g_ntt_probe_copy = [] {
+  const char* e = getenv("STARKPERP_NTT_PROBE");
+  return e != nullptr && strcmp(e, "copy") == 0;
+}();
 // The tile needs more dynamic LDS than a kernel gets by default.  The attribute is per function AND per device, and
 // sp_shutdown followed by sp_init on another device keeps this process's statics: the result is cached per device
 // (as pedersen.hip's finish_lds_ready does), under its own mutex because the prover's entry points may be entered
@@ -1144,7 +1204,7 @@ static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse,
     const unsigned blocks = (unsigned)(((size_t)1 << log_n) >> ps.log_e);
     const int pb = first ? pad_log_b : 0;
     hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks, ncols), dim3(NTT_THREADS), NTT_LDS_BYTES, st, src, out, ps.log_e, ps.log_t,
-                       ps.log_lo, ps.nst, ps.t_first, dit, tw, log_n, last ? (use_scale ? 1 : 0) : (g_ntt_lazy_store ? 2 : 0), scale, src_stride,
+                       ps.log_lo, g_ntt_probe_copy ? 0 : ps.nst, ps.t_first, dit, tw, log_n, last ? (use_scale ? 1 : 0) : (g_ntt_lazy_store ? 2 : 0), scale, src_stride,
                        out_col_stride, pb ? pad_G : (const uint64_t*)nullptr, pb, pb ? log_n - pad_log_b : 0);
     src = out;
     src_stride = out_col_stride;
