@@ -180,8 +180,11 @@ def summary_object(result):
         "c3_tree_update_ms": _ms(g(result, "extra", "c3_4096_orders_numpy_entry_points_seconds",
                                    "orders_tree_height64_update_on_existing_state")),
         "c3_verify_frac": g(result, "extra", "c3", "roofline", "verify_keyed", "frac"),
+        "c3_verify_ladder_frac": g(result, "extra", "c3", "roofline", "verify_ladder", "frac"),
         "ecdsa_verifies_per_sec_ladder": g(result, "extra", "ecdsa_verifies_per_sec_x_only_2p16"),
         "ecdsa_verifies_per_sec_key_tables": g(result, "extra", "ecdsa_verifies_per_sec_key_tables_2p16"),
+        "ecdsa_verifies_per_sec_ladder_2p18": g(result, "extra", "ecdsa_verifies_per_sec_x_only_2p18"),
+        "ecdsa_verifies_per_sec_key_tables_2p18": g(result, "extra", "ecdsa_verifies_per_sec_key_tables_2p18"),
         "ecdsa_signs_per_sec": g(result, "extra", "ecdsa_signs_per_sec_2p16"),
         "ecdsa_signs_per_sec_list_api_host_inclusive": g(result, "extra", "ecdsa_signs_per_sec_2p16_host_inclusive"),
         "cpu_hashes_per_sec_python_port": g(result, "cpu_baseline", "value"),

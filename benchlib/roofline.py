@@ -13,6 +13,7 @@ PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.js
              "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 AIRFRI_PMC_FILES = ("r06_pmc_traffic_airfri.json", "r04_pmc_traffic_airfri.json", "r03_pmc_traffic_airfri.json",
                     "r02_pmc_traffic_airfri.json")
+C3_COUNTER_FILES = ("r06_c3_sq_counters.json",)
 VALU_ISSUE_FILES = ("r06_valu_issue.json", "r04_valu_issue.json", "r03_valu_issue.json", "r02_valu_issue.json",
                     "r01_valu_issue.json")
 # Where the prose about the peak lives (it was 1.3 KB of every line in round 5)
@@ -125,3 +126,54 @@ def airfri_config_key(wbits):
     """2^20-row jobs alternating over three streams (the `airfri` object and `--workload airfri`); the files of rounds
     2 - 4 carry the bare key "airfri" and so never compare equal."""
     return "airfri:rows=2^20:streams=3:w=%d" % wbits
+
+
+def c3_roofline(live_rates):
+    """Roofline of the kernels BASELINE.json configs[2] is made of: instructions per item from the
+    committed SQ_INSTS_VALU pass (profiles/r06_c3_sq_counters.json, tools/c3_counters.py), the rate LIVE where
+    bench.py measures one (`live_rates`: {"verify_ladder": signatures/s at 2^16, "verify_keyed": ...}) and from the
+    counter pass's own launch otherwise.  achieved = wave64 VALU instructions per second; frac against the same issue
+    peak as the hash kernels (all of them are fe_mul-dominated: the same instruction mix)."""
+    m = None
+    for name in C3_COUNTER_FILES:
+        m = _load(name)
+        if m is not None:
+            src = "profiles/" + name
+            break
+    if m is None:
+        return None
+    peak = valu_peak()
+    out = {"unit": "wave64 VALU instr/s", "peak": peak, "cycles_per_instr_of_the_mix": valu_cycles_per_instr(),
+           "instr_source": src}
+
+    def entry(kernel, grid):
+        return ((m["kernels"].get(kernel) or {}).get("by_grid") or {}).get(str(grid))
+
+    for key, kernel, live in (("verify_ladder", "sp::ecdsa_verify_kernel", live_rates.get("verify_ladder")),
+                              ("verify_keyed", "sp::ecdsa_verify_keyed_kernel", live_rates.get("verify_keyed"))):
+        e = entry(kernel, 1 << 16)
+        if not e:
+            continue
+        ips = e["instr_per_signature"]
+        rate = live if live else (1 << 16) / (e["duration_us_under_pmc"] * 1e-6)
+        ach = ips * rate / 64.0
+        out[key] = {"kernel": kernel, "items": 1 << 16, "instr_per_item": ips, "items_per_sec": rate,
+                    "rate_is": "live (this run)" if live else "the counter pass's launch",
+                    "achieved": ach, "frac": ach / peak, "waves_per_simd": e["waves_per_simd"],
+                    "registers": {k: (m["kernels"][kernel].get(k)) for k in ("vgpr", "agpr", "scratch_bytes_per_lane")}}
+    for key, kernel, grid, items, what in (
+            ("verify_keyed_4096", "sp::ecdsa_verify_keyed_kernel", 4096, 4096, "signatures"),
+            ("message_hash_chains", "sp::ped_chain_kernel<2>", 65536, 3 * 4096, "hashes (4096 chains x 3)"),
+            ("tree_paths", "sp::ped_path_kernel<2, true>", 65536, None, "4096 paths x the unmerged levels")):
+        e = entry(kernel, grid)
+        if not e:
+            continue
+        ach = e["valu_wave_instr"] / (e["duration_us_under_pmc"] * 1e-6)
+        out[key] = {"kernel": kernel, "items": items, "item": what, "valu_wave_instr_per_launch": e["valu_wave_instr"],
+                    "instr_per_wave": e["instr_per_wave"], "launch_us": e["duration_us_under_pmc"],
+                    "rate_is": "the counter pass's launch", "achieved": ach, "frac": ach / peak,
+                    "waves_per_simd": e["waves_per_simd"],
+                    "ns_per_dependent_instr": 1e3 * e["duration_us_under_pmc"] / e["instr_per_wave"]}
+        if items:
+            out[key]["instr_per_item"] = e["valu_wave_instr"] * 64.0 / items  # lane-instructions per item
+    return out

@@ -1400,25 +1400,30 @@ static int verify_batch_keyed_impl(const uint64_t* z, const uint64_t* r, const u
   std::vector<uint32_t> slots(n);
   uint8_t* d_res = nullptr;
   tl_mark("keyed verify: lane open");
+  // z, r, s go to the lane's own buffer on the lane's own stream BEFORE the lock is taken: nothing shared is touched,
+  // and three copies from pageable memory are the longest part of this function's host time (0.5 ms for 4096
+  // signatures, profiles/r06_c3_timeline.txt) - round 5 made them under the lock, where sp_order_batch's tree update
+  // (the critical path of that call) queued behind them.
+  const uint64_t* host[3] = {z, r, s};
+  uint64_t* dev[3];
+  char* extra;
+  int rc = stage_in_lane(L, host, 3, n, dev, n * 4 + n, &extra);
+  if (rc != SP_OK) return rc;
+  tl_mark("keyed verify: inputs staged");
   {
     ctx_lock lk(ctx().mu);
     tl_mark("keyed verify: context lock taken");
     // the handles never leave this call, so this is not an `external_handles` registration (sp_order_batch comes
     // through here on every batch: it must not switch the policy's eviction off)
-    int rc = register_keys_locked(qx, qy, n, slots.data());
+    rc = register_keys_locked(qx, qy, n, slots.data());
     if (policy && rc == SP_ERR_CACHE_FULL && !g_keys.external_handles) {
       // full (register_keys_locked rolled its partial work back): start a new generation and register once more.
       // use_key_tables has checked that the batch's distinct keys fit an empty cache.
       if (sp_ecdsa_key_cache_reset() == SP_OK) rc = register_keys_locked(qx, qy, n, slots.data());
     }
-    if (policy && rc == SP_ERR_CACHE_FULL) { *fell_back = true; return SP_OK; }  // still no room: the ladder
-    if (rc != SP_OK) return rc;
+    if (policy && rc == SP_ERR_CACHE_FULL) { *fell_back = true; lane_drain(&L); return SP_OK; }  // still no room: the ladder
+    if (rc != SP_OK) { lane_drain(&L); return rc; }
     tl_mark("keyed verify: keys registered");
-    const uint64_t* host[3] = {z, r, s};
-    uint64_t* dev[3];
-    char* extra;
-    rc = stage_in_lane(L, host, 3, n, dev, n * 4 + n, &extra);
-    if (rc != SP_OK) return rc;
     uint32_t* d_slots = (uint32_t*)extra;
     d_res = (uint8_t*)(extra + n * 4);
     SP_HIP(hipMemcpyAsync(d_slots, slots.data(), n * 4, hipMemcpyHostToDevice, L.stream));

@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 cd $R
 python tools/c3_probe.py calls 24 > $O/calls.txt 2> $O/calls.err
 python tools/c3_probe.py calls 24 >> $O/calls.txt 2>> $O/calls.err
+STARKPERP_TIMELINE=1 python tools/c3_probe.py calls 6 > /dev/null 2> $O/host_timeline.txt
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python $R/tools/c3_probe.py one > $O/one.txt 2> $O/one.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $O/pmc -o p -- python $R/tools/c3_probe.py pmc > $O/pmc.txt 2> $O/pmc.err
@@ -18,7 +19,6 @@ cd $R
 T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 python tools/c3_timeline.py $T > $O/r06_c3_timeline.txt 2>&1
 C=$(find $O/pmc -name "*counter_collection.csv" | head -1)
-K=$(find $O/pmc -name "*kernel_trace.csv" | head -1)
-python tools/c3_counters.py $C $K $O/r06_c3_sq_counters.json > /dev/null 2> $O/counters.err
+python tools/c3_counters.py $C $O/r06_c3_sq_counters.json > /dev/null 2> $O/counters.err
 rm -rf $O/trace $O/pmc
 cat $O/calls.txt; tail -25 $O/r06_c3_timeline.txt; head -60 $O/r06_c3_sq_counters.json
