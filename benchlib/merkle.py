@@ -63,7 +63,7 @@ def kernel_roofline(prof, wbits, config_key, value_per_gpu, held_mhz, share_of_h
                     note="the roofline the contract names; this kernel is integer-ALU bound (about 27 k VALU "
                          "instructions per 96 algorithmic bytes), so the HBM fraction says nothing about it"),
         "whole_region": valu_issue(value_per_gpu, wbits, "every kernel of the timed region: hashes/s per GPU over the "
-                                                         "wall time (latency-bound upper levels included)"),
+                                                         "wall time (latency-bound upper levels included)", whole_forest=True),
         "frac_basis": "peak at the NOMINAL 2.4 GHz with c_mix = %.2f cycles per wave64 instruction" % valu_cycles_per_instr(),
     })
     add_held_clock(roof, held_mhz)

@@ -65,13 +65,32 @@ def valu_peak(clock_mhz=None):
     return VALU_PEAK_SIMDS * hz / valu_cycles_per_instr()
 
 
-def valu_issue(hashes_per_sec, window_bits, workload, include_finish=True):
+def forest_instr_per_hash(window_bits):
+    """VALU instructions per hash over EVERY kernel of the 20-tree forest build (accumulate, finish-lds, split, quad and
+    top kernels; profiles/r06_valu_issue.json `forest_20`, measured at 26-bit windows) and its file, or None."""
+    if window_bits != 26:
+        return None
+    for name in VALU_ISSUE_FILES:
+        m = _load(name)
+        try:
+            return float(m["forest_20"]["instr_per_hash_all_kernels"]), name
+        except Exception:  # noqa: BLE001
+            continue
+    return None
+
+
+def valu_issue(hashes_per_sec, window_bits, workload, include_finish=True, whole_forest=False):
     """The roofline that binds the hash kernels: wave64 VALU instructions issued per
-    second against the chip's issue peak."""
+    second against the chip's issue peak.  whole_forest: price a hash at what the whole 20-tree build issues per hash
+    (every kernel, measured) instead of accumulate + finish of the bulk batch."""
     c = valu_counts(window_bits)
     if c is None:
         return None
     per_hash = c[0] + (c[1] if include_finish else 0)
+    if whole_forest:
+        f = forest_instr_per_hash(window_bits)
+        if f is not None:
+            per_hash, c = f[0], (c[0], c[1], f[1])
     achieved = hashes_per_sec * per_hash / 64.0
     peak = valu_peak()
     return {"bound": "valu_issue", "workload": workload, "instr_per_hash": per_hash,

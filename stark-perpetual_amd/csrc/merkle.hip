@@ -502,6 +502,7 @@ static int tree_reserve(SparseTree& t, uint64_t extra) {
   }
   TreeSlot* fresh = nullptr;
   SP_HIP(hipMalloc(&fresh, want * sizeof(TreeSlot)));
+  tl_mark("tree: table allocated");
   SP_HIP(hipMemsetAsync(fresh, 0, want * sizeof(TreeSlot), t.stream));
   if (t.table) {
     hipLaunchKernelGGL(tree_rehash_kernel, dim3((unsigned)((t.slots + 255) / 256)), dim3(256), 0, t.stream, t.table,
@@ -609,6 +610,7 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
     SP_HIP(hipMemcpyAsync(d_emp, emp->data(), emp_bytes, hipMemcpyHostToDevice, st));
     SP_HIP(hipMemcpyAsync(d_felts, leaves, n * 32, hipMemcpyHostToDevice, st));
     SP_HIP(hipMemcpyAsync(d_idx, keys, n * 8, hipMemcpyHostToDevice, st));
+    tl_mark("tree: inputs copied");
     // the structure of every level and the sibling lookups, then the hashes level by level
     hipLaunchKernelGGL(tree_level_nodes_kernel, dim3(height), dim3(1024), 0, st, lv, d_idx, d_idx);
     hipLaunchKernelGGL(tree_children_kernel, dim3((unsigned)((total - cnt[height] + 255) / 256)), dim3(256), 0, st, lv,
@@ -616,6 +618,7 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
     hipLaunchKernelGGL(tree_lookup_kernel, dim3((unsigned)((srcs + 255) / 256)), dim3(256), 0, st, lv, d_idx, t.table,
                        t.slots - 1, d_felts, d_src, (unsigned)srcs);
     SP_HIP(hipGetLastError());
+    tl_mark("tree: structure kernels enqueued");
     if (t.cpts_state == 0) {  // once per tree: the constant points of its 64 levels (d_emp is on the stream already)
       SP_HIP(t.cpts.reserve(2 * (size_t)height * sizeof(aff_packed)));
       bool usable = false;
