@@ -166,6 +166,7 @@ void release_host_lanes() {
       l.stream = nullptr;
     }
     l.io.release();
+    l.hio.release();
     l.busy = false;
   }
 }

@@ -53,6 +53,33 @@ struct DeviceBuffer {
   }
 };
 
+// Page-locked host memory for staging SMALL host-pointer batches (round 6).  A hipMemcpyAsync from pageable memory
+// makes the runtime pin / unpin the caller's pages around every copy; when two host threads of one call do that at
+// the same time - sp_order_batch's tree update and its verifier thread - one of them was seen to stall for 6 - 11 ms
+// (profiles/r06_c3_host_timeline.txt).  Staged copies (memcpy into this buffer, then a truly asynchronous DMA) have no
+// such path.  Batches above PINNED_STAGE_MAX keep the direct copy: they are throughput-bound, and page-locking hundreds
+// of megabytes per lane would cost more than it saves.
+constexpr size_t PINNED_STAGE_MAX = (size_t)4 << 20;
+struct PinnedBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t need) {  // grow-only; contents are not preserved
+    if (need <= bytes) return hipSuccess;
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    size_t want = need + need / 4;
+    hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+    if (e == hipSuccess) bytes = want;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
 // One context per device the process drives (sp_init: one; sp_init_devices: several).  Context 0 is the
 // PRIMARY: the stateful machinery - persistent trees, the ECDSA key cache, the prover's twiddle tables and
 // witness scratch - lives on its device only.  The stateless batches (hash, ladder verification, signing,
@@ -120,6 +147,7 @@ struct HostLane {
   hipStream_t stream = nullptr;
   int stream_ctx = -1;          // the context the stream was created for
   DeviceBuffer io;
+  PinnedBuffer hio;             // host-side staging of small batches (see PinnedBuffer)
   bool busy = false;
 };
 HostLane* lane_acquire(int* ctx_index, int want_ctx);  // want_ctx < 0: any context, round-robin
@@ -127,6 +155,10 @@ void lane_release(HostLane* lane);
 void lane_drain(HostLane* lane);  // waits for whatever is still queued on the lane's stream
 int lane_stream(HostLane* lane);  // creates the lane's stream on the current device if needed; SP_OK or SP_ERR_HIP
 void release_host_lanes();        // sp_shutdown
+// ecdsa.hip: keyed verification of a host batch; `before_lock` runs once, after the lock-free part and before the
+// library lock is taken (also when there is nothing to verify).
+int verify_batch_keyed_gated(const uint64_t* z, const uint64_t* r, const uint64_t* s, const uint64_t* qx,
+                             const uint64_t* qy, uint8_t* result, size_t n, const std::function<void()>& before_lock);
 // Usage in an entry point:  LaneScope ls;  SP_REQUIRE_READY();  if (ls.open() != SP_OK) return SP_ERR_HIP;
 // A large host batch on several contexts: `fn(offset, count)` runs once per context on its own host thread, each
 // bound to its context (so the LaneScope inside takes a lane of that context), over contiguous slices of the n

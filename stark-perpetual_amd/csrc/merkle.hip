@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
 #include <map>
 #include <memory>
@@ -405,6 +406,7 @@ struct SparseTree {
   // updates of OTHER trees proceed meanwhile (round 2: null stream, library lock across everything).
   hipStream_t stream = nullptr;
   DeviceBuffer buf;
+  PinnedBuffer hbuf;  // host-side staging of an update's inputs (empty roots, leaves, keys): see PinnedBuffer
   // The constant points of the levels (pedersen.hip SPARSE quad kernel): for level l the sum of the table entries
   // that the level's empty-subtree root selects as a left / right operand, [2 l] and [2 l + 1]; computed on the
   // tree's stream by its first update, kept for its lifetime (the window plan cannot change under a live tree).
@@ -427,6 +429,7 @@ static void tree_free(SparseTree& t) {
   if (t.retired) (void)hipFree(t.retired);
   if (t.d_entries) (void)hipFree(t.d_entries);
   t.buf.release();
+  t.hbuf.release();
   t.cpts.release();
   t.cpts_state = 0;
   t.stream = nullptr;
@@ -535,7 +538,8 @@ static int tree_root_locked(SparseTree& t, uint64_t* root) {
 // node has been hashed and before anything is written to the table: false leaves the tree as it was
 // (*status = SP_TREE_NOT_COMMITTED).
 static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_t* leaves, size_t n, uint64_t* old_root,
-                              uint64_t* new_root, uint8_t* status, const std::function<bool()>* may_commit) {
+                              uint64_t* new_root, uint8_t* status, const std::function<bool()>* may_commit,
+                              const std::function<void()>* enqueued = nullptr) {
   const unsigned height = t.height;
   for (size_t i = 0; i < n; ++i) {
     if (i > 0 && keys[i] <= keys[i - 1]) { set_error("keys must be strictly increasing"); return SP_ERR_BAD_ARGUMENT; }
@@ -607,9 +611,24 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
     const std::vector<uint64_t>* emp = nullptr;
     rc = empty_roots(t.empty_leaf, s, &emp);
     if (rc != SP_OK) return rc;
-    SP_HIP(hipMemcpyAsync(d_emp, emp->data(), emp_bytes, hipMemcpyHostToDevice, st));
-    SP_HIP(hipMemcpyAsync(d_felts, leaves, n * 32, hipMemcpyHostToDevice, st));
-    SP_HIP(hipMemcpyAsync(d_idx, keys, n * 8, hipMemcpyHostToDevice, st));
+    // empty roots + leaves are adjacent in the work buffer (d_emp, then the level-0 values at the start of d_felts):
+    // one copy; the keys a second one.  Small updates go through the tree's page-locked buffer (PinnedBuffer).
+    const size_t in_bytes = emp_bytes + n * 32 + n * 8;
+    char* stage = nullptr;
+    if (in_bytes <= PINNED_STAGE_MAX && t.hbuf.reserve(in_bytes) == hipSuccess) stage = (char*)t.hbuf.ptr;
+    else (void)hipGetLastError();
+    if (stage) {
+      // the previous update's copies out of this buffer are long finished: every update ends with a wait on `st`
+      std::memcpy(stage, emp->data(), emp_bytes);
+      std::memcpy(stage + emp_bytes, leaves, n * 32);
+      std::memcpy(stage + emp_bytes + n * 32, keys, n * 8);
+      SP_HIP(hipMemcpyAsync(d_emp, stage, emp_bytes + n * 32, hipMemcpyHostToDevice, st));
+      SP_HIP(hipMemcpyAsync(d_idx, stage + emp_bytes + n * 32, n * 8, hipMemcpyHostToDevice, st));
+    } else {
+      SP_HIP(hipMemcpyAsync(d_emp, emp->data(), emp_bytes, hipMemcpyHostToDevice, st));
+      SP_HIP(hipMemcpyAsync(d_felts, leaves, n * 32, hipMemcpyHostToDevice, st));
+      SP_HIP(hipMemcpyAsync(d_idx, keys, n * 8, hipMemcpyHostToDevice, st));
+    }
     tl_mark("tree: inputs copied");
     // the structure of every level and the sibling lookups, then the hashes level by level
     hipLaunchKernelGGL(tree_level_nodes_kernel, dim3(height), dim3(1024), 0, st, lv, d_idx, d_idx);
@@ -650,6 +669,7 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
     }
   }
   tl_mark("tree: levels enqueued");
+  if (enqueued) (*enqueued)();  // the library lock is free again: sp_order_batch lets its verifier through
   // ---- the device runs; nobody waits on the library lock for it ----
   // The status flag and the candidate root come back together: ONE wait per update.
   unsigned f = 0;
@@ -825,17 +845,34 @@ int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t
   // The verification needs nothing but z: it starts NOW, on a thread of its own, so that its host work (lane, staging
   // copies, key lookup) runs beside the sort below and its launch beside the tree's levels.  (Round 5 spawned it after
   // the sort: 150 us later, and it then queued for the library lock behind the tree's enqueue.)
+  // The verifier does its lock-free part at once (lane, staging copies) and then waits at a gate until the tree
+  // update has enqueued its levels: the tree is the critical path and both need the library lock.
+  struct Gate {
+    std::mutex m;
+    std::condition_variable cv;
+    bool open = false;
+    void release() {
+      { std::lock_guard<std::mutex> lk(m); open = true; }
+      cv.notify_all();
+    }
+    void wait() {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return open; });
+    }
+  } gate;
+  const std::function<void()> open_gate = [&] { gate.release(); };
   int vrc = SP_OK;
   std::thread verifier([&] {
     tl_mark("verifier thread runs");
-    vrc = sp_ecdsa_verify_batch_keyed(z_out, r, s, qx, qy, verdicts, n);
+    vrc = verify_batch_keyed_gated(z_out, r, s, qx, qy, verdicts, n, [&] { gate.wait(); });
     tl_mark("verifier done");
   });
   tl_mark("verifier spawned");
-  struct Joiner {  // every return below joins the verifier first: it reads the caller's arrays
+  struct Joiner {  // every return below opens the gate and joins the verifier first: it reads the caller's arrays
     std::thread& t;
-    ~Joiner() { if (t.joinable()) t.join(); }
-  } joiner{verifier};
+    Gate& g;
+    ~Joiner() { g.release(); if (t.joinable()) t.join(); }
+  } joiner{verifier, gate};
   // order ids, sorted, with the leaves in the same order.  The ids are bits of hash outputs - uniform - so one
   // counting pass over their top bits leaves buckets of about one id each and a tiny std::sort inside every bucket
   // (any input is still sorted correctly: a skewed one only makes a bucket's sort longer).  120 us -> ~25 us for
@@ -871,6 +908,7 @@ int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t
   tl_mark("ids sorted");
   bool joined = false;
   const std::function<bool()> all_verified = [&]() {
+    gate.release();  // (an empty update asks before anything was enqueued)
     verifier.join();
     joined = true;
     if (vrc != SP_OK) return false;
@@ -882,8 +920,10 @@ int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t
     TreeScope ts;
     rc = ts.open(tree);
     if (rc == SP_OK)
-      rc = tree_update_locked(*ts.t, keys.data(), sorted_leaves.data(), n, old_root, new_root, tree_status, &all_verified);
+      rc = tree_update_locked(*ts.t, keys.data(), sorted_leaves.data(), n, old_root, new_root, tree_status, &all_verified,
+                              &open_gate);
   }
+  gate.release();  // (the tree failed before it enqueued anything)
   if (!joined && verifier.joinable()) verifier.join();
   // the error text is process-wide (set_error), so what the verifier thread reported is what sp_last_error says;
   // when both legs failed the tree's code wins and the text is whichever leg failed last

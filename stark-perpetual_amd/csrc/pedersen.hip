@@ -16,6 +16,7 @@
 // Algorithmic bytes per hash: 96 (two felts in, one out).  The kernel is VALU bound
 // (~1.75e3 VALU instructions per window addition, 39e3 per hash), not HBM bound - see DESIGN.md.
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <vector>
 
@@ -1401,12 +1402,19 @@ int sp_pedersen_chains(const uint64_t* elems, size_t width, size_t depth, uint64
   SP_HIP(L.io.reserve((width * depth + width) * 32 + 64));
   uint64_t* d_el = (uint64_t*)L.io.ptr;
   uint64_t* d_out = d_el + 4 * width * depth;
-  SP_HIP(hipMemcpyAsync(d_el, elems, width * depth * 32, hipMemcpyHostToDevice, L.stream));
+  // small batches (sp_order_batch's message hashes) in and out through the lane's page-locked buffer: see PinnedBuffer
+  const size_t in_bytes = width * depth * 32, out_bytes = width * 32;
+  char* stage = nullptr;
+  if (in_bytes + out_bytes <= PINNED_STAGE_MAX && L.hio.reserve(in_bytes + out_bytes) == hipSuccess) stage = (char*)L.hio.ptr;
+  else (void)hipGetLastError();
+  if (stage) std::memcpy(stage, elems, in_bytes);
+  SP_HIP(hipMemcpyAsync(d_el, stage ? (const void*)stage : (const void*)elems, in_bytes, hipMemcpyHostToDevice, L.stream));
   uint8_t st8 = 0;  // written by the stream (the chains' status flag), read after the synchronisation below
   int rc = sp_pedersen_chains_dev(d_el, width, depth, d_out, &st8, L.stream);
   if (rc != SP_OK) return rc;
-  SP_HIP(hipMemcpyAsync(out, d_out, width * 32, hipMemcpyDeviceToHost, L.stream));
+  SP_HIP(hipMemcpyAsync(stage ? (void*)(stage + in_bytes) : (void*)out, d_out, out_bytes, hipMemcpyDeviceToHost, L.stream));
   SP_HIP(hipStreamSynchronize(L.stream));
+  if (stage) std::memcpy(out, stage + in_bytes, out_bytes);
   if (status) *status = st8;
   return SP_OK;
 }

@@ -251,6 +251,37 @@ def test_library_tree_large_batches_and_table_growth():
     lib_tree.close()
 
 
+def test_library_tree_grows_through_three_tables_without_losing_a_node():
+    """Round 6 growth policy (csrc/merkle.hip tree_reserve): a table that must grow is sized for four times the need,
+    the rehash is enqueued on the tree's stream and the OLD table is retired, not freed, until the next growth.  48
+    small batches take a fresh tree from its first 2^16-slot table through two growths (the second one frees the table
+    retired by the first): every root equals the Python tree's, and keys written before either growth are still there."""
+    import random
+    from oracle import cref
+    from starkperp import state
+
+    def oracle_hash_many(xs, ys):
+        return cref.opt_pedersen_hash_many(list(xs), list(ys))[0]
+
+    rng = random.Random(61)
+    lib_tree = state.LibrarySparseTree(64, 0)
+    ref_tree = state.SparseMerkleTree(64, 0, hash_many=oracle_hash_many)
+    first = {rng.randrange(2**64): rng.randrange(1, P) for _ in range(50)}
+    assert lib_tree.update(first) == ref_tree.update(first)
+    written = dict(first)
+    for r in range(47):
+        mods = {rng.randrange(2**64): rng.randrange(1, P) for _ in range(50)}
+        if r % 5 == 0:  # overwrite some early keys as well: replaced nodes must not be counted twice
+            for k in rng.sample(list(first), 5):
+                mods[k] = rng.randrange(1, P)
+        written.update(mods)
+        assert lib_tree.update(mods) == ref_tree.update(mods), r
+    keys = list(written)
+    assert lib_tree.get_many(keys) == [written[k] for k in keys]
+    assert lib_tree.get_many(keys[:20]) == ref_tree.get_many(keys[:20])
+    lib_tree.close()
+
+
 def test_order_batch_in_one_call_matches_the_separate_calls():
     """sp_order_batch (BASELINE configs[2] in one library call): message hashes, verdicts and the orders-tree roots
     equal those of the separate entry points; a bad signature leaves the tree uncommitted; equal order ids are an
