@@ -241,9 +241,6 @@ def extras(torch, lib, _lib, dev, stream):
         dz.data_ptr(), dr.data_ptr(), dsig.data_ptr(), dslots.data_ptr(), res.data_ptr(), nv, stream), "keyed"), 3)
     out["ecdsa_verifies_per_sec_key_tables_2p16"] = nv / kv_t
     out["ecdsa_verify_key_tables_all_true"] = bool(int((res == 1).sum()) == stv.count(0))
-    # configs[2]'s kernels against the issue roofline (instruction counts from the committed PMC pass, rates live)
-    out["c3"] = {"roofline": c3_roofline({"verify_ladder": out["ecdsa_verifies_per_sec_x_only_2p16"],
-                                          "verify_keyed": out["ecdsa_verifies_per_sec_key_tables_2p16"]})}
     # the same two kernels at 2^18 signatures (two waves per SIMD resident: where the round-6 occupancy pays)
     rep4 = lambda t_: t_.repeat(4, 1).contiguous()  # noqa: E731
     z4, r4, s4, q4 = rep4(dz), rep4(dr), rep4(dsig), rep4(dq)
@@ -256,6 +253,11 @@ def extras(torch, lib, _lib, dev, stream):
     out["ecdsa_verifies_per_sec_key_tables_2p18"] = 4 * nv / t4
     out["ecdsa_verify_2p18_all_true"] = bool(int((res4 == 1).sum()) == 4 * stv.count(0))
     del z4, r4, s4, q4, sl4, res4
+    # configs[2]'s kernels against the issue roofline (instruction counts from the committed PMC pass, rates live)
+    out["c3"] = {"roofline": c3_roofline({"verify_ladder": out["ecdsa_verifies_per_sec_x_only_2p16"],
+                                          "verify_keyed": out["ecdsa_verifies_per_sec_key_tables_2p16"],
+                                          "verify_ladder_2p18": out["ecdsa_verifies_per_sec_x_only_2p18"],
+                                          "verify_keyed_2p18": out["ecdsa_verifies_per_sec_key_tables_2p18"]})}
     # full deterministic signing (RFC 6979 nonce + attempt on the device), Python ints in and out
     t0 = time.perf_counter()
     signed = _batch.sign_many(zv, dsk)

@@ -181,6 +181,8 @@ def summary_object(result):
                                    "orders_tree_height64_update_on_existing_state")),
         "c3_verify_frac": g(result, "extra", "c3", "roofline", "verify_keyed", "frac"),
         "c3_verify_ladder_frac": g(result, "extra", "c3", "roofline", "verify_ladder", "frac"),
+        "verify_keyed_frac_2p18": g(result, "extra", "c3", "roofline", "verify_keyed_2p18", "frac"),
+        "verify_ladder_frac_2p18": g(result, "extra", "c3", "roofline", "verify_ladder_2p18", "frac"),
         "ecdsa_verifies_per_sec_ladder": g(result, "extra", "ecdsa_verifies_per_sec_x_only_2p16"),
         "ecdsa_verifies_per_sec_key_tables": g(result, "extra", "ecdsa_verifies_per_sec_key_tables_2p16"),
         "ecdsa_verifies_per_sec_ladder_2p18": g(result, "extra", "ecdsa_verifies_per_sec_x_only_2p18"),

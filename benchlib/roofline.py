@@ -180,6 +180,14 @@ def c3_roofline(live_rates):
                     "rate_is": "live (this run)" if live else "the counter pass's launch",
                     "achieved": ach, "frac": ach / peak, "waves_per_simd": e["waves_per_simd"],
                     "registers": {k: (m["kernels"][kernel].get(k)) for k in ("vgpr", "agpr", "scratch_bytes_per_lane")}}
+    # the same kernels at 2^18 signatures (two waves per SIMD resident since round 6): live rates only
+    for key, base, n_waves in (("verify_ladder_2p18", "verify_ladder", 2.0), ("verify_keyed_2p18", "verify_keyed", 2.0)):
+        rate = live_rates.get(key)
+        if rate and base in out:
+            ach = out[base]["instr_per_item"] * rate / 64.0
+            out[key] = {"kernel": out[base]["kernel"], "items": 1 << 18, "instr_per_item": out[base]["instr_per_item"],
+                        "items_per_sec": rate, "rate_is": "live (this run)", "achieved": ach, "frac": ach / peak,
+                        "waves_per_simd": n_waves}
     for key, kernel, grid, items, what in (
             ("verify_keyed_4096", "sp::ecdsa_verify_keyed_kernel", 4096, 4096, "signatures"),
             ("message_hash_chains", "sp::ped_chain_kernel<2>", 65536, 3 * 4096, "hashes (4096 chains x 3)"),

@@ -11,7 +11,8 @@ export TMPDIR=/tmp
 cd $R
 python tools/c3_probe.py calls 24 > $O/calls.txt 2> $O/calls.err
 python tools/c3_probe.py calls 24 >> $O/calls.txt 2>> $O/calls.err
-STARKPERP_TIMELINE=1 python tools/c3_probe.py calls 6 > /dev/null 2> $O/host_timeline.txt
+STARKPERP_TIMELINE=1 python tools/c3_probe.py calls 8 > /dev/null 2> $O/host_timeline.txt
+sed -i "/amdgpu.ids/d" $O/host_timeline.txt
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python $R/tools/c3_probe.py one > $O/one.txt 2> $O/one.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $O/pmc -o p -- python $R/tools/c3_probe.py pmc > $O/pmc.txt 2> $O/pmc.err
