@@ -37,15 +37,25 @@ namespace sp {
 #endif
 constexpr int TILE_LOG = SP_NTT_TILE_LOG;
 constexpr int TILE = 1 << TILE_LOG;
-#ifndef SP_NTT_THREADS
-#define SP_NTT_THREADS (1 << (SP_NTT_TILE_LOG - 3))
-#endif
-constexpr int NTT_THREADS = SP_NTT_THREADS;  // threads x 8 felts in registers = one radix-8 step of a tile
-constexpr size_t NTT_LDS_BYTES = (size_t)NL * TILE * sizeof(int32_t);
+// threads of a block = tile / 8: threads x 8 felts in registers = one radix-8 step of a tile (ntt_threads_of below)
 #ifndef SP_NTT_STRIDED_MAX
 #define SP_NTT_STRIDED_MAX (SP_NTT_TILE_LOG - 2)  // at least 4 adjacent columns = 128-byte segments
 #endif
 constexpr int NTT_STRIDED_MAX = SP_NTT_STRIDED_MAX;  // stages of a strided pass
+// Round 6: a SECOND tile size for the transforms that take the same number of passes with it.  Tiles of 1024 felts
+// (36 KiB of LDS, 128 threads) put FOUR independent blocks on a CU instead of two: the load / compute / store phases of
+// a tile do not overlap inside a block (profiles/r06_ntt_pass_ceiling.txt: the data path alone is 0.85 of the 2.17 ms
+// of a 4-column LDE), they overlap across blocks, and four blocks overlap better than two - the three forward passes
+// over 2^22 points take 1.62 ms instead of 1.75.  A 2^20-point transform needs 11 + 9 stages = two passes with the big
+// tile and three with the small one, so it keeps the big one: pick_tile_log() chooses per transform.
+// -DSP_NTT_SMALL_TILE_LOG=0 builds the single-tile plan of rounds 3 - 5.
+#ifndef SP_NTT_SMALL_TILE_LOG
+#define SP_NTT_SMALL_TILE_LOG 10
+#endif
+constexpr int SMALL_TILE_LOG = SP_NTT_SMALL_TILE_LOG;
+constexpr int ntt_threads_of(int tile_log) { return 1 << (tile_log - 3); }
+constexpr size_t ntt_lds_bytes_of(int tile_log) { return (size_t)NL * ((size_t)1 << tile_log) * sizeof(int32_t); }
+constexpr int ntt_strided_max_of(int tile_log) { return tile_log == TILE_LOG ? NTT_STRIDED_MAX : tile_log - 2; }
 
 // Slot of tile element e inside a limb plane: bank bit i = e_i ^ e_(i+3).  The lanes of a wave walk the tile
 // with their six index bits at e3..e8 (radix-8 group of stages 0-2), at e0..e2 + e6..e8 (stages 3-5), at e0..e5
@@ -53,17 +63,19 @@ constexpr int NTT_STRIDED_MAX = SP_NTT_STRIDED_MAX;  // stages of a strided pass
 // i.e. two lanes per bank - what a wave64 access costs anyway.  The plain layout put the first two patterns on
 // 8 banks (68 % of the LDS cycles of the contiguous passes were bank conflicts, SQ_LDS_BANK_CONFLICT).
 __device__ __forceinline__ int lds_slot(int e) { return e ^ ((e >> 3) & 31); }
+template <int TILE_>
 __device__ __forceinline__ fe lds_get(const int32_t* lds, int e) {
   const int s = lds_slot(e);
   fe v;
 #pragma unroll
-  for (int l = 0; l < NL; ++l) v.l[l] = lds[l * TILE + s];
+  for (int l = 0; l < NL; ++l) v.l[l] = lds[l * TILE_ + s];
   return v;
 }
+template <int TILE_>
 __device__ __forceinline__ void lds_put(int32_t* lds, int e, const fe& v) {
   const int s = lds_slot(e);
 #pragma unroll
-  for (int l = 0; l < NL; ++l) lds[l * TILE + s] = v.l[l];
+  for (int l = 0; l < NL; ++l) lds[l * TILE_ + s] = v.l[l];
 }
 __device__ __forceinline__ fe ld_fe_packed(const uint64_t* p) { return fe_unpack(ld_u256(p)); }
 // The tile kernel streams: every felt of a pass is read once and written once, 1 GB per pass of a 4-column 2^22-point
@@ -160,7 +172,7 @@ __device__ __forceinline__ void ntt_stage(fe (&x)[1 << LOGR], int (&B)[1 << LOGR
     }
   }
 }
-template <int LOGR, bool DIT>
+template <int LOGR, bool DIT, int TILE_>
 __device__ __forceinline__ void ntt_group(int32_t* lds, const ntt_geom& g, int grp, int t_lo, bool unit_low) {
   constexpr int R = 1 << LOGR;
   const int c = grp & ((1 << g.log_c) - 1), kk = grp >> g.log_c;
@@ -181,7 +193,7 @@ __device__ __forceinline__ void ntt_group(int32_t* lds, const ntt_geom& g, int g
   int B[R];
 #pragma unroll
   for (int m = 0; m < R; ++m) {
-    x[m] = lds_get(lds, e0 + m * estep);
+    x[m] = lds_get<TILE_>(lds, e0 + m * estep);
     B[m] = 1;
   }
   if constexpr (DIT) {
@@ -198,7 +210,7 @@ __device__ __forceinline__ void ntt_group(int32_t* lds, const ntt_geom& g, int g
     B[0] = 1;
   }
 #pragma unroll
-  for (int m = 0; m < R; ++m) lds_put(lds, e0 + m * estep, B[m] > 1 ? fe_carry(x[m]) : x[m]);
+  for (int m = 0; m < R; ++m) lds_put<TILE_>(lds, e0 + m * estep, B[m] > 1 ? fe_carry(x[m]) : x[m]);
 }
 
 // One pass = `nst` consecutive radix-2 stages on tiles of 2^log_e felts (2^log_t coupled points x
@@ -215,12 +227,14 @@ __device__ __forceinline__ void ntt_group(int32_t* lds, const ntt_geom& g, int g
 // for 0 otherwise (zero padding in bit-reversed positions), and the first pad_log_b DIT stages - which
 // only copy that value over its 2^pad_log_b slots (a + w * 0) - are skipped: the padded column is
 // never written to HBM.
-__global__ void __launch_bounds__(NTT_THREADS)
+template <int TL>
+__global__ void __launch_bounds__(1 << (TL - 3))
 ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int log_e, int log_t,
                 int log_lo, int nst, int t_first, int dit, const uint64_t* __restrict__ tw, int log_tw,
                 int use_scale, fe scale, size_t in_col_stride, size_t out_col_stride,
                 const uint64_t* __restrict__ pad_G, int pad_log_b, int pad_log_n) {
-  extern __shared__ int32_t lds[];  // NL planes of TILE int32 (NTT_LDS_BYTES: above the 64 KiB a static array may have)
+  constexpr int TILE = 1 << TL, NTT_THREADS = TILE / 8;  // (shadow the file-level constants: this instantiation's tile)
+  extern __shared__ int32_t lds[];  // NL planes of TILE int32 (72 KiB for the big tile: above the 64 KiB a static array may have)
   in += 4 * in_col_stride * blockIdx.y;    // grid.y = column: independent columns share one launch
   out += 4 * out_col_stride * blockIdx.y;
   const int E = 1 << log_e;
@@ -237,7 +251,7 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
       const size_t j = (base >> pad_log_b) + (size_t)g;
       const size_t c = pad_log_n ? (__brevll((unsigned long long)j) >> (64 - pad_log_n)) : 0;
       const fe v = fe_mul(ld_fe_packed(in + 4 * j), ld_fe_packed(pad_G + 4 * c));
-      for (int q = 0; q < B; ++q) lds_put(lds, (g << pad_log_b) + q, v);
+      for (int q = 0; q < B; ++q) lds_put<TILE>(lds, (g << pad_log_b) + q, v);
     }
     s_begin = pad_log_b < nst ? pad_log_b : nst;
   } else {
@@ -251,12 +265,12 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
         v[q] = ntt_ld(in + 4 * (base | ((size_t)k << log_lo) | (size_t)c));
       }
 #pragma unroll
-      for (int q = 0; q < PER; ++q) lds_put(lds, threadIdx.x + q * NTT_THREADS, fe_unpack(v[q]));
+      for (int q = 0; q < PER; ++q) lds_put<TILE>(lds, threadIdx.x + q * NTT_THREADS, fe_unpack(v[q]));
     } else {
       for (int e = threadIdx.x; e < E; e += NTT_THREADS) {
         const int k = e >> log_c, c = e & (C - 1);
         const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
-        lds_put(lds, e, fe_unpack(ntt_ld(in + 4 * idx)));  // 256-bit input: limbs 0..7 normal, top limb < 2^24
+        lds_put<TILE>(lds, e, fe_unpack(ntt_ld(in + 4 * idx)));  // 256-bit input: limbs 0..7 normal, top limb < 2^24
       }
     }
   }
@@ -272,13 +286,13 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
     const int groups = E >> r;
     for (int grp = threadIdx.x; grp < groups; grp += NTT_THREADS) {
       if (dit) {
-        if (r == 3) ntt_group<3, true>(lds, g, grp, t_lo, unit_low);
-        else if (r == 2) ntt_group<2, true>(lds, g, grp, t_lo, unit_low);
-        else ntt_group<1, true>(lds, g, grp, t_lo, unit_low);
+        if (r == 3) ntt_group<3, true, TILE>(lds, g, grp, t_lo, unit_low);
+        else if (r == 2) ntt_group<2, true, TILE>(lds, g, grp, t_lo, unit_low);
+        else ntt_group<1, true, TILE>(lds, g, grp, t_lo, unit_low);
       } else {
-        if (r == 3) ntt_group<3, false>(lds, g, grp, t_lo, unit_low);
-        else if (r == 2) ntt_group<2, false>(lds, g, grp, t_lo, unit_low);
-        else ntt_group<1, false>(lds, g, grp, t_lo, unit_low);
+        if (r == 3) ntt_group<3, false, TILE>(lds, g, grp, t_lo, unit_low);
+        else if (r == 2) ntt_group<2, false, TILE>(lds, g, grp, t_lo, unit_low);
+        else ntt_group<1, false, TILE>(lds, g, grp, t_lo, unit_low);
       }
     }
     __syncthreads();
@@ -288,7 +302,7 @@ ntt_tile_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int
   for (int e = threadIdx.x; e < E; e += NTT_THREADS) {
     const int k = e >> log_c, c = e & (C - 1);
     const size_t idx = base | ((size_t)k << log_lo) | (size_t)c;
-    fe v = lds_get(lds, e);
+    fe v = lds_get<TILE>(lds, e);
     if (use_scale & 1) v = fe_mul(v, scale);
     if (use_scale & 2) {
       // Between the passes of one transform the felt only has to FIT 256 bits: take floor(v / 2^251) - 1 multiples
@@ -1149,10 +1163,38 @@ static int ntt_lds_ready() {
   std::lock_guard<std::mutex> lk(mu);
   auto it = done.find(dev);
   if (it != done.end()) return it->second;
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)NTT_LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel<TILE_LOG>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ntt_lds_bytes_of(TILE_LOG));
+  if (e == hipSuccess && SMALL_TILE_LOG > 0 && SMALL_TILE_LOG != TILE_LOG && ntt_lds_bytes_of(SMALL_TILE_LOG > 0 ? SMALL_TILE_LOG : TILE_LOG) > 65536)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_tile_kernel<(SMALL_TILE_LOG > 0 ? SMALL_TILE_LOG : TILE_LOG)>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ntt_lds_bytes_of(SMALL_TILE_LOG > 0 ? SMALL_TILE_LOG : TILE_LOG));
   return done[dev] = (e == hipSuccess ? SP_OK : hip_fail(e, "hipFuncSetAttribute(ntt_tile_kernel, MaxDynamicSharedMemorySize)"));
 }
+// Passes a transform of 2^log_n points takes with tiles of 2^tile_log felts: one contiguous pass + strided passes.
+static int ntt_passes(int log_n, int tile_log) {
+  if (log_n <= tile_log) return 1;
+  const int smax = ntt_strided_max_of(tile_log);
+  return 1 + (log_n - tile_log + smax - 1) / smax;
+}
+// The small tile wherever it costs no extra pass (four blocks per CU overlap their phases better than two), the big
+// one otherwise.  pad_log_b: the LDE's zero padding must fit the contiguous pass.
+static int pick_tile_log(int log_n, int pad_log_b) {
+  if (SMALL_TILE_LOG <= 0 || SMALL_TILE_LOG >= TILE_LOG) return TILE_LOG;
+  if (log_n <= SMALL_TILE_LOG) return TILE_LOG;  // one pass either way: rounds 3 - 5's kernel
+  if (pad_log_b > SMALL_TILE_LOG) return TILE_LOG;
+  return ntt_passes(log_n, SMALL_TILE_LOG) <= ntt_passes(log_n, TILE_LOG) ? SMALL_TILE_LOG : TILE_LOG;
+}
+// One launch of the tile kernel for the chosen tile size.
+#define SP_NTT_LAUNCH(TLV, GRID, ...)                                                                                  \
+  do {                                                                                                                 \
+    if ((TLV) == TILE_LOG)                                                                                             \
+      hipLaunchKernelGGL((ntt_tile_kernel<TILE_LOG>), GRID, dim3(ntt_threads_of(TILE_LOG)), ntt_lds_bytes_of(TILE_LOG), \
+                         st, __VA_ARGS__);                                                                             \
+    else                                                                                                               \
+      hipLaunchKernelGGL((ntt_tile_kernel<(SMALL_TILE_LOG > 0 ? SMALL_TILE_LOG : TILE_LOG)>), GRID,                    \
+                         dim3(ntt_threads_of(SMALL_TILE_LOG > 0 ? SMALL_TILE_LOG : TILE_LOG)),                         \
+                         ntt_lds_bytes_of(SMALL_TILE_LOG > 0 ? SMALL_TILE_LOG : TILE_LOG), st, __VA_ARGS__);           \
+  } while (0)
 static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse, int dit, int use_scale,
                       fe scale, hipStream_t st, unsigned ncols = 1, size_t in_col_stride = 0,
                       size_t out_col_stride = 0, const uint64_t* pad_G = nullptr, int pad_log_b = 0) {
@@ -1163,23 +1205,25 @@ static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse,
   if (rc != SP_OK) return rc;
   if (log_n == 0) {
     // single point: (optionally) scale
-    hipLaunchKernelGGL(ntt_tile_kernel, dim3(1, ncols), dim3(NTT_THREADS), NTT_LDS_BYTES, st, in, out, 0, 0, 0, 0, 0, dit, tw, 1,
-                       use_scale, scale, in_col_stride, out_col_stride, (const uint64_t*)nullptr, 0, 0);
+    SP_NTT_LAUNCH(TILE_LOG, dim3(1, ncols), in, out, 0, 0, 0, 0, 0, dit, tw, 1, use_scale, scale, in_col_stride, out_col_stride,
+                  (const uint64_t*)nullptr, 0, 0);
     SP_HIP(hipGetLastError());
     return SP_OK;
   }
-  // pass plan: local pass covers the low min(TILE_LOG, log_n) stages; the rest in strided passes of <= NTT_STRIDED_MAX
+  // pass plan: local pass covers the low min(tile, log_n) stages; the rest in strided passes of <= the tile's maximum
   struct Pass { int log_e, log_t, log_lo, nst, t_first; };
   std::vector<Pass> plan;
-  const int local = log_n < TILE_LOG ? log_n : TILE_LOG;
+  const int tile_log = pick_tile_log(log_n, pad_log_b);
+  const int strided_max = ntt_strided_max_of(tile_log);
+  const int local = log_n < tile_log ? log_n : tile_log;
   const int rest = log_n - local;
-  const int npass = (rest + NTT_STRIDED_MAX - 1) / NTT_STRIDED_MAX;
+  const int npass = (rest + strided_max - 1) / strided_max;
   std::vector<Pass> strided;
   int lo = local;
   for (int pi = 0; pi < npass; ++pi) {
     const int cnt = (rest - (lo - local) + (npass - pi) - 1) / (npass - pi);
     Pass ps;
-    ps.log_e = TILE_LOG;
+    ps.log_e = tile_log;
     ps.log_t = cnt;
     ps.log_lo = lo;
     ps.nst = cnt;
@@ -1203,9 +1247,9 @@ static int ntt_column(const uint64_t* in, uint64_t* out, int log_n, int inverse,
     const bool first = pi == 0, last = pi + 1 == plan.size();
     const unsigned blocks = (unsigned)(((size_t)1 << log_n) >> ps.log_e);
     const int pb = first ? pad_log_b : 0;
-    hipLaunchKernelGGL(ntt_tile_kernel, dim3(blocks, ncols), dim3(NTT_THREADS), NTT_LDS_BYTES, st, src, out, ps.log_e, ps.log_t,
-                       ps.log_lo, g_ntt_probe_copy ? 0 : ps.nst, ps.t_first, dit, tw, log_n, last ? (use_scale ? 1 : 0) : (g_ntt_lazy_store ? 2 : 0), scale, src_stride,
-                       out_col_stride, pb ? pad_G : (const uint64_t*)nullptr, pb, pb ? log_n - pad_log_b : 0);
+    SP_NTT_LAUNCH(tile_log, dim3(blocks, ncols), src, out, ps.log_e, ps.log_t, ps.log_lo, g_ntt_probe_copy ? 0 : ps.nst, ps.t_first, dit,
+                  tw, log_n, last ? (use_scale ? 1 : 0) : (g_ntt_lazy_store ? 2 : 0), scale, src_stride, out_col_stride,
+                  pb ? pad_G : (const uint64_t*)nullptr, pb, pb ? log_n - pad_log_b : 0);
     src = out;
     src_stride = out_col_stride;
   }
