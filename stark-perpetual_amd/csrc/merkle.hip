@@ -607,10 +607,13 @@ static int tree_update_locked(SparseTree& t, const uint64_t* keys, const uint64_
     tl_mark("tree: library lock taken");
     rc = get_scratch_public(n, s, st);
     if (rc != SP_OK) return rc;
+    tl_mark("tree: scratch");
     SP_HIP(hipMemsetAsync(s.flag, 0, sizeof(unsigned), st));
+    tl_mark("tree: flag cleared");
     const std::vector<uint64_t>* emp = nullptr;
     rc = empty_roots(t.empty_leaf, s, &emp);
     if (rc != SP_OK) return rc;
+    tl_mark("tree: empty roots");
     // empty roots + leaves are adjacent in the work buffer (d_emp, then the level-0 values at the start of d_felts):
     // one copy; the keys a second one.  Small updates go through the tree's page-locked buffer (PinnedBuffer).
     const size_t in_bytes = emp_bytes + n * 32 + n * 8;
