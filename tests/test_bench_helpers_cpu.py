@@ -233,3 +233,51 @@ def test_process_group_report_over_gloo(tmp_path):
     assert info["rccl_version"] is None  # gloo
     for r in info["ranks"]:  # no GPU here: either a full entry or the degraded one
         assert "error" in r or r["window_bits"] == 21
+
+
+def test_plan_splits_steps_into_the_fewest_even_calls():
+    from benchlib import merkle
+    assert merkle.plan(20, 64) == [20] and merkle.plan(128, 64) == [64, 64] and merkle.plan(130, 64) == [44, 43, 43]
+    assert merkle.plan(0, 64) == [] and merkle.plan(5, 1) == [1] * 5
+    for k, cap in ((20, 64), (77, 16), (1000, 64)):
+        p = merkle.plan(k, cap)
+        assert sum(p) == k and max(p) <= cap and max(p) - min(p) <= 1 and len(p) == -(-k // cap)
+
+
+def test_kernel_roofline_arithmetic_from_a_canned_measurement():
+    """The roofline object of the headline kernel from (total ms, launches, hashes) of sp_profile_end: achieved =
+    instr_per_hash x hashes / 64 / time, frac against 1024 SIMDs x 2.4 GHz / c_mix, the held-clock variant, HBM from the
+    96 algorithmic bytes per hash, whole_region priced at the whole forest's measured instruction count."""
+    from benchlib import merkle
+    launches, hashes_per_launch, avg_us = 3562, 491520, 423.5
+    prof = (launches * avg_us / 1e3, launches, launches * hashes_per_launch)
+    r = merkle.kernel_roofline(prof, 26, roofline.merkle_config_key(20, [20], 2, 26), 7.9e8, 2330.0, 0.75)
+    per_hash = roofline.valu_counts(26)[0]
+    rate = hashes_per_launch / (avg_us * 1e-6)
+    assert r["bound"] == "valu_issue" and r["instr_per_hash"] == per_hash
+    assert r["achieved"] == pytest.approx(rate * per_hash / 64.0) and r["avg_launch_us"] == pytest.approx(avg_us)
+    assert r["peak"] == pytest.approx(1024 * 2.4e9 / roofline.valu_cycles_per_instr())
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.7 < r["frac"] < 0.9
+    assert r["frac_at_held_clock"] == pytest.approx(r["frac"] * 2400.0 / 2330.0)
+    assert r["hbm"]["achieved"] == pytest.approx(96 * rate / 1e9) and r["hbm"]["frac"] == pytest.approx(96 * rate / 1e9 / 8000.0)
+    w = r["whole_region"]
+    f = roofline.forest_instr_per_hash(26)
+    assert w["instr_per_hash"] == (f[0] if f else per_hash + roofline.valu_counts(26)[1])
+    assert w["achieved"] == pytest.approx(7.9e8 * w["instr_per_hash"] / 64.0) and "held_clock_mhz" not in w
+    slim = line.slim_roofline(r, 96 * hashes_per_launch)
+    assert slim["kernel"] == "ped_accumulate_kernel" and slim["algorithmic_bytes_per_launch"] == 96 * hashes_per_launch
+    assert slim["whole_region"]["frac"] == w["frac"]
+
+
+def test_c3_roofline_uses_live_rates_where_given():
+    c = roofline.c3_roofline({"verify_keyed": 2.4e8, "verify_ladder": 4.5e7, "verify_keyed_2p18": 3.3e8})
+    if c is None:
+        pytest.skip("no C3 counter file committed yet")
+    k = c["verify_keyed"]
+    assert k["rate_is"].startswith("live") and k["achieved"] == pytest.approx(k["instr_per_item"] * 2.4e8 / 64.0)
+    assert k["frac"] == pytest.approx(k["achieved"] / c["peak"]) and k["waves_per_simd"] == 1.0
+    assert c["verify_keyed_2p18"]["frac"] == pytest.approx(k["frac"] * 3.3e8 / 2.4e8)
+    assert "verify_ladder_2p18" not in c  # no live rate given: not invented
+    for key in ("message_hash_chains", "tree_paths", "verify_keyed_4096"):
+        assert c[key]["rate_is"].startswith("the counter pass") and 0 < c[key]["frac"] < 1
+        assert 1.5 < c[key]["ns_per_dependent_instr"] < 6
