@@ -405,6 +405,31 @@ static int make_plan(int log2e, PedPlan& p) {
   return SP_OK;
 }
 
+// The HIP runtime sets something up for sizeable asynchronous copies ONCE per process, some tens of copies in: the
+// ~43rd 128-KiB hipMemcpyAsync of a process stalls its caller for 6 - 7 ms (profiles/r06_copy_path_warmup_ubench.txt:
+// reproduced with torch tensors alone).  An exchange's first order batches met it around their sixth call, inside
+// sp_order_batch's tree update.  Initialisation already costs 0.1 s and more: run those copies here (64 x 128 KiB each
+// way through a page-locked buffer, ~8 ms, best effort - every failure is ignored).  STARKPERP_NO_COPY_WARMUP=1 skips it.
+static void warm_copy_path() {
+  static bool done = false;  // once per process (init_locked runs under the library lock)
+  if (done || getenv("STARKPERP_NO_COPY_WARMUP")) return;
+  done = true;
+  const size_t bytes = 128 << 10;
+  void *h = nullptr, *d = nullptr;
+  if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+  memset(h, 0, bytes);
+  for (int i = 0; i < 64; ++i) {
+    if (hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, 0) != hipSuccess) break;
+    if (hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, 0) != hipSuccess) break;
+    if ((i & 15) == 15 && hipStreamSynchronize(0) != hipSuccess) break;
+  }
+  (void)hipStreamSynchronize(0);
+  (void)hipGetLastError();
+  (void)hipFree(d);
+  (void)hipHostFree(h);
+}
+
 static int init_locked(Context& c, int device, int window_bits) {
   if (c.ready) return SP_OK;
   int ndev = 0;
@@ -534,6 +559,7 @@ static int init_locked(Context& c, int device, int window_bits) {
       c.table_bytes += (size_t)63 * 16 * sizeof(aff_packed);
     }
   }
+  warm_copy_path();
   c.ready = true;
   return SP_OK;
 }

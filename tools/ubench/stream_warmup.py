@@ -2,7 +2,7 @@
 """Does a NEW HIP stream stall once after a fixed number of operations?  (Round 6: one sp_order_batch call among the first
 ten of a process takes 7 - 15 ms inside the runtime's enqueue on the tree's own stream, at a fixed operation count.)
 Enqueue `n` tiny operations on a fresh stream, host-time each enqueue, print the slow ones.
-    python tools/ubench/stream_warmup.py [n=1200] [kind=kernel|memset|copy]"""
+    python tools/ubench/stream_warmup.py [n=1200] [kind=kernel|memset|copy|copy128k|mixed]"""
 import sys
 import time
 
@@ -15,6 +15,9 @@ def main():
     dev = torch.device("cuda", 0)
     x = torch.zeros(1024, device=dev)
     h = torch.zeros(1024).pin_memory()
+    xb = torch.zeros(32768, device=dev)          # 128 KiB
+    hb = torch.zeros(32768).pin_memory()
+    hp = torch.zeros(32768)                      # pageable
     torch.cuda.synchronize()
     for trial in range(3):
         st = torch.cuda.Stream(device=dev)
@@ -26,8 +29,15 @@ def main():
                     x.add_(1.0)
                 elif kind == "memset":
                     x.zero_()
-                else:
+                elif kind == "copy":
                     x.copy_(h, non_blocking=True)
+                elif kind == "copy128k":
+                    xb.copy_(hb, non_blocking=True)
+                else:  # mixed: what one sp_order_batch call does to the copy engines
+                    xb.copy_(hb, non_blocking=True)
+                    hb.copy_(xb, non_blocking=True)
+                    xb.copy_(hp, non_blocking=True)
+                    xb.add_(1.0)
                 if i % 32 == 31:
                     st.synchronize()  # like an update: a burst of operations, then a wait
                 dt = time.perf_counter() - t0
