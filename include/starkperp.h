@@ -78,7 +78,10 @@ extern "C" {
 /* Selects the HIP device and builds the window tables of the Pedersen constant points
  * (signature.py:43 CONSTANT_POINTS; table structure nothing_up_my_sleeve_gen.py:88-90) and of
  * EC_GEN (signature.py:56) in HBM.  window_bits = 0 picks the default (21: 2^20 + 22 x 2^21 Pedersen entries + 12 x 2^21
- * EC_GEN entries, 64 B each = 4.3 GiB of tables).  Idempotent. */
+ * EC_GEN entries, 64 B each = 4.3 GiB of tables; 26 = 75 GiB, 19 entries per hash, ~15 % faster hashing: what the
+ * benchmark runs with).  The first sp_init of a process also runs 64 asynchronous 128-KiB copies each way (~8 ms):
+ * the HIP runtime takes a one-time 6 - 7 ms step at about the 43rd sizeable copy of a process, which would
+ * otherwise land inside a caller's batch (STARKPERP_NO_COPY_WARMUP=1 skips it).  Idempotent. */
 int sp_init(int device, int window_bits);
 /* Several devices in one process (the SURVEY 8(b) shape `sp_init(n_devices, device_ids)`): one context - its own
  * window tables - per entry of device_ids; context 0 is the PRIMARY.  What runs where:
@@ -181,7 +184,13 @@ int sp_tree_root(int tree, uint64_t* root);
  * x-only keys) -> order id = bits [id_shift, id_shift + 64) of z (187 for the 251-bit message: the top 64 bits) ->
  * update of the orders tree `tree` with leaves[i] at order id i.  Verification and tree hashing overlap on the
  * device; the new nodes are committed only when every signature verified, otherwise *tree_status =
- * SP_TREE_NOT_COMMITTED and new_root = old_root.  Two orders with one id: SP_ERR_BAD_ARGUMENT. */
+ * SP_TREE_NOT_COMMITTED and new_root = old_root.  Two orders with one id: SP_ERR_BAD_ARGUMENT.
+ * Host side: the verification runs on a thread of the call's own (spawned as soon as the message hashes are back,
+ * parked until the tree update - the critical path - has enqueued its levels; joined before the call returns);
+ * 4096 orders on a tree that holds state: 1.75 - 1.85 ms median, p90 within 7 %, against 1.51 ms of dependent
+ * hashing (3 chain links + 64 tree levels; DESIGN.md 4.2, profiles/r06_c3_timeline.txt).  A tree's slot table that
+ * must grow is sized for four times the need and grows without a device-wide wait; STARKPERP_TIMELINE=1 prints
+ * the host-side marks of every call to stderr. */
 int sp_order_batch(const uint64_t* words, size_t depth, size_t n, const uint64_t* r, const uint64_t* s,
                    const uint64_t* qx, const uint64_t* qy, int tree, const uint64_t* leaves, unsigned id_shift,
                    uint64_t* z_out, uint8_t* verdicts, uint64_t* old_root, uint64_t* new_root, uint8_t* tree_status);

@@ -12,8 +12,8 @@
 // fe_mul(plain, constant R) = plain * constant - the R of the reduction cancels against the R of the
 // constant (round 1 paid 13 of ~45 multiplications per composition point, 3 of 6 per fold and 2 per
 // transform element for conversions).  Algorithmic bytes: an NTT pass reads and writes each felt once
-// (64 B per element per pass); 2^22 points take 3 passes (9 + 2 strided stages, then 11 stages on a
-// contiguous 2048-point tile in LDS).
+// (64 B per element per pass); 2^22 points take 3 passes (two strided ones of 6 stages each and one of 10 stages on
+// a contiguous 1024-felt tile in LDS; 2^20 points 2 passes with the 2048-felt tile: pick_tile_log below).
 #include <cstring>
 #include <map>
 #include <mutex>
