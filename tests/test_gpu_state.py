@@ -255,7 +255,9 @@ def test_library_tree_grows_through_three_tables_without_losing_a_node():
     """Round 6 growth policy (csrc/merkle.hip tree_reserve): a table that must grow is sized for four times the need,
     the rehash is enqueued on the tree's stream and the OLD table is retired, not freed, until the next growth.  48
     small batches take a fresh tree from its first 2^16-slot table through two growths (the second one frees the table
-    retired by the first): every root equals the Python tree's, and keys written before either growth are still there."""
+    retired by the first).  Checked: every old root handed back is the previous new root; the final root equals the
+    root of ONE from-scratch multi-update of everything written - on the device (sp_merkle_sparse_root, a different
+    code path) and in the Python tree with the C comparator's hash; keys written before either growth are still there."""
     import random
     from oracle import cref
     from starkperp import state
@@ -265,9 +267,8 @@ def test_library_tree_grows_through_three_tables_without_losing_a_node():
 
     rng = random.Random(61)
     lib_tree = state.LibrarySparseTree(64, 0)
-    ref_tree = state.SparseMerkleTree(64, 0, hash_many=oracle_hash_many)
     first = {rng.randrange(2**64): rng.randrange(1, P) for _ in range(50)}
-    assert lib_tree.update(first) == ref_tree.update(first)
+    _, root = lib_tree.update(first)
     written = dict(first)
     for r in range(47):
         mods = {rng.randrange(2**64): rng.randrange(1, P) for _ in range(50)}
@@ -275,10 +276,14 @@ def test_library_tree_grows_through_three_tables_without_losing_a_node():
             for k in rng.sample(list(first), 5):
                 mods[k] = rng.randrange(1, P)
         written.update(mods)
-        assert lib_tree.update(mods) == ref_tree.update(mods), r
-    keys = list(written)
-    assert lib_tree.get_many(keys) == [written[k] for k in keys]
-    assert lib_tree.get_many(keys[:20]) == ref_tree.get_many(keys[:20])
+        old, new = lib_tree.update(mods)
+        assert old == root and new != root, r
+        root = new
+    keys = sorted(written)
+    assert lib_tree.root == root and lib_tree.get_many(keys) == [written[k] for k in keys]
+    assert root == state.orders_tree_root(written, 64)  # one from-scratch multi-update on the device
+    ref_tree = state.SparseMerkleTree(64, 0, hash_many=oracle_hash_many)
+    assert ref_tree.update(written)[1] == root            # and on the CPU: 64 level calls instead of 48 x 64
     lib_tree.close()
 
 
@@ -334,6 +339,62 @@ def test_order_batch_in_one_call_matches_the_separate_calls():
         t.join()
     assert got["a"] == got["b"] and tree.root == twin.root
     tree.close(), twin.close()
+
+
+def test_order_batch_error_paths_release_the_verifier():
+    """Round 6: sp_order_batch parks its verifier thread at a gate until the tree update has enqueued its levels.
+    Every way out of the call must open that gate and join the thread - a path that forgets would hang the caller.
+    Each case runs under a watchdog: an unknown tree handle (the tree fails before it enqueues anything), two orders
+    with one id (refused after the verifier was spawned), a leaf out of range (detected on the device, 64 levels
+    later, nothing committed), and a good batch afterwards on the same tree."""
+    import threading
+    import numpy as np
+    import workloads as wl
+    from starkperp import batch, batch_np as bn, perpetual_messages as pm, state
+    orders = wl.limit_orders(256, seed=31)
+    keys = wl.private_keys(32, seed=32)
+    pubs = batch.public_keys_many(keys)
+    args = [wl.order_args(o) for o in orders]
+    words = np.stack([bn.felts_from_ints(col) for col in zip(*[pm._limit_order_words(*a) for a in args])])
+    zs = pm.limit_order_msgs_many(args)
+    sigs = batch.sign_many([z % 2**251 for z in zs], [keys[o["key_index"] % 32] for o in orders])
+    r, s = bn.felts_from_ints([a for a, _ in sigs]), bn.felts_from_ints([b for _, b in sigs])
+    qx = bn.felts_from_ints([pubs[o["key_index"] % 32][0] for o in orders])
+    leaves = bn.felts_from_ints([o["amount_synthetic"] + 1 for o in orders])
+    tree = state.LibrarySparseTree(64, 0)
+    tree.update({9: 9})
+    root0 = tree.root
+
+    def guarded(fn):
+        box = {}
+
+        def run():
+            try:
+                box["value"] = fn()
+            except BaseException as e:  # noqa: BLE001 - the outcome is inspected by the caller
+                box["error"] = e
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        t.join(120)
+        assert not t.is_alive(), "sp_order_batch did not return: the verifier was left at its gate"
+        return box
+
+    class Ghost:  # a handle the library never issued
+        _handle = 987654
+    out = guarded(lambda: bn.order_batch(words, r, s, qx, Ghost(), leaves))
+    assert "error" in out and tree.root == root0
+    dup = np.concatenate([words[:, :4], words[:, :1]], axis=1)
+    pick = [0, 1, 2, 3, 0]
+    out = guarded(lambda: bn.order_batch(dup, r[pick], s[pick], qx[pick], tree, leaves[pick]))
+    assert "error" in out and tree.root == root0
+    bad_leaves = leaves.copy()
+    bad_leaves[5] = bn.felts_from_ints([P])[0]  # leaf == p: out of range, found by the hash kernel
+    out = guarded(lambda: bn.order_batch(words, r, s, qx, tree, bad_leaves))
+    assert "error" in out and tree.root == root0
+    out = guarded(lambda: bn.order_batch(words, r, s, qx, tree, leaves))
+    z, verdicts, old, new, committed = out["value"]
+    assert committed and old == root0 and new == tree.root != root0 and verdicts.tolist() == [1] * 256
+    tree.close()
 
 
 def test_order_batch_refuses_a_message_hash_of_2p251_or_more():
